@@ -1,0 +1,135 @@
+/*
+ * pea.h — C ABI of the MI355X-native embedding -> affinity hot path.
+ *
+ * One shared library (libpea_hip.so, built by hipcc for gfx950) exports exactly the
+ * entry points declared here.  Every data pointer is a DEVICE pointer owned by the
+ * caller; the library allocates nothing, keeps no global state, never synchronises the
+ * host, and launches on the HIP stream it is handed (`void *stream` is a hipStream_t;
+ * NULL = the default stream).  No torch types appear in any signature.
+ *
+ * What each entry point replaces in the reference (weih527/Pixel-Embedded-Affinity):
+ *
+ *   pea_affinity_infer  <- scripts_cvppp/loss/loss_embedding_mse.py:58-66   embedding2affs
+ *                          scripts_ac3ac4/loss/loss_embedding_mse.py:54-67  inf_embedding_loss_norm1
+ *                          scripts_ac3ac4/loss/loss_embedding_mse.py:212-234 inf_embedding_loss_norm5
+ *   pea_affinity_fwd    <- scripts_cvppp/loss/loss_embedding_mse.py:18-47   embedding_loss
+ *                          scripts_cvppp/loss/loss_embedding_mse.py:79-95   ema_embedding_loss
+ *                          scripts_ac3ac4/loss/loss_embedding_mse.py:7-27   embedding_loss_norm1
+ *                          scripts_ac3ac4/loss/loss_embedding_mse.py:169-194 embedding_loss_norm5
+ *                          scripts_ac3ac4/loss/loss_embedding_mse.py:30-51,263-289 ema_..._norm1/5
+ *                          with loss/loss.py:106-124 WeightedMSE (same in all three script trees) fused in
+ *   pea_affinity_bwd    <- the torch.autograd backward of the functions above
+ *                          (the reference has no explicit backward; loss.backward() at
+ *                          scripts_cvppp/main.py:311, scripts_ac3ac4/main.py:232)
+ *
+ * Tensor layouts (all C-contiguous, exactly the reference's):
+ *   e, e_other, de, de_other : [B, D, Z, Y, X]   f32 (PEA_F32) or f16 (PEA_F16);  2D => Z = 1
+ *   target, weight, affs     : [B, K, Z, Y, X]   f32
+ *   mask                     : [B, K, Z, Y, X]   u8   (NULL => all ones; the 3D path has none)
+ *
+ * Semantics (SURVEY.md section 8a closed forms; n(p) = max(||e(p)||_2, eps), ehat = e / n):
+ *   a_i(p)  = < ehat(p), ehat_other(p + o_i) >          (ehat_other = ehat when e_other == NULL)
+ *   border CIRCULAR : p + o_i taken modulo (Y, X)   (torch.roll, 2D reference path)
+ *   border CROP_ZERO: a_i(p) = 0 and no loss where p + o_i leaves the volume (3D reference path)
+ *   r_i(p)  = a_i(p) * m_i(p) - t_i(p) * m_i(p)
+ *   L_i     = sum_{b,p} w_i(p) * r_i(p)^2 / N_i ,   loss = sum_i lambda_i * L_i
+ *   N_i     = B * X                      (PEA_NORM_BX: the 2D WeightedMSE quirk, pred is [B,H,W])
+ *           = B * prod(dims - |o_i|)     (PEA_NORM_CROPPED: 3D, pred is the cropped [B,1,Z',Y',X'])
+ *           = B * Z * Y * X              (PEA_NORM_FULL)
+ */
+#ifndef PEA_H_
+#define PEA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PEA_ABI_VERSION 1
+#define PEA_MAX_K 32 /* 26-neighbourhood (BASELINE config 4) fits */
+
+/* border modes */
+#define PEA_BORDER_CIRCULAR 0
+#define PEA_BORDER_CROP_ZERO 1
+/* storage dtype of e / de (arithmetic is always f32) */
+#define PEA_F32 0
+#define PEA_F16 1
+/* loss normaliser */
+#define PEA_NORM_BX 0
+#define PEA_NORM_CROPPED 1
+#define PEA_NORM_FULL 2
+/* flags */
+#define PEA_FLAG_RELU_AFFS 1u /* affs output = max(a, 0)  (F.relu(pred), scripts_cvppp/main.py:312) */
+
+/* error codes: 0 = ok, negative = PEA_E_*, positive = a hipError_t from the runtime */
+#define PEA_OK 0
+#define PEA_E_NULL (-1)        /* a required pointer is NULL */
+#define PEA_E_DESC (-2)        /* descriptor field out of range */
+#define PEA_E_UNSUPPORTED (-3) /* valid but not implemented combination */
+#define PEA_E_WORKSPACE (-4)   /* workspace too small / missing */
+#define PEA_E_ALIGN (-5)       /* pointer not aligned to its element size */
+
+typedef struct PeaDesc {
+  int32_t abi;     /* must equal PEA_ABI_VERSION */
+  int32_t ndim;    /* 2 or 3 (informational; 2 requires dims[0] == 1) */
+  int32_t B;       /* batch */
+  int32_t D;       /* embedding channels */
+  int32_t dims[3]; /* Z, Y, X */
+  int32_t K;       /* number of offsets, 1..PEA_MAX_K */
+  int32_t border;  /* PEA_BORDER_* */
+  int32_t dtype;   /* PEA_F32 / PEA_F16 */
+  int32_t norm;    /* PEA_NORM_* */
+  uint32_t flags;  /* PEA_FLAG_* */
+  float eps;       /* clamp of the L2 norm: 1e-12 (F.normalize) or 1e-6 (nn.CosineSimilarity) */
+  int32_t offsets[PEA_MAX_K][3]; /* o_i = (dz, dy, dx); the neighbour of p is p + o_i */
+  float lambda[PEA_MAX_K];       /* per-offset loss weight (affs0_weight on the first channels) */
+  /* batch strides, in elements, of target / weight / mask; 0 = dense (K*Z*Y*X).  Lets the caller pass the
+   * channel slices down1[:, 0:k], [k:2k], [2k:3k] of one packed tensor (scripts_cvppp/main.py:284-287)
+   * without a copy; inside one batch item the [K,Z,Y,X] block must be dense. */
+  int64_t target_bstride, weight_bstride, mask_bstride;
+} PeaDesc;
+
+/* ABI version of the loaded library (== PEA_ABI_VERSION it was built with). */
+int pea_version(void);
+
+/* Static string for an error code returned by any pea_* call. */
+const char *pea_strerror(int code);
+
+/* Host-only check of a descriptor: PEA_OK or PEA_E_DESC / PEA_E_UNSUPPORTED. No GPU needed. */
+int pea_desc_validate(const PeaDesc *desc);
+
+/* Bytes of device scratch pea_affinity_fwd needs for its per-workgroup loss partials. */
+size_t pea_workspace_bytes(const PeaDesc *desc);
+
+/* Inference: affs[B,K,Z,Y,X] only.  e_other may be NULL. */
+int pea_affinity_infer(const PeaDesc *desc, const void *e, const void *e_other, float *affs,
+                       void *stream);
+
+/* Training forward: affs (nullable) and loss_out[1 + K] = { loss, L_0 .. L_{K-1} } (device, f32;
+ * L_i is the un-weighted per-offset loss, i.e. the reference's all_loss list).
+ * Deterministic: per-workgroup partials in `workspace`, reduced in a fixed order. */
+int pea_affinity_fwd(const PeaDesc *desc, const void *e, const void *e_other, const float *target,
+                     const float *weight, const uint8_t *mask, float *affs, float *loss_out,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* Training backward: de = dloss * d(loss)/d(e)  (same dtype/layout as e).  `dloss` is a DEVICE
+ * f32 scalar (autograd's grad_output), so no host sync is needed.  de_other: NULL when the second
+ * operand is detached (convert_consistency_flip, scripts_cvppp/data/data_consistency.py:36),
+ * otherwise receives d(loss)/d(e_other).  Gather form, no atomics, bit-reproducible. */
+int pea_affinity_bwd(const PeaDesc *desc, const void *e, const void *e_other, const float *target,
+                     const float *weight, const uint8_t *mask, const float *dloss, void *de,
+                     void *de_other, void *stream);
+
+/* Vector-Jacobian product of the affinity map alone: de = sum_i d_affs_i * d a_i / d e, for callers
+ * that apply their own criterion to affs in the host framework (the reference passes `criterion`
+ * as an argument, scripts_cvppp/main.py:188-189,284-293, and selects nn.CosineSimilarity for
+ * mode != 'ours', scripts_cvppp/loss/loss_embedding_mse.py:11-13).  d_affs: [B,K,Z,Y,X] f32. */
+int pea_affinity_vjp(const PeaDesc *desc, const void *e, const void *e_other, const float *d_affs,
+                     void *de, void *de_other, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEA_H_ */

@@ -1,0 +1,26 @@
+"""pixel-embedded-affinity_amd -- the MI355X-native embedding -> affinity hot path.
+
+A drop-in for the one data-parallel hot path of weih527/Pixel-Embedded-Affinity: per-pixel embedding
+-> K-offset affinity map -> class-balanced weighted-MSE loss -> gradient, as hand-written HIP for
+gfx950 behind a C ABI (include/pea.h), with this thin Python layer mirroring the reference's own
+function names so its main.py / inference.py call sites only change their import line
+(see INTEGRATION.md).
+
+Import name: the directory is not a valid Python identifier, so load it through
+`__graft_entry__.load_package()` (registers it as `pixel_embedded_affinity_amd`).
+"""
+from . import _lib
+from ._lib import PeaLibraryError, build
+from .affinity_op import AffinityMap, AffinitySpec, FusedAffinityMSE, affinity_infer
+from .loss.loss import WeightedMSE
+from .loss.loss_embedding_mse import ema_embedding_loss, embedding2affs, embedding_loss
+from .loss.loss_embedding_mse_3d import (ema_embedding_loss_norm1, ema_embedding_loss_norm5, embedding_loss_norm1,
+                                         embedding_loss_norm5, inf_embedding_loss_norm1, inf_embedding_loss_norm5)
+from .utils.affinity_ours import gen_offsets, multi_offset
+
+__all__ = [
+    "PeaLibraryError", "build", "AffinityMap", "AffinitySpec", "FusedAffinityMSE", "affinity_infer", "WeightedMSE",
+    "embedding_loss", "ema_embedding_loss", "embedding2affs", "embedding_loss_norm1", "embedding_loss_norm5",
+    "ema_embedding_loss_norm1", "ema_embedding_loss_norm5", "inf_embedding_loss_norm1", "inf_embedding_loss_norm5",
+    "gen_offsets", "multi_offset",
+]

@@ -1,0 +1,107 @@
+"""ctypes binding of libpea_hip.so (the C ABI declared in include/pea.h).
+
+The library is the product: there is NO CPU fallback.  If the shared object is missing or cannot be
+loaded, every op raises PeaLibraryError loudly.  `build()` compiles it in-tree with hipcc for gfx950
+(cross-compiles without a GPU), so the .so travels with the repository snapshot.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libpea_hip.so")
+HEADER = os.path.join(HERE, "..", "include", "pea.h")
+
+PEA_ABI_VERSION = 1
+PEA_MAX_K = 32
+BORDER_CIRCULAR, BORDER_CROP_ZERO = 0, 1
+F32, F16 = 0, 1
+NORM_BX, NORM_CROPPED, NORM_FULL = 0, 1, 2
+FLAG_RELU_AFFS = 1
+
+EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",
+           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_vjp")
+
+
+class PeaLibraryError(RuntimeError):
+    """libpea_hip.so is missing / unloadable, or a pea_* call returned an error."""
+
+
+class PeaDesc(ctypes.Structure):
+    """mirror of `struct PeaDesc` in include/pea.h"""
+    _fields_ = [("abi", ctypes.c_int32), ("ndim", ctypes.c_int32), ("B", ctypes.c_int32),
+                ("D", ctypes.c_int32), ("dims", ctypes.c_int32 * 3), ("K", ctypes.c_int32),
+                ("border", ctypes.c_int32), ("dtype", ctypes.c_int32), ("norm", ctypes.c_int32),
+                ("flags", ctypes.c_uint32), ("eps", ctypes.c_float),
+                ("offsets", (ctypes.c_int32 * 3) * PEA_MAX_K), ("lam", ctypes.c_float * PEA_MAX_K),
+                ("target_bstride", ctypes.c_int64), ("weight_bstride", ctypes.c_int64),
+                ("mask_bstride", ctypes.c_int64)]
+
+
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/pea_hip.hip -> csrc/libpea_hip.so for gfx950."""
+    src = os.path.join(CSRC, "pea_hip.hip")
+    deps = [src, HEADER]
+    if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
+        return SO_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise PeaLibraryError("hipcc not found: cannot build libpea_hip.so")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO_PATH + ".tmp", src]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    os.replace(SO_PATH + ".tmp", SO_PATH)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the library (after torch, so both bind to the same HIP runtime, libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise PeaLibraryError(
+            "%s not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback." % SO_PATH)
+    import torch  # noqa: F401  (loads torch's bundled libamdhip64 first)
+    try:
+        L = ctypes.CDLL(SO_PATH)
+    except OSError as ex:
+        raise PeaLibraryError("cannot load %s: %s" % (SO_PATH, ex))
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise PeaLibraryError("%s does not export %s" % (SO_PATH, name))
+    vp, dp = ctypes.c_void_p, ctypes.POINTER(PeaDesc)
+    L.pea_version.restype = ctypes.c_int
+    L.pea_strerror.restype = ctypes.c_char_p
+    L.pea_strerror.argtypes = [ctypes.c_int]
+    L.pea_desc_validate.restype = ctypes.c_int
+    L.pea_desc_validate.argtypes = [dp]
+    L.pea_workspace_bytes.restype = ctypes.c_size_t
+    L.pea_workspace_bytes.argtypes = [dp]
+    L.pea_affinity_infer.restype = ctypes.c_int
+    L.pea_affinity_infer.argtypes = [dp, vp, vp, vp, vp]
+    L.pea_affinity_fwd.restype = ctypes.c_int
+    L.pea_affinity_fwd.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.pea_affinity_bwd.restype = ctypes.c_int
+    L.pea_affinity_bwd.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pea_affinity_vjp.restype = ctypes.c_int
+    L.pea_affinity_vjp.argtypes = [dp, vp, vp, vp, vp, vp, vp]
+    if L.pea_version() != PEA_ABI_VERSION:
+        raise PeaLibraryError("ABI mismatch: library %d, binding %d" % (L.pea_version(), PEA_ABI_VERSION))
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise PeaLibraryError("%s failed: rc=%d (%s)" % (what, rc, lib().pea_strerror(rc).decode()))

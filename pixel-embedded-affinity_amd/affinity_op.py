@@ -1,0 +1,239 @@
+"""Host side of the hot path: descriptor construction, argument checking, autograd glue.
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); all arithmetic happens in
+libpea_hip.so through the C ABI of include/pea.h.  Nothing in this file has a CPU implementation:
+tensors that are not on a ROCm device raise, and a missing library raises PeaLibraryError.
+
+Reference behaviour mirrored (file:line in the reference tree):
+  * embedding_loss / ema_embedding_loss / embedding2affs      scripts_cvppp/loss/loss_embedding_mse.py:18-95
+  * embedding_loss_norm1/5, ema_*, inf_*                        scripts_ac3ac4/loss/loss_embedding_mse.py:7-289
+  * WeightedMSE normaliser                                      scripts_cvppp/loss/loss.py:112-119
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import PeaDesc
+
+SUPPORTED_TRAIN_D = (4, 8, 16, 32, 64)
+
+
+class AffinitySpec(object):
+    """Everything about one call that is not a tensor."""
+
+    def __init__(self, ndim, offsets, lam, border, norm, eps=1e-12, relu=False):
+        self.ndim = int(ndim)
+        self.offsets = [tuple([0] * (3 - len(o)) + [int(v) for v in o]) for o in offsets]
+        self.K = len(self.offsets)
+        if not 1 <= self.K <= _lib.PEA_MAX_K:
+            raise ValueError("number of offsets must be in 1..%d, got %d" % (_lib.PEA_MAX_K, self.K))
+        self.lam = [1.0] * self.K if lam is None else [float(v) for v in lam]
+        if len(self.lam) != self.K:
+            raise ValueError("lambda list must have one entry per offset")
+        self.border, self.norm, self.eps, self.relu = border, norm, float(eps), bool(relu)
+
+
+def _spatial(e, ndim):
+    if e.dim() != ndim + 2:
+        raise ValueError("embedding must be %s, got shape %s" % ("[B,D,H,W]" if ndim == 2 else "[B,D,Z,Y,X]", tuple(e.shape)))
+    sp = list(e.shape[2:])
+    return [1] * (3 - len(sp)) + sp
+
+
+def _require_gpu(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s is on %s: the affinity path runs on an MI355X only (no CPU fallback)" % (name, t.device))
+
+
+def _embedding_arg(t, name):
+    _require_gpu(t, name)
+    if t.dtype not in (torch.float32, torch.float16):
+        raise TypeError("%s must be float32 or float16, got %s" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _batch_strided(t, name, dtype, shape):
+    """-> (tensor, batch stride in elements).  The [K, spatial...] block of every batch item must be
+    dense; the batch stride itself may be anything (channel slices of a packed tensor)."""
+    _require_gpu(t, name)
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    if t.shape[0] > 1 and not t[0].is_contiguous():
+        t = t.contiguous()
+    elif t.shape[0] == 1 and not t.is_contiguous():
+        t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else 0)
+
+
+def make_desc(spec, e, tstride=0, wstride=0, mstride=0):
+    dims = _spatial(e, spec.ndim)
+    d = PeaDesc()
+    d.abi, d.ndim, d.B, d.D = _lib.PEA_ABI_VERSION, spec.ndim, e.shape[0], e.shape[1]
+    d.dims[:] = dims
+    d.K = spec.K
+    d.border, d.norm, d.eps = spec.border, spec.norm, spec.eps
+    d.dtype = _lib.F16 if e.dtype == torch.float16 else _lib.F32
+    d.flags = _lib.FLAG_RELU_AFFS if spec.relu else 0
+    for i, o in enumerate(spec.offsets):
+        if spec.border == _lib.BORDER_CIRCULAR:  # torch.roll is modular: fold into (-dim, dim)
+            o = tuple(int(v) - dims[a] * int(int(v) / dims[a]) if dims[a] else 0 for a, v in enumerate(o))
+        d.offsets[i][:] = o
+        d.lam[i] = spec.lam[i]
+    d.target_bstride, d.weight_bstride, d.mask_bstride = int(tstride), int(wstride), int(mstride)
+    rc = _lib.lib().pea_desc_validate(ctypes.byref(d))
+    if rc:
+        raise ValueError("invalid affinity descriptor: %s" % _lib.lib().pea_strerror(rc).decode())
+    return d
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _affs_shape(e, K):
+    return (e.shape[0], K) + tuple(e.shape[2:])
+
+
+def affinity_infer(e, e_other, spec):
+    """affs [B,K,...] f32 = pea_affinity_infer (no autograd)."""
+    e = _embedding_arg(e, "embedding")
+    if e_other is not None:
+        e_other = _embedding_arg(e_other, "ema_embedding").to(e.dtype)
+        if e_other.shape != e.shape:
+            raise ValueError("ema_embedding shape %s != embedding shape %s" % (tuple(e_other.shape), tuple(e.shape)))
+    with torch.cuda.device(e.device):
+        d = make_desc(spec, e)
+        affs = torch.empty(_affs_shape(e, spec.K), dtype=torch.float32, device=e.device)
+        _lib.check(_lib.lib().pea_affinity_infer(ctypes.byref(d), _ptr(e.detach()), _ptr(None if e_other is None else e_other.detach()),
+                                                 _ptr(affs), _stream()), "pea_affinity_infer")
+    return affs
+
+
+class FusedAffinityMSE(torch.autograd.Function):
+    """loss, affs, per_offset_losses = f(e, e_other, target, weight, mask): one fwd + one bwd launch."""
+
+    @staticmethod
+    def forward(ctx, e, e_other, target, weight, mask, spec):
+        e_c = _embedding_arg(e, "embedding")
+        o_c = None
+        if e_other is not None:
+            o_c = _embedding_arg(e_other, "ema_embedding").to(e_c.dtype)
+            if o_c.shape != e_c.shape:
+                raise ValueError("ema_embedding shape %s != embedding shape %s" % (tuple(o_c.shape), tuple(e_c.shape)))
+        kshape = _affs_shape(e_c, spec.K)
+        target, ts = _batch_strided(target, "target", torch.float32, kshape)
+        weight, ws = _batch_strided(weight, "weightmap", torch.float32, kshape)
+        ms = 0
+        if mask is not None:
+            if mask.dtype == torch.bool:
+                mask = mask.view(torch.uint8)
+            mask, ms = _batch_strided(mask, "mask", torch.uint8, kshape)
+        for t in (o_c, target, weight, mask):
+            if t is not None and t.device != e_c.device:
+                raise RuntimeError("all operands must live on %s" % e_c.device)
+        with torch.cuda.device(e_c.device):
+            d = make_desc(spec, e_c, ts, ws, ms)
+            L = _lib.lib()
+            affs = torch.empty(kshape, dtype=torch.float32, device=e_c.device)
+            loss_vec = torch.empty(1 + spec.K, dtype=torch.float32, device=e_c.device)
+            wsb = L.pea_workspace_bytes(ctypes.byref(d))
+            work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=e_c.device)
+            _lib.check(L.pea_affinity_fwd(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(target), _ptr(weight), _ptr(mask),
+                                          _ptr(affs), _ptr(loss_vec), _ptr(work), wsb, _stream()), "pea_affinity_fwd")
+        ctx.spec, ctx.desc = spec, d
+        ctx.has_other = o_c is not None
+        ctx.save_for_backward(e_c, o_c, target, weight, mask)
+        loss, per_offset = loss_vec[0], loss_vec[1:]  # views of a buffer that is not itself returned
+        ctx.mark_non_differentiable(affs, per_offset)
+        return loss, affs, per_offset
+
+    @staticmethod
+    def backward(ctx, dloss, _daffs, _dvec):
+        e_c, o_c, target, weight, mask = ctx.saved_tensors
+        want_e = ctx.needs_input_grad[0]
+        want_o = ctx.has_other and ctx.needs_input_grad[1]
+        if not (want_e or want_o):
+            return None, None, None, None, None, None
+        if e_c.shape[1] not in SUPPORTED_TRAIN_D:
+            raise NotImplementedError("backward needs D in %s (got %d); pad the embedding channels" % (SUPPORTED_TRAIN_D, e_c.shape[1]))
+        with torch.cuda.device(e_c.device):
+            dl = dloss.to(device=e_c.device, dtype=torch.float32).contiguous()
+            de = torch.empty_like(e_c)
+            de_o = torch.empty_like(o_c) if want_o else None
+            _lib.check(_lib.lib().pea_affinity_bwd(ctypes.byref(ctx.desc), _ptr(e_c), _ptr(o_c), _ptr(target), _ptr(weight),
+                                                   _ptr(mask), _ptr(dl), _ptr(de), _ptr(de_o), _stream()), "pea_affinity_bwd")
+        return (de if want_e else None), de_o, None, None, None, None
+
+
+class AffinityMap(torch.autograd.Function):
+    """affs = f(e, e_other) with a true vjp, for criteria other than the fused WeightedMSE."""
+
+    @staticmethod
+    def forward(ctx, e, e_other, spec):
+        affs = affinity_infer(e, e_other, spec)
+        e_c = _embedding_arg(e, "embedding")
+        o_c = None if e_other is None else _embedding_arg(e_other, "ema_embedding").to(e_c.dtype)
+        ctx.spec = spec
+        ctx.has_other = o_c is not None
+        ctx.save_for_backward(e_c, o_c)
+        return affs
+
+    @staticmethod
+    def backward(ctx, d_affs):
+        e_c, o_c = ctx.saved_tensors
+        want_e = ctx.needs_input_grad[0]
+        want_o = ctx.has_other and ctx.needs_input_grad[1]
+        if not (want_e or want_o):
+            return None, None, None
+        if ctx.spec.relu:
+            raise NotImplementedError("relu epilogue is inference-only")
+        if e_c.shape[1] not in SUPPORTED_TRAIN_D:
+            raise NotImplementedError("backward needs D in %s (got %d)" % (SUPPORTED_TRAIN_D, e_c.shape[1]))
+        with torch.cuda.device(e_c.device):
+            d = make_desc(ctx.spec, e_c)
+            da = d_affs.to(torch.float32).contiguous()
+            de = torch.empty_like(e_c)
+            de_o = torch.empty_like(o_c) if want_o else None
+            _lib.check(_lib.lib().pea_affinity_vjp(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(da), _ptr(de), _ptr(de_o),
+                                                   _stream()), "pea_affinity_vjp")
+        return (de if want_e else None), de_o, None
+
+
+class LossList(list):
+    """The reference's `all_loss` (a list of K Python floats filled by K `.item()` syncs,
+    scripts_cvppp/loss/loss_embedding_mse.py:41) without the syncs: a list whose floats are fetched
+    from the device tensor on first access."""
+
+    def __init__(self, dev_tensor):
+        super(LossList, self).__init__()
+        self.tensor = dev_tensor
+        self._filled = False
+
+    def _fill(self):
+        if not self._filled:
+            self._filled = True
+            super(LossList, self).extend(self.tensor.tolist())
+
+    def __len__(self):
+        return self.tensor.numel()
+
+    def __getitem__(self, i):
+        self._fill()
+        return super(LossList, self).__getitem__(i)
+
+    def __iter__(self):
+        self._fill()
+        return super(LossList, self).__iter__()
+
+    def __repr__(self):
+        self._fill()
+        return super(LossList, self).__repr__()

@@ -1,0 +1,72 @@
+"""3D embedding -> affinity losses: drop-in for the reference's scripts_ac3ac4/loss/loss_embedding_mse.py
+(norm1, norm5 and their ema_/inf_ variants -- the ones the shipped ac3ac4.yaml selects, embedding_mode 5
+plus norm1 for the four deep-supervision heads, scripts_ac3ac4/main.py:219-230).
+
+Semantics kept from the reference (file:line there):
+  * channel i compares p with p - shift along axis i % 3 of (z,y,x) on the CROPPED extent (:11-18,:143-151);
+    the first `shift` slices of that axis stay 0 in `affs` (:22-25,:175-190); no mask tensor
+  * WeightedMSE normaliser = B * cropped volume of that channel (pred is [B,1,Z',Y',X'], loss.py:113-115)
+  * affs0_weight multiplies loss0 only in norm1 (:20) and channels 0..2 in norm5 (:181-184)
+  * norm5's shift table is the literal [1,1,1,2,3,3,3,9,9,4,27,27] (:176); its `shift`/`fill` arguments are unused
+  * ema_*: the EMA embedding is the shifted-from operand (:35,:241)
+"""
+import torch
+
+from .. import _lib
+from ..affinity_op import AffinityMap, AffinitySpec, FusedAffinityMSE, affinity_infer
+from ..utils.affinity_ours import NORM5_SHIFTS, axis_offsets_3d
+
+
+def _spec(shifts, affs0_weight, first):
+    lam = [float(affs0_weight) if i < first else 1.0 for i in range(len(shifts))]
+    return AffinitySpec(3, axis_offsets_3d(shifts), lam, _lib.BORDER_CROP_ZERO, _lib.NORM_CROPPED, 1e-12)
+
+
+def _foreign(embedding, ema_embedding, target, weightmap, criterion, shifts, spec):
+    affs = AffinityMap.apply(embedding, ema_embedding, spec)
+    loss = 0
+    for i, s in enumerate(shifts):
+        ax = 2 + i % 3
+        n = affs.shape[ax] - s
+        li = criterion(affs[:, i:i + 1].narrow(ax, s, n), target[:, i:i + 1].narrow(ax, s, n),
+                       weightmap[:, i:i + 1].narrow(ax, s, n))
+        loss = loss + li * spec.lam[i]
+    return loss, affs.detach()
+
+
+def _run(embedding, ema_embedding, target, weightmap, criterion, shifts, affs0_weight, first):
+    spec = _spec(shifts, affs0_weight, first)
+    if getattr(criterion, 'pea_fused', False):
+        loss, affs, _ = FusedAffinityMSE.apply(embedding, ema_embedding, target, weightmap, None, spec)
+        return loss, affs
+    return _foreign(embedding, ema_embedding, target, weightmap, criterion, shifts, spec)
+
+
+def embedding_loss_norm1(embedding, target, weightmap, criterion, affs0_weight=1, shift=1, fill=True):
+    """-> (loss, affs [B,3,Z,Y,X]) -- reference :7-27"""
+    return _run(embedding, None, target, weightmap, criterion, [shift] * 3, affs0_weight, 1)
+
+
+def ema_embedding_loss_norm1(embedding, ema_embedding, target, weightmap, criterion, affs0_weight=1, shift=1, fill=True):
+    """reference :30-51"""
+    return _run(embedding, ema_embedding, target, weightmap, criterion, [shift] * 3, affs0_weight, 1)
+
+
+def inf_embedding_loss_norm1(embedding, shift=1):
+    """-> affs [B,3,Z,Y,X] -- reference :54-67"""
+    return affinity_infer(embedding, None, _spec([shift] * 3, 1, 1))
+
+
+def embedding_loss_norm5(embedding, target, weightmap, criterion, affs0_weight=1, shift=1, fill=True):
+    """-> (loss, affs [B,12,Z,Y,X]) -- reference :169-194"""
+    return _run(embedding, None, target, weightmap, criterion, NORM5_SHIFTS, affs0_weight, 3)
+
+
+def ema_embedding_loss_norm5(embedding, ema_embedding, target, weightmap, criterion, affs0_weight=1, shift=1, fill=True):
+    """reference :263-289"""
+    return _run(embedding, ema_embedding, target, weightmap, criterion, NORM5_SHIFTS, affs0_weight, 3)
+
+
+def inf_embedding_loss_norm5(embedding):
+    """-> affs [B,12,Z,Y,X] -- reference :212-234"""
+    return affinity_infer(embedding, None, _spec(NORM5_SHIFTS, 1, 3))

@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own functions.
+
+Run in the build container only (needs /root/reference; the GPU box has neither):
+    python tests/golden/make_golden.py
+
+What is imported from the reference (nothing is copied; the files are loaded where they lie):
+    scripts_cvppp/loss/loss_embedding_mse.py   embedding_loss, ema_embedding_loss, embedding2affs
+    scripts_ac3ac4/loss/loss_embedding_mse.py  embedding_loss_norm1/5, ema_..., inf_...
+    scripts_cvppp/loss/loss.py                 WeightedMSE  (run unmodified; its `.cuda()` call at
+                                               loss.py:116 is made a no-op on this GPU-less host)
+    scripts_cvppp/utils/affinity_ours.py       multi_offset, gen_affs_ours
+    scripts_cvppp/data/data_segmentation.py    not importable here (needs skimage): weight_binary_ratio
+                                               (:205-228) is restated below for realistic class-balance weights.
+
+Every fixture is data only: seeded inputs, and the reference's outputs (loss, per-offset losses,
+affinity maps, autograd gradients).  Inputs are stored, not re-derived, so the fixtures do not
+depend on any RNG implementation.
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load(name, path):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, path))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+ref2d = load("ref_mse2d", "scripts_cvppp/loss/loss_embedding_mse.py")
+ref3d = load("ref_mse3d", "scripts_ac3ac4/loss/loss_embedding_mse.py")
+refloss = load("ref_loss", "scripts_cvppp/loss/loss.py")
+refaff = load("ref_aff", "scripts_cvppp/utils/affinity_ours.py")
+
+# WeightedMSE.weighted_mse_loss calls norm_term.cuda() (loss.py:116); on a CPU-only host make that
+# call the identity so the reference class itself runs, arithmetic untouched.
+torch.Tensor.cuda = lambda self, *a, **k: self
+criterion = refloss.WeightedMSE()
+
+
+def weight_binary_ratio(label, alpha=1.0):
+    """data_segmentation.py:205-228 (mask=None branch)."""
+    if label.max() == label.min():
+        return np.ones_like(label, np.float32)
+    label = (label != 0).astype(int)
+    f = float(label.sum()) / np.prod(label.shape)
+    f = np.clip(f, 5e-2, 0.99)
+    if f > 0.5:
+        w = label + alpha * f / (1 - f) * (1 - label)
+    else:
+        w = alpha * (1 - f) / f * label + (1 - label)
+    return w.astype(np.float32)
+
+
+def blocky_labels(rng, H, W, cell=8, n=12):
+    """Random instance map: background 0 plus n instances, piecewise constant on a coarse grid."""
+    gh, gw = -(-H // cell), -(-W // cell)
+    coarse = rng.integers(0, n + 1, size=(gh, gw))
+    lab = np.kron(coarse, np.ones((cell, cell), dtype=coarse.dtype))[:H, :W]
+    return lab.astype(np.float32)  # gen_affs_ours subtracts labels; the reference feeds float/uint arrays
+
+
+def targets_2d(rng, B, H, W, offsets):
+    t = np.zeros((B, len(offsets), H, W), np.float32)
+    m = np.zeros((B, len(offsets), H, W), np.uint8)
+    w = np.zeros((B, len(offsets), H, W), np.float32)
+    for b in range(B):
+        lab = blocky_labels(rng, H, W)
+        tb, mb = refaff.gen_affs_ours(lab, offsets, ignore=False, padding=True)
+        t[b], m[b] = tb, mb
+        for i in range(len(offsets)):
+            w[b, i] = weight_binary_ratio(tb[i])
+    return t, w, m
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def save(name, **kw):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in kw.items()})
+    print("%-28s %7.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+def case_2d(name, seed, B, D, H, W, shifts, nb, K=None, mode="ours", zero_px=False, scale=1.0):
+    rng = np.random.default_rng(seed)
+    offsets = refaff.multi_offset(shifts, neighbor=nb)
+    if K:
+        offsets = offsets[:K]
+    e = (rng.standard_normal((B, D, H, W)) * scale).astype(np.float32)
+    if zero_px:  # a pixel whose norm is below eps: F.normalize divides by eps
+        e[0, :, 3, 4] = 0.0
+        e[-1, :, H - 1, W - 1] = 1e-14
+    t, w, m = targets_2d(rng, B, H, W, offsets)
+    et = T(e).requires_grad_(True)
+    loss, affs, all_loss = ref2d.embedding_loss(et, T(t), T(w), T(m), criterion, offsets, affs0_weight=1, mode=mode)
+    loss.backward()
+    inf = ref2d.embedding2affs(T(e), offsets, mode=mode)
+    save(name, kind="2d_self", mode=mode, offsets=np.array(offsets, np.int32), e=e, target=t, weight=w, mask=m,
+         loss=np.float32(loss.item()), all_loss=np.array(all_loss, np.float64), affs=affs.detach().numpy(),
+         affs_infer=inf.numpy(), grad=et.grad.numpy())
+
+
+def case_2d_ema(name, seed, B, D, H, W, shifts, nb, affs0_weight, detach):
+    rng = np.random.default_rng(seed)
+    offsets = refaff.multi_offset(shifts, neighbor=nb)
+    e = rng.standard_normal((B, D, H, W)).astype(np.float32)
+    ema = (e + 0.5 * rng.standard_normal((B, D, H, W))).astype(np.float32)
+    t, w, m = targets_2d(rng, B, H, W, offsets)
+    et = T(e).requires_grad_(True)
+    mt = T(ema).requires_grad_(not detach)
+    loss, affs = ref2d.ema_embedding_loss(et, mt, T(t), T(w), T(m), criterion, offsets, affs0_weight=affs0_weight)
+    loss.backward()
+    kw = dict(kind="2d_ema", offsets=np.array(offsets, np.int32), e=e, ema=ema, target=t, weight=w, mask=m,
+              affs0_weight=np.float32(affs0_weight), detach=np.bool_(detach), loss=np.float32(loss.item()),
+              affs=affs.detach().numpy(), grad=et.grad.numpy())
+    if not detach:
+        kw["grad_ema"] = mt.grad.numpy()
+    save(name, **kw)
+
+
+def targets_3d(rng, B, K, Z, Y, X):
+    t = (rng.random((B, K, Z, Y, X)) < 0.7).astype(np.float32)
+    w = np.stack([np.stack([weight_binary_ratio(t[b, i]) for i in range(K)]) for b in range(B)])
+    return t, w.astype(np.float32)
+
+
+def case_3d(name, seed, B, D, Z, Y, X, which, affs0_weight=1, shift=1, ema=False):
+    rng = np.random.default_rng(seed)
+    K = 3 if which == "norm1" else 12
+    e = rng.standard_normal((B, D, Z, Y, X)).astype(np.float32)
+    t, w = targets_3d(rng, B, K, Z, Y, X)
+    et = T(e).requires_grad_(True)
+    kw = {}
+    if ema:
+        em = (e + 0.5 * rng.standard_normal(e.shape)).astype(np.float32)
+        fn = ref3d.ema_embedding_loss_norm1 if which == "norm1" else ref3d.ema_embedding_loss_norm5
+        loss, affs = fn(et, T(em), T(t), T(w), criterion, affs0_weight=affs0_weight, shift=shift)
+        kw["ema"] = em
+    else:
+        fn = ref3d.embedding_loss_norm1 if which == "norm1" else ref3d.embedding_loss_norm5
+        loss, affs = fn(et, T(t), T(w), criterion, affs0_weight=affs0_weight, shift=shift)
+        inf = ref3d.inf_embedding_loss_norm1(T(e), shift=shift) if which == "norm1" else ref3d.inf_embedding_loss_norm5(T(e))
+        kw["affs_infer"] = inf.numpy()
+    loss.backward()
+    save(name, kind="3d_" + which + ("_ema" if ema else ""), e=e, target=t, weight=w, shift=np.int32(shift),
+         affs0_weight=np.float32(affs0_weight), loss=np.float32(loss.item()), affs=affs.detach().numpy(),
+         grad=et.grad.numpy(), **kw)
+
+
+def case_full_summary(name, seed, B, D, H, W):
+    """One full-size CVPPP case (B x 16 x 544 x 544, K=10): too big to store, so inputs are a closed-form
+    function of the index (no RNG) and only summary statistics + samples of the outputs are kept."""
+    offsets = refaff.multi_offset([1, 3, 5, 9, 27], neighbor=4)
+    K = len(offsets)
+    e, t, w, m = synth_full(B, D, H, W, K, seed)
+    et = T(e).requires_grad_(True)
+    loss, affs, all_loss = ref2d.embedding_loss(et, T(t), T(w), T(m), criterion, offsets)
+    loss.backward()
+    affs = affs.detach().numpy()
+    grad = et.grad.numpy()
+    idx = np.random.default_rng(0).integers(0, affs.size, 4096)
+    gidx = np.random.default_rng(1).integers(0, grad.size, 4096)
+    save(name, kind="2d_full_summary", seed=np.int64(seed), shape=np.array([B, D, H, W]), offsets=np.array(offsets, np.int32),
+         loss=np.float32(loss.item()), all_loss=np.array(all_loss, np.float64),
+         affs_sum=np.float64(affs.astype(np.float64).sum()), affs_sq=np.float64((affs.astype(np.float64) ** 2).sum()),
+         grad_sum=np.float64(grad.astype(np.float64).sum()), grad_sq=np.float64((grad.astype(np.float64) ** 2).sum()),
+         affs_idx=idx, affs_val=affs.reshape(-1)[idx], grad_idx=gidx, grad_val=grad.reshape(-1)[gidx])
+
+
+def synth_full(B, D, H, W, K, seed):
+    """Deterministic, RNG-free synthetic inputs (pixel-embedded-affinity_amd/utils/synth.py)."""
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    import importlib
+    import __graft_entry__ as ge
+    ge.load_package()
+    synth = importlib.import_module(ge.PKG_NAME + ".utils.synth")
+    return synth.synth_inputs_2d(B, D, H, W, refaff.multi_offset([1, 3, 5, 9, 27], neighbor=4)[:K], seed)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    # 2D, shipped CVPPP stencil (shifts 1,3,5,9,27 x neighbor 4 -> K=10), ragged sizes
+    case_2d("g2d_cvppp_k10", 1, B=2, D=16, H=40, W=56, shifts=[1, 3, 5, 9, 27], nb=4)
+    # neighbor=8: diagonal and mixed-sign offsets
+    case_2d("g2d_nb8_k12", 2, B=1, D=16, H=48, W=37, shifts=[1, 3, 9], nb=8)
+    # deep-supervision head: offsets[:8] (main.py:284), odd sizes, zero-norm pixels
+    case_2d("g2d_k8_zero", 3, B=2, D=16, H=33, W=35, shifts=[1, 3, 5, 9, 27], nb=4, K=8, zero_px=True)
+    # D=32 (BASELINE config 3) and the CosineSimilarity branch (mode != 'ours')
+    case_2d("g2d_d32", 4, B=1, D=32, H=32, W=64, shifts=[1, 3, 5, 9, 11], nb=4)
+    case_2d("g2d_cos_mode", 5, B=1, D=16, H=24, W=40, shifts=[1, 3, 5], nb=4, mode="cos", scale=3.0)
+    case_2d("g2d_d64", 6, B=1, D=64, H=16, W=64, shifts=[1, 3, 5, 9], nb=4)
+    case_2d("g2d_d5_generic", 7, B=1, D=5, H=19, W=23, shifts=[1, 2], nb=8)
+    # EMA cross loss: detached second operand (shipped, if_ema_flip) and the non-detached variant
+    case_2d_ema("g2d_ema_detach", 11, B=2, D=16, H=40, W=56, shifts=[1, 3, 5, 9, 27], nb=4, affs0_weight=2, detach=True)
+    case_2d_ema("g2d_ema_both", 12, B=1, D=16, H=32, W=40, shifts=[1, 3, 9], nb=8, affs0_weight=1, detach=False)
+    # 3D
+    case_3d("g3d_norm1", 21, B=2, D=16, Z=6, Y=20, X=24, which="norm1", affs0_weight=1)
+    case_3d("g3d_norm1_s2_w", 22, B=1, D=16, Z=5, Y=12, X=17, which="norm1", affs0_weight=0.5, shift=2)
+    case_3d("g3d_norm5", 23, B=1, D=16, Z=6, Y=30, X=31, which="norm5", affs0_weight=1)
+    case_3d("g3d_norm5_w", 24, B=2, D=16, Z=5, Y=29, X=28, which="norm5", affs0_weight=2)
+    case_3d("g3d_norm1_ema", 25, B=1, D=16, Z=6, Y=20, X=24, which="norm1", ema=True)
+    case_3d("g3d_norm5_ema", 26, B=1, D=16, Z=6, Y=30, X=31, which="norm5", affs0_weight=2, ema=True)
+    # full CVPPP size, summary only
+    case_full_summary("g2d_full544_summary", 555, B=2, D=16, H=544, W=544)
