@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's headline benchmark (BASELINE.json: affinity-map Mpixels/s, fwd+bwd).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: embedding_loss forward (affinity maps + fused
+weighted-MSE loss) and its backward (d loss / d embedding), through the reference-named Python API,
+i.e. through the C ABI of include/pea.h.  Workload at every N = BASELINE.json configs[1]:
+CVPPP-shaped B=8 x D=16 x 544 x 544 embeddings per GPU, the shipped K=10 stencil
+(shifts 1,3,5,9,27 x neighbor 4), fp32, synthetic inputs already resident in HBM.  Images are
+independent units: ranks shard the batch with no data-path collective (weak scaling, 8 images per GPU).
+
+Rank 0 prints ONE JSON line; besides the contract fields it carries
+  "roofline":     the dominant kernel's algorithmic bytes / its HIP-event duration vs 8 TB/s HBM
+  "cpu_baseline": the reference's op sequence (torch CPU, all host cores) on a bounded sample
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+import __graft_entry__ as ge
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SHIFTS, NEIGHBOR = [1, 3, 5, 9, 27], 4
+B_PER_GPU, D, H, W = 8, 16, 544, 544
+
+
+def algorithmic_bytes_per_px(D, K):
+    """SURVEY.md section 8d (fp32, 2D with u8 mask): fwd 4D+13K, bwd 8D+9K, fwd+bwd 12D+22K."""
+    return {"fwd": 4 * D + 13 * K, "bwd": 8 * D + 9 * K, "step": 12 * D + 22 * K}
+
+
+def event_time_ms(fn, iters):
+    """average duration of fn() over `iters` back-to-back calls, by HIP events on the launch stream"""
+    s = torch.cuda.current_stream()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(s)
+    for _ in range(iters):
+        fn()
+    b.record(s)
+    b.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def cpu_baseline(offsets, e, t, w, m, budget_s=20.0):
+    """The reference's arithmetic (F.normalize -> K x roll/mul/sum -> WeightedMSE -> autograd backward) as the
+    oracle's torch-CPU restatement, on all host cores, same workload; at most ~budget_s of CPU work."""
+    orc = ge.load_oracle()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    et, tt, wt, mt = (torch.from_numpy(x) for x in (e, t, w, m))
+
+    def one():
+        x = et.clone().requires_grad_(True)
+        loss, _, _ = orc.torch_embedding_loss(x, tt, wt, mt, offsets)
+        loss.backward()
+        return float(loss)
+
+    t0 = time.perf_counter()
+    one()  # warm-up (allocator, thread pool)
+    first = time.perf_counter() - t0
+    iters = int(max(1, min(5, budget_s // max(first, 1e-3) - 1)))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    dt = (time.perf_counter() - t0) / iters
+    px = e.shape[0] * e.shape[2] * e.shape[3]
+    return {"value": round(px / dt / 1e6, 4), "unit": "Mpx/s", "cores": cores, "kind": "port",
+            "sample": "%d timed fwd+bwd iterations (after 1 warm-up) of the same B=%d x %d x %dx%d K=%d batch, "
+                      "oracle/pea_oracle.py torch_embedding_loss, %.2f s/iter" % (iters, e.shape[0], e.shape[1], e.shape[2], e.shape[3], len(offsets), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = ge.load_package()
+    synth = __import__("importlib").import_module(ge.PKG_NAME + ".utils.synth")
+    offsets = pkg.multi_offset(SHIFTS, NEIGHBOR)
+    K, B = len(offsets), args.batch
+    # each rank owns its own images (different seeds): independent units, no exchange
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, seed=555 + rank)
+    E = torch.from_numpy(e).to(dev).requires_grad_(True)
+    T, Wt, M = torch.from_numpy(t).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(m).to(dev)
+    crit = pkg.WeightedMSE()
+
+    def step():
+        E.grad = None
+        loss, affs, _ = pkg.embedding_loss(E, T, Wt, M, crit, offsets)
+        loss.backward()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    px_per_step = world * B * H * W
+    value = px_per_step * args.steps / dt / 1e6
+
+    out = None
+    if rank == 0:
+        # ---- per-kernel durations (HIP events on the launch stream) through the C ABI --------------------
+        op, L = pkg.affinity_op, pkg._lib.lib()
+        spec = op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX)
+        Ed = E.detach()
+        desc = op.make_desc(spec, Ed)
+        affs = torch.empty(B, K, H, W, device=dev)
+        lossv = torch.empty(1 + K, device=dev)
+        wsb = L.pea_workspace_bytes(ctypes.byref(desc))
+        work = torch.empty(max(wsb, 4) // 4, device=dev)
+        dE = torch.empty_like(Ed)
+        one = torch.ones((), device=dev)
+        P = lambda x: ctypes.c_void_p(x.data_ptr())
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        fwd = lambda: L.pea_affinity_fwd(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(affs), P(lossv), P(work), wsb, st)
+        bwd = lambda: L.pea_affinity_bwd(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(one), P(dE), None, st)
+        inf = lambda: L.pea_affinity_infer(ctypes.byref(desc), P(Ed), None, P(affs), st)
+        kt = {}
+        for name, fn in (("fwd", fwd), ("bwd", bwd), ("infer", inf)):
+            event_time_ms(fn, 10)
+            kt[name] = event_time_ms(fn, max(20, min(args.steps, 200)))
+        ab = algorithmic_bytes_per_px(D, K)
+        dom = "bwd" if kt["bwd"] >= kt["fwd"] else "fwd"
+        launch_bytes = ab[dom] * B * H * W
+        achieved = launch_bytes / (kt[dom] * 1e-3) / 1e9
+        step_gbs = ab["step"] * B * H * W / ((kt["fwd"] + kt["bwd"]) * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ge.ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):  # PMC-measured HBM bytes per launch, recorded from a rocprofv3 --pmc run
+            rec = json.load(open(tpath)).get(dom + "_b%d" % B)
+            traffic = rec.get("bytes_per_launch") if rec else None
+        out = {
+            "metric": "affinity-map Mpixels/sec (fwd+bwd)", "value": round(value, 2), "unit": "Mpx/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: CVPPP A1 embedding_loss fwd+bwd, B=%d per GPU x D=%d x %dx%d (530x500 padded), "
+                                   "K=%d offsets (shifts 1,3,5,9,27 x neighbor 4), circular border, u8 mask" % (B, D, H, W, K),
+                       "images_per_gpu": B, "embedding_dim": D, "height": H, "width": W, "offsets": K,
+                       "sharding": "batch across ranks, no data-path collective"},
+            "kernel_ms": {k: round(v, 5) for k, v in kt.items()},
+            "kernel_sum_mpx_s": round(B * H * W / ((kt["fwd"] + kt["bwd"]) * 1e-3) / 1e6, 1),
+            "infer_mpx_s": round(B * H * W / (kt["infer"] * 1e-3) / 1e6, 1),
+            "roofline": {"bound": "hbm", "kernel": "pea_affinity_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_px": ab[dom], "px_per_launch": B * H * W,
+                         "fwd_plus_bwd_GBs": round(step_gbs, 1), "fwd_plus_bwd_frac": round(step_gbs / HBM_PEAK_GBS, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(offsets, e, t, w, m)
+            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -246,8 +246,9 @@ def torch_weighted_mse(pred, target, weight):
     return torch.sum(weight * (pred - target) ** 2) / norm
 
 
-def torch_embedding_loss(e, target, weight, mask, offsets, ema=None, affs0_weight=1, eps=1e-12):
+def torch_embedding_loss(e, target, weight, mask, offsets, ema=None, affs0_weight=1, eps=1e-12, criterion=None):
     """fwd of the 2D path on torch tensors (autograd-capable): (loss, affs, per-offset list of tensors)."""
+    criterion = criterion or torch_weighted_mse
     import torch
     import torch.nn.functional as F
     eh = F.normalize(e, p=2, dim=1, eps=eps)
@@ -258,7 +259,7 @@ def torch_embedding_loss(e, target, weight, mask, offsets, ema=None, affs0_weigh
     parts = []
     for i, off in enumerate(offsets):
         a = torch.sum(torch.roll(oh, shifts=(-off[0], -off[1]), dims=(2, 3)) * eh, dim=1)
-        li = torch_weighted_mse(a * m[:, i], target[:, i] * m[:, i], weight[:, i])
+        li = criterion(a * m[:, i], target[:, i] * m[:, i], weight[:, i])
         loss = loss + li * ((affs0_weight if i < 2 else 1.0) if ema is not None else 1.0)
         parts.append(li)
         affs[:, i] = a.detach()

@@ -1,0 +1,85 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/pea.h declares;
+host-only entry points (validate, workspace size, strerror) behave; no compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "pea.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pea_[a-z_0-9]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    pkg.build()
+    return pkg._lib.lib()
+
+
+def test_header_declares_the_expected_entry_points():
+    assert declared_symbols() == sorted(["pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes",
+                                         "pea_affinity_infer", "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_vjp"])
+
+
+def test_library_exports_every_declared_symbol(pkg, lib):
+    raw = ctypes.CDLL(pkg._lib.SO_PATH)
+    for name in declared_symbols():
+        assert hasattr(raw, name), name
+    assert sorted(pkg._lib.EXPORTS) == declared_symbols()
+    assert lib.pea_version() == pkg._lib.PEA_ABI_VERSION == 1
+
+
+def test_struct_layout_matches_header(pkg):
+    # 13 leading 4-byte fields, offsets[32][3] int32, lambda[32] f32, 3 x int64 (8-aligned)
+    assert ctypes.sizeof(pkg._lib.PeaDesc) == 13 * 4 + 32 * 3 * 4 + 32 * 4 + 4 + 3 * 8
+    assert pkg._lib.PeaDesc.offsets.offset == 52
+    assert pkg._lib.PeaDesc.target_bstride.offset % 8 == 0
+
+
+def _desc(pkg, **kw):
+    d = pkg._lib.PeaDesc()
+    d.abi, d.ndim, d.B, d.D, d.K = 1, 2, 2, 16, 2
+    d.dims[:] = [1, 32, 48]
+    d.border, d.dtype, d.norm, d.eps = 0, 0, 0, 1e-12
+    d.offsets[0][:] = [0, -1, 0]
+    d.offsets[1][:] = [0, 0, -27]
+    d.lam[0] = d.lam[1] = 1.0
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+def test_validate_and_workspace(pkg, lib):
+    d = _desc(pkg)
+    assert lib.pea_desc_validate(ctypes.byref(d)) == 0
+    # one partial per 256-pixel workgroup per offset
+    assert lib.pea_workspace_bytes(ctypes.byref(d)) == 2 * ((32 * 48 + 255) // 256) * 2 * 4
+    assert lib.pea_strerror(0) == b"ok"
+    for bad in (dict(abi=7), dict(K=0), dict(K=33), dict(B=0), dict(D=0), dict(border=5), dict(dtype=3), dict(norm=9),
+                dict(eps=0.0), dict(ndim=4), dict(target_bstride=-1)):
+        assert lib.pea_desc_validate(ctypes.byref(_desc(pkg, **bad))) == -2, bad
+    d = _desc(pkg)
+    d.offsets[1][:] = [0, 0, -48]  # |o| must be < dim
+    assert lib.pea_desc_validate(ctypes.byref(d)) == -2
+    d = _desc(pkg)
+    d.dims[0] = 3  # ndim 2 requires Z == 1
+    assert lib.pea_desc_validate(ctypes.byref(d)) == -2
+    assert lib.pea_workspace_bytes(ctypes.byref(d)) == 0
+    assert b"NULL" in lib.pea_strerror(-1)
+
+
+def test_null_and_alignment_errors_need_no_gpu(pkg, lib):
+    d = _desc(pkg)
+    assert lib.pea_affinity_infer(ctypes.byref(d), None, None, None, None) == -1
+    assert lib.pea_affinity_fwd(ctypes.byref(d), None, None, None, None, None, None, None, None, 0, None) == -1
+    assert lib.pea_affinity_bwd(ctypes.byref(d), None, None, None, None, None, None, None, None, None) == -1
+    assert lib.pea_affinity_vjp(ctypes.byref(d), None, None, None, None, None, None) == -1
+    assert lib.pea_affinity_infer(ctypes.byref(d), ctypes.c_void_p(0x1002), None, ctypes.c_void_p(0x2000), None) == -5
+    # workspace too small is reported before anything is launched
+    p = ctypes.c_void_p(0x1000)
+    assert lib.pea_affinity_fwd(ctypes.byref(d), p, None, p, p, None, p, p, p, 8, None) == -4

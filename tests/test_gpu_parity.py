@@ -1,0 +1,317 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the reference's golden vectors, the
+CPU oracle, and size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (north_star: affinity maps within 1e-4 of the reference; fp32 everywhere in the reference):
+    affs   abs 1e-5  (10x tighter than required)      loss  rel 1e-5      grads  rel-to-max 1e-4
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import __graft_entry__ as ge
+from conftest import golden_names, lam_for, load_golden, shifts_for
+
+pytestmark = pytest.mark.gpu
+
+AFFS_ATOL, LOSS_RTOL, GRAD_RTOL = 1e-5, 1e-5, 1e-4
+G2D = [n for n in golden_names("g2d_") if "summary" not in n]
+G3D = golden_names("g3d_")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def synth():
+    ge.load_package()
+    return importlib.import_module(ge.PKG_NAME + ".utils.synth")
+
+
+def cu(a, dev):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def relmax(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def run_2d(pkg, g, dev, dloss=1.0):
+    e = cu(g["e"], dev).requires_grad_(True)
+    crit = pkg.WeightedMSE()
+    offsets = g["offsets"].tolist()
+    mode = str(g["mode"]) if "mode" in g else "ours"
+    if str(g["kind"]) == "2d_ema":
+        ema = cu(g["ema"], dev).requires_grad_(not bool(g["detach"]))
+        loss, affs = pkg.ema_embedding_loss(e, ema, cu(g["target"], dev), cu(g["weight"], dev), cu(g["mask"], dev), crit,
+                                            offsets, affs0_weight=float(g["affs0_weight"]))
+        all_loss = None
+    else:
+        ema = None
+        loss, affs, all_loss = pkg.embedding_loss(e, cu(g["target"], dev), cu(g["weight"], dev), cu(g["mask"], dev), crit,
+                                                  offsets, affs0_weight=1, mode=mode)
+    (loss * dloss).backward()
+    return loss, affs, all_loss, e.grad, (ema.grad if ema is not None and ema.requires_grad else None)
+
+
+@pytest.mark.parametrize("name", G2D)
+def test_2d_matches_reference_golden(pkg, dev, name):
+    g = load_golden(name)
+    if g["e"].shape[1] not in (4, 8, 16, 32, 64):
+        pytest.skip("training backward needs D in {4,8,16,32,64}; forward covered by test_generic_d_forward")
+    loss, affs, all_loss, grad, grad_ema = run_2d(pkg, g, dev)
+    assert np.abs(affs.cpu().numpy() - g["affs"]).max() < AFFS_ATOL
+    assert abs(loss.item() - float(g["loss"])) <= LOSS_RTOL * max(1.0, abs(float(g["loss"])))
+    if all_loss is not None:
+        np.testing.assert_allclose(np.array(list(all_loss)), g["all_loss"], rtol=LOSS_RTOL, atol=1e-9)
+    assert relmax(grad.cpu().numpy(), g["grad"]) < GRAD_RTOL
+    if "grad_ema" in g:
+        assert relmax(grad_ema.cpu().numpy(), g["grad_ema"]) < GRAD_RTOL
+    if "affs_infer" in g:
+        mode = str(g["mode"]) if "mode" in g else "ours"
+        inf = pkg.embedding2affs(cu(g["e"], dev), g["offsets"].tolist(), mode=mode)
+        assert np.abs(inf.cpu().numpy() - g["affs_infer"]).max() < AFFS_ATOL
+
+
+def test_generic_d_forward(pkg, dev):
+    g = load_golden("g2d_d5_generic")
+    offsets = g["offsets"].tolist()
+    inf = pkg.embedding2affs(cu(g["e"], dev), offsets)
+    assert np.abs(inf.cpu().numpy() - g["affs_infer"]).max() < AFFS_ATOL
+    loss, affs, all_loss = pkg.embedding_loss(cu(g["e"], dev), cu(g["target"], dev), cu(g["weight"], dev), cu(g["mask"], dev),
+                                              pkg.WeightedMSE(), offsets)
+    assert abs(loss.item() - float(g["loss"])) <= LOSS_RTOL * max(1.0, abs(float(g["loss"])))
+    e = cu(g["e"], dev).requires_grad_(True)
+    loss, _, _ = pkg.embedding_loss(e, cu(g["target"], dev), cu(g["weight"], dev), cu(g["mask"], dev), pkg.WeightedMSE(), offsets)
+    with pytest.raises(NotImplementedError):
+        loss.backward()
+
+
+@pytest.mark.parametrize("name", G3D)
+def test_3d_matches_reference_golden(pkg, dev, name):
+    g = load_golden(name)
+    kind = str(g["kind"])
+    e = cu(g["e"], dev).requires_grad_(True)
+    t, w = cu(g["target"], dev), cu(g["weight"], dev)
+    crit = pkg.WeightedMSE()
+    a0, sh = float(g["affs0_weight"]), int(g["shift"])
+    if kind == "3d_norm1":
+        loss, affs = pkg.embedding_loss_norm1(e, t, w, crit, affs0_weight=a0, shift=sh)
+        inf = pkg.inf_embedding_loss_norm1(e.detach(), shift=sh)
+    elif kind == "3d_norm5":
+        loss, affs = pkg.embedding_loss_norm5(e, t, w, crit, affs0_weight=a0)
+        inf = pkg.inf_embedding_loss_norm5(e.detach())
+    elif kind == "3d_norm1_ema":
+        loss, affs = pkg.ema_embedding_loss_norm1(e, cu(g["ema"], dev), t, w, crit, affs0_weight=a0, shift=sh)
+        inf = None
+    else:
+        loss, affs = pkg.ema_embedding_loss_norm5(e, cu(g["ema"], dev), t, w, crit, affs0_weight=a0)
+        inf = None
+    loss.backward()
+    assert np.abs(affs.cpu().numpy() - g["affs"]).max() < AFFS_ATOL
+    assert abs(loss.item() - float(g["loss"])) <= LOSS_RTOL * max(1.0, abs(float(g["loss"])))
+    assert relmax(e.grad.cpu().numpy(), g["grad"]) < GRAD_RTOL
+    if inf is not None:
+        assert np.abs(inf.cpu().numpy() - g["affs_infer"]).max() < AFFS_ATOL
+    # the border slices the reference leaves at zero
+    a = affs.cpu().numpy()
+    for i, s in enumerate(shifts_for(g)):
+        sl = [slice(None)] * 5
+        sl[1], sl[2 + i % 3] = i, slice(0, s)
+        assert np.all(a[tuple(sl)] == 0)
+
+
+def test_full_size_cvppp_against_reference_summary(pkg, dev, synth):
+    """2 x 16 x 544 x 544, K=10 (BASELINE configs[0] shape): HIP vs the reference's summary statistics"""
+    g = load_golden("g2d_full544_summary")
+    B, D, H, W = [int(v) for v in g["shape"]]
+    offsets = g["offsets"].tolist()
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, int(g["seed"]))
+    et = cu(e, dev).requires_grad_(True)
+    loss, affs, all_loss = pkg.embedding_loss(et, cu(t, dev), cu(w, dev), cu(m, dev), pkg.WeightedMSE(), offsets)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= LOSS_RTOL * float(g["loss"])
+    np.testing.assert_allclose(np.array(list(all_loss)), g["all_loss"], rtol=LOSS_RTOL)
+    a = affs.cpu().numpy()
+    assert np.abs(a.reshape(-1)[g["affs_idx"]] - g["affs_val"]).max() < AFFS_ATOL
+    assert abs(a.astype(np.float64).sum() - float(g["affs_sum"])) < 1e-5 * a.size ** 0.5 * 10
+    assert abs((a.astype(np.float64) ** 2).sum() / float(g["affs_sq"]) - 1) < 1e-5
+    gr = et.grad.cpu().numpy()
+    assert np.abs(gr.reshape(-1)[g["grad_idx"]] - g["grad_val"]).max() <= GRAD_RTOL * np.abs(g["grad_val"]).max()
+    assert abs((gr.astype(np.float64) ** 2).sum() / float(g["grad_sq"]) - 1) < 1e-4
+
+
+def test_baseline_config_b8_properties(pkg, dev, synth):
+    """BASELINE configs[1]: B=8, D=16, 544x544, K=10 -- size-independent properties instead of a CPU re-run:
+    run-to-run bit reproducibility, linearity of the gradient in dloss, batch additivity of the loss
+    (what the multi-GPU sharding relies on), and roll-equivariance of the circular stencil."""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    B, D, H, W = 8, 16, 544, 544
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 555)
+    E, T, Wt, M = cu(e, dev), cu(t, dev), cu(w, dev), cu(m, dev)
+    crit = pkg.WeightedMSE()
+
+    def run(Ein, scale=1.0, sl=slice(None)):
+        x = Ein[sl].clone().requires_grad_(True)
+        loss, affs, parts = pkg.embedding_loss(x, T[sl], Wt[sl], M[sl], crit, offsets)
+        (loss * scale).backward()
+        return loss.detach(), affs, parts.tensor.clone(), x.grad
+
+    l1, a1, p1, g1 = run(E)
+    l2, a2, p2, g2 = run(E)
+    assert torch.equal(l1, l2) and torch.equal(a1, a2) and torch.equal(p1, p2) and torch.equal(g1, g2)
+    _, _, _, g3 = run(E, scale=3.0)
+    assert relmax(g3.cpu().numpy(), 3.0 * g1.cpu().numpy()) < 1e-6
+    # batch additivity: loss(B=8) == mean over 4 shards of loss(B=2) (normaliser 1/(B*W)), grads scale by 1/4
+    shard_losses = []
+    for r in range(4):
+        sl = slice(2 * r, 2 * r + 2)
+        ls, as_, _, gs = run(E, sl=sl)
+        shard_losses.append(ls.item())
+        assert torch.equal(as_, a1[sl])
+        assert relmax(gs.cpu().numpy() / 4.0, g1[sl].cpu().numpy()) < 1e-5
+    assert abs(np.mean(shard_losses) - l1.item()) < 1e-6 * abs(l1.item())
+    # roll equivariance of embedding2affs (circular border): rolling e rolls affs
+    inf = pkg.embedding2affs(E[:1], offsets)
+    inf_r = pkg.embedding2affs(torch.roll(E[:1], shifts=(13, -29), dims=(2, 3)), offsets)
+    assert torch.equal(torch.roll(inf, shifts=(13, -29), dims=(2, 3)), inf_r)
+    assert torch.equal(inf, a1[:1])
+    # |a| <= 1 (cosine) and the zero offset would be exactly ~1
+    assert float(a1.abs().max()) <= 1.0 + 1e-5
+
+
+def test_packed_down_tensor_slices_need_no_copy(pkg, dev, orc, synth):
+    """scripts_cvppp/main.py:284: target/weight/mask are channel slices of one packed `down` tensor"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)[:8]
+    B, D, H, W = 3, 16, 34, 40
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 7)
+    down = torch.from_numpy(np.concatenate([t, w, m.astype(np.float32)], axis=1)).to(dev)
+    et = cu(e, dev).requires_grad_(True)
+    loss, affs, _ = pkg.embedding_loss(et, down[:, 0:8], down[:, 8:16], down[:, 16:24], pkg.WeightedMSE(), offsets)
+    loss.backward()
+    d = orc.desc_2d(e, offsets)
+    o_affs, o_loss = orc.c_fwd(d, e, None, t, w, m)
+    o_grad, _ = orc.c_bwd(d, e, None, t, w, m)
+    assert np.abs(affs.cpu().numpy() - o_affs).max() < AFFS_ATOL
+    assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+    assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL
+
+
+def test_foreign_criterion_uses_vjp(pkg, dev, orc, synth):
+    """criterion is a parameter of the reference API: a non-fused criterion runs on a differentiable
+    affinity map (pea_affinity_vjp) and must match torch autograd of the reference op sequence"""
+    offsets = pkg.multi_offset([1, 3, 9], 8)
+    B, D, H, W = 2, 16, 30, 44
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 11)
+    crit = lambda pred, tgt, wt: torch.sum(wt * torch.abs(pred - tgt) ** 3) / pred.shape[0]
+    et = cu(e, dev).requires_grad_(True)
+    loss, affs, all_loss = pkg.embedding_loss(et, cu(t, dev), cu(w, dev), cu(m, dev), crit, offsets)
+    loss.backward()
+    ec = torch.from_numpy(e).requires_grad_(True)
+    l_ref, a_ref, _ = orc.torch_embedding_loss(ec, torch.from_numpy(t), torch.from_numpy(w), torch.from_numpy(m), offsets, criterion=crit)
+    l_ref.backward()
+    assert abs(loss.item() - l_ref.item()) <= 1e-5 * abs(l_ref.item())
+    assert np.abs(affs.cpu().numpy() - a_ref.numpy()).max() < AFFS_ATOL
+    assert relmax(et.grad.cpu().numpy(), ec.grad.numpy()) < GRAD_RTOL
+    assert len(list(all_loss)) == len(offsets)
+
+
+def test_relu_epilogue_and_c_abi_direct(pkg, dev, orc, synth):
+    """direct ctypes call of pea_affinity_infer with the RELU flag (F.relu(pred), scripts_cvppp/inference.py:193)"""
+    import ctypes
+    op = pkg.affinity_op
+    offsets = pkg.multi_offset([1, 3], 4)
+    e, _, _, _ = synth.synth_inputs_2d(1, 16, 20, 24, offsets, 3)
+    E = cu(e, dev)
+    spec = op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX, relu=True)
+    d = op.make_desc(spec, E)
+    out = torch.full((1, 4, 20, 24), -7.0, device=dev)
+    rc = pkg._lib.lib().pea_affinity_infer(ctypes.byref(d), ctypes.c_void_p(E.data_ptr()), None, ctypes.c_void_p(out.data_ptr()),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    o_affs, _ = orc.c_fwd(orc.desc_2d(e, offsets, relu=True), e)
+    assert np.abs(out.cpu().numpy() - o_affs).max() < AFFS_ATOL
+    assert float(out.min()) >= 0.0
+
+
+def test_fp16_storage_f32_accumulate(pkg, dev, orc, synth):
+    """BASELINE configs[4] flavour: f16 embedding storage, f32 arithmetic; D=64, K=8"""
+    offsets = pkg.multi_offset([1, 3, 5, 9], 4)
+    B, D, H, W = 1, 64, 24, 40
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 5)
+    e16 = e.astype(np.float16)
+    et = torch.from_numpy(e16).to(dev).requires_grad_(True)
+    loss, affs, _ = pkg.embedding_loss(et, cu(t, dev), cu(w, dev), cu(m, dev), pkg.WeightedMSE(), offsets)
+    loss.backward()
+    e_r = e16.astype(np.float32)  # the oracle sees exactly the rounded inputs
+    d = orc.desc_2d(e_r, offsets)
+    o_affs, o_loss = orc.c_fwd(d, e_r, None, t, w, m)
+    o_grad, _ = orc.c_bwd(d, e_r, None, t, w, m)
+    assert affs.dtype == torch.float32 and et.grad.dtype == torch.float16
+    assert np.abs(affs.cpu().numpy() - o_affs).max() < AFFS_ATOL
+    assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+    assert relmax(et.grad.float().cpu().numpy(), o_grad) < 2e-3  # f16 rounding of the stored gradient
+
+
+def test_3d_26_neighbourhood_vs_oracle(pkg, dev, orc, synth):
+    """BASELINE configs[3] stencil: full 3x3x3 neighbourhood minus centre, CROP_ZERO border"""
+    op = pkg.affinity_op
+    offs = [[dz, dy, dx] for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dz, dy, dx) != (0, 0, 0)]
+    B, D, Z, Y, X = 1, 16, 5, 21, 37
+    e, t, w = synth.synth_inputs_3d(B, D, Z, Y, X, offs, 9)
+    spec = op.AffinitySpec(3, offs, None, pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
+    et = cu(e, dev).requires_grad_(True)
+    loss, affs, parts = op.FusedAffinityMSE.apply(et, None, cu(t, dev), cu(w, dev), None, spec)
+    (loss * 2.0).backward()
+    d = orc.make_desc(B, D, [Z, Y, X], offs, None, orc.BORDER_CROP_ZERO, orc.NORM_CROPPED)
+    o_affs, o_loss = orc.c_fwd(d, e, None, t, w, None)
+    o_grad, _ = orc.c_bwd(d, e, None, t, w, None, dloss=2.0)
+    assert np.abs(affs.cpu().numpy() - o_affs).max() < AFFS_ATOL
+    np.testing.assert_allclose(parts.cpu().numpy(), o_loss[1:], rtol=LOSS_RTOL)
+    assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL
+
+
+def test_random_shapes_and_stencils_vs_oracle(pkg, dev, orc, synth):
+    """seeded sweep over ragged sizes, offset lists (both signs), borders, batch and D"""
+    op = pkg.affinity_op
+    rng = np.random.default_rng(2024)
+    for it in range(24):
+        three_d = it % 3 == 2
+        D = int(rng.choice([4, 8, 16, 32]))
+        B = int(rng.integers(1, 4))
+        if three_d:
+            dims = [int(rng.integers(2, 7)), int(rng.integers(3, 40)), int(rng.integers(3, 70))]
+        else:
+            dims = [1, int(rng.integers(2, 60)), int(rng.integers(2, 300))]
+        K = int(rng.integers(1, 9))
+        offs = []
+        for _ in range(K):
+            offs.append([int(rng.integers(-(d - 1), d)) if d > 1 else 0 for d in dims])
+        border = int(rng.integers(0, 2))
+        norm = int(rng.integers(0, 3))
+        lam = [float(v) for v in rng.uniform(0.25, 2.0, K)]
+        S = dims[0] * dims[1] * dims[2]
+        e = synth.synth_embedding((B, D, S), 100 + it).reshape([B, D] + dims)
+        t = (synth.hash_uniform(np.arange(B * K * S, dtype=np.uint64), 200 + it) < 0.6).astype(np.float32).reshape([B, K] + dims)
+        w = (0.5 + synth.hash_uniform(np.arange(B * K * S, dtype=np.uint64), 300 + it)).astype(np.float32).reshape([B, K] + dims)
+        m = (synth.hash_uniform(np.arange(B * K * S, dtype=np.uint64), 400 + it) < 0.9).astype(np.uint8).reshape([B, K] + dims)
+        use_mask = bool(it % 2)
+        ema = synth.synth_embedding((B, D, S), 500 + it).reshape([B, D] + dims) if it % 4 == 1 else None
+        spec = op.AffinitySpec(3, offs, lam, border, norm)
+        et = cu(e, dev).requires_grad_(True)
+        em = cu(ema, dev).requires_grad_(True) if ema is not None else None
+        loss, affs, parts = op.FusedAffinityMSE.apply(et, em, cu(t, dev), cu(w, dev), cu(m, dev) if use_mask else None, spec)
+        loss.backward()
+        d = orc.make_desc(B, D, dims, offs, lam, border, norm, ndim=3)
+        o_affs, o_loss = orc.c_fwd(d, e, ema, t, w, m if use_mask else None)
+        o_grad, o_grad_e = orc.c_bwd(d, e, ema, t, w, m if use_mask else None, want_other=True)
+        ctx = "case %d dims=%s offs=%s border=%d norm=%d" % (it, dims, offs, border, norm)
+        assert np.abs(affs.cpu().numpy().reshape(o_affs.shape) - o_affs).max() < AFFS_ATOL, ctx
+        assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * max(abs(o_loss[0]), 1e-6), ctx
+        assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL, ctx
+        if ema is not None:
+            assert relmax(em.grad.cpu().numpy(), o_grad_e) < GRAD_RTOL, ctx
