@@ -53,7 +53,8 @@ def cpu_baseline(offsets, e, t, w, m, budget_s=20.0):
     """The reference's arithmetic (F.normalize -> K x roll/mul/sum -> WeightedMSE -> autograd backward) as the
     oracle's torch-CPU restatement, on all host cores, same workload; at most ~budget_s of CPU work."""
     orc = ge.load_oracle()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # the GPU box gives one GPU a 16-core CPU share; more threads than that only oversubscribes
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     torch.set_num_threads(cores)
     et, tt, wt, mt = (torch.from_numpy(x) for x in (e, t, w, m))
 
@@ -61,7 +62,7 @@ def cpu_baseline(offsets, e, t, w, m, budget_s=20.0):
         x = et.clone().requires_grad_(True)
         loss, _, _ = orc.torch_embedding_loss(x, tt, wt, mt, offsets)
         loss.backward()
-        return float(loss)
+        return float(loss.detach())
 
     t0 = time.perf_counter()
     one()  # warm-up (allocator, thread pool)
@@ -148,14 +149,15 @@ def main():
         desc = op.make_desc(spec, Ed)
         affs = torch.empty(B, K, H, W, device=dev)
         lossv = torch.empty(1 + K, device=dev)
+        G = torch.empty(B, K, H, W, device=dev)
         wsb = L.pea_workspace_bytes(ctypes.byref(desc))
         work = torch.empty(max(wsb, 4) // 4, device=dev)
         dE = torch.empty_like(Ed)
         one = torch.ones((), device=dev)
         P = lambda x: ctypes.c_void_p(x.data_ptr())
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        fwd = lambda: L.pea_affinity_fwd(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(affs), P(lossv), P(work), wsb, st)
-        bwd = lambda: L.pea_affinity_bwd(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(one), P(dE), None, st)
+        fwd = lambda: L.pea_affinity_fwd(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(affs), P(G), P(lossv), P(work), wsb, st)
+        bwd = lambda: L.pea_affinity_bwd(ctypes.byref(desc), P(Ed), None, P(G), P(one), P(dE), None, st)
         inf = lambda: L.pea_affinity_infer(ctypes.byref(desc), P(Ed), None, P(affs), st)
         kt = {}
         for name, fn in (("fwd", fwd), ("bwd", bwd), ("infer", inf)):

@@ -18,7 +18,7 @@
  *                          scripts_ac3ac4/loss/loss_embedding_mse.py:169-194 embedding_loss_norm5
  *                          scripts_ac3ac4/loss/loss_embedding_mse.py:30-51,263-289 ema_..._norm1/5
  *                          with loss/loss.py:106-124 WeightedMSE (same in all three script trees) fused in
- *   pea_affinity_bwd    <- the torch.autograd backward of the functions above
+ *   pea_affinity_bwd    <- the torch.autograd backward of the functions above (also the vjp for foreign criteria)
  *                          (the reference has no explicit backward; loss.backward() at
  *                          scripts_cvppp/main.py:311, scripts_ac3ac4/main.py:232)
  *
@@ -107,26 +107,24 @@ size_t pea_workspace_bytes(const PeaDesc *desc);
 int pea_affinity_infer(const PeaDesc *desc, const void *e, const void *e_other, float *affs,
                        void *stream);
 
-/* Training forward: affs (nullable) and loss_out[1 + K] = { loss, L_0 .. L_{K-1} } (device, f32;
- * L_i is the un-weighted per-offset loss, i.e. the reference's all_loss list).
+/* Training forward: affs (nullable), loss_out[1 + K] = { loss, L_0 .. L_{K-1} } (device, f32; L_i is the
+ * un-weighted per-offset loss, i.e. the reference's all_loss list) and, when g_out != NULL,
+ * g_out[B,K,Z,Y,X] = d loss / d affs = lambda_i * 2 w m (a m - t m) / N_i  (0 where the neighbour is cropped
+ * away) -- the only thing the backward needs besides the embeddings.
  * Deterministic: per-workgroup partials in `workspace`, reduced in a fixed order. */
 int pea_affinity_fwd(const PeaDesc *desc, const void *e, const void *e_other, const float *target,
-                     const float *weight, const uint8_t *mask, float *affs, float *loss_out,
+                     const float *weight, const uint8_t *mask, float *affs, float *g_out, float *loss_out,
                      void *workspace, size_t workspace_bytes, void *stream);
 
-/* Training backward: de = dloss * d(loss)/d(e)  (same dtype/layout as e).  `dloss` is a DEVICE
- * f32 scalar (autograd's grad_output), so no host sync is needed.  de_other: NULL when the second
- * operand is detached (convert_consistency_flip, scripts_cvppp/data/data_consistency.py:36),
- * otherwise receives d(loss)/d(e_other).  Gather form, no atomics, bit-reproducible. */
-int pea_affinity_bwd(const PeaDesc *desc, const void *e, const void *e_other, const float *target,
-                     const float *weight, const uint8_t *mask, const float *dloss, void *de,
-                     void *de_other, void *stream);
-
-/* Vector-Jacobian product of the affinity map alone: de = sum_i d_affs_i * d a_i / d e, for callers
- * that apply their own criterion to affs in the host framework (the reference passes `criterion`
- * as an argument, scripts_cvppp/main.py:188-189,284-293, and selects nn.CosineSimilarity for
- * mode != 'ours', scripts_cvppp/loss/loss_embedding_mse.py:11-13).  d_affs: [B,K,Z,Y,X] f32. */
-int pea_affinity_vjp(const PeaDesc *desc, const void *e, const void *e_other, const float *d_affs,
+/* Backward / vector-Jacobian product of the affinity map:
+ *     de = dloss * sum_i g_i * d a_i / d e        (same dtype/layout as e)
+ * g [B,K,Z,Y,X] f32 is either what pea_affinity_fwd wrote (fused WeightedMSE path) or any upstream gradient
+ * d(criterion)/d(affs) of a criterion the caller applied itself (the reference passes `criterion` as an
+ * argument, scripts_cvppp/main.py:188-189,284-293).  `dloss` is a DEVICE f32 scalar (autograd's grad_output)
+ * or NULL (= 1), so no host sync is needed.  de_other: NULL when the second operand is detached
+ * (convert_consistency_flip, scripts_cvppp/data/data_consistency.py:36), otherwise receives the gradient
+ * w.r.t. e_other; de may be NULL when only de_other is wanted.  Gather form, no atomics, bit-reproducible. */
+int pea_affinity_bwd(const PeaDesc *desc, const void *e, const void *e_other, const float *g, const float *dloss,
                      void *de, void *de_other, void *stream);
 
 #ifdef __cplusplus

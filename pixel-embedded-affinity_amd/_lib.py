@@ -22,7 +22,7 @@ NORM_BX, NORM_CROPPED, NORM_FULL = 0, 1, 2
 FLAG_RELU_AFFS = 1
 
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",
-           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_vjp")
+           "pea_affinity_fwd", "pea_affinity_bwd")
 
 
 class PeaLibraryError(RuntimeError):
@@ -91,11 +91,9 @@ def lib():
     L.pea_affinity_infer.restype = ctypes.c_int
     L.pea_affinity_infer.argtypes = [dp, vp, vp, vp, vp]
     L.pea_affinity_fwd.restype = ctypes.c_int
-    L.pea_affinity_fwd.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.pea_affinity_fwd.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.pea_affinity_bwd.restype = ctypes.c_int
-    L.pea_affinity_bwd.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    L.pea_affinity_vjp.restype = ctypes.c_int
-    L.pea_affinity_vjp.argtypes = [dp, vp, vp, vp, vp, vp, vp]
+    L.pea_affinity_bwd.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp]
     if L.pea_version() != PEA_ABI_VERSION:
         raise PeaLibraryError("ABI mismatch: library %d, binding %d" % (L.pea_version(), PEA_ABI_VERSION))
     _lib = L

@@ -147,18 +147,21 @@ class FusedAffinityMSE(torch.autograd.Function):
             loss_vec = torch.empty(1 + spec.K, dtype=torch.float32, device=e_c.device)
             wsb = L.pea_workspace_bytes(ctypes.byref(d))
             work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=e_c.device)
+            # g = d loss / d affs is all the backward needs besides the embeddings; skip it when nothing trains
+            need_g = e.requires_grad or (e_other is not None and e_other.requires_grad)
+            g = torch.empty(kshape, dtype=torch.float32, device=e_c.device) if need_g else None
             _lib.check(L.pea_affinity_fwd(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(target), _ptr(weight), _ptr(mask),
-                                          _ptr(affs), _ptr(loss_vec), _ptr(work), wsb, _stream()), "pea_affinity_fwd")
+                                          _ptr(affs), _ptr(g), _ptr(loss_vec), _ptr(work), wsb, _stream()), "pea_affinity_fwd")
         ctx.spec, ctx.desc = spec, d
         ctx.has_other = o_c is not None
-        ctx.save_for_backward(e_c, o_c, target, weight, mask)
+        ctx.save_for_backward(e_c, o_c, g)
         loss, per_offset = loss_vec[0], loss_vec[1:]  # views of a buffer that is not itself returned
         ctx.mark_non_differentiable(affs, per_offset)
         return loss, affs, per_offset
 
     @staticmethod
     def backward(ctx, dloss, _daffs, _dvec):
-        e_c, o_c, target, weight, mask = ctx.saved_tensors
+        e_c, o_c, g = ctx.saved_tensors
         want_e = ctx.needs_input_grad[0]
         want_o = ctx.has_other and ctx.needs_input_grad[1]
         if not (want_e or want_o):
@@ -167,11 +170,11 @@ class FusedAffinityMSE(torch.autograd.Function):
             raise NotImplementedError("backward needs D in %s (got %d); pad the embedding channels" % (SUPPORTED_TRAIN_D, e_c.shape[1]))
         with torch.cuda.device(e_c.device):
             dl = dloss.to(device=e_c.device, dtype=torch.float32).contiguous()
-            de = torch.empty_like(e_c)
+            de = torch.empty_like(e_c) if want_e else None
             de_o = torch.empty_like(o_c) if want_o else None
-            _lib.check(_lib.lib().pea_affinity_bwd(ctypes.byref(ctx.desc), _ptr(e_c), _ptr(o_c), _ptr(target), _ptr(weight),
-                                                   _ptr(mask), _ptr(dl), _ptr(de), _ptr(de_o), _stream()), "pea_affinity_bwd")
-        return (de if want_e else None), de_o, None, None, None, None
+            _lib.check(_lib.lib().pea_affinity_bwd(ctypes.byref(ctx.desc), _ptr(e_c), _ptr(o_c), _ptr(g), _ptr(dl), _ptr(de),
+                                                   _ptr(de_o), _stream()), "pea_affinity_bwd")
+        return de, de_o, None, None, None, None
 
 
 class AffinityMap(torch.autograd.Function):
@@ -201,11 +204,11 @@ class AffinityMap(torch.autograd.Function):
         with torch.cuda.device(e_c.device):
             d = make_desc(ctx.spec, e_c)
             da = d_affs.to(torch.float32).contiguous()
-            de = torch.empty_like(e_c)
+            de = torch.empty_like(e_c) if want_e else None
             de_o = torch.empty_like(o_c) if want_o else None
-            _lib.check(_lib.lib().pea_affinity_vjp(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(da), _ptr(de), _ptr(de_o),
-                                                   _stream()), "pea_affinity_vjp")
-        return (de if want_e else None), de_o, None
+            _lib.check(_lib.lib().pea_affinity_bwd(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(da), None, _ptr(de), _ptr(de_o),
+                                                   _stream()), "pea_affinity_bwd (vjp)")
+        return de, de_o, None
 
 
 class LossList(list):

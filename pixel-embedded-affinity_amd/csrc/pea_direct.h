@@ -1,0 +1,280 @@
+// pea_direct.h -- common device helpers + the direct (global-memory) kernels.  Included by pea_hip.hip only.
+//
+// The direct kernels are the general fallback (any D in the forward, any offsets that no LDS tile can
+// hold): one lane = one pixel, D-loop in registers, every neighbour vector read from global memory
+// (coalesced row reads; the L2 norm of the neighbour is accumulated while its channels stream in).
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pea.h"
+
+namespace pea {
+
+constexpr int kBlock = 256;  // 4 waves of 64
+constexpr int kXcd = 8;
+
+struct KParams {
+  int B, D, Z, Y, X, K;
+  int S;  // Z*Y*X (fits int32: checked on the host)
+  int border;
+  unsigned flags;
+  float eps;
+  int chunks;          // workgroups per batch item = ceil(S / kBlock)
+  int tiles;           // B * chunks
+  int tiles_per_xcd;   // ceil(tiles / 8)
+  int off[PEA_MAX_K][3];
+  float lam[PEA_MAX_K];
+  float inv_n[PEA_MAX_K];   // 1 / N_i
+  float gscale[PEA_MAX_K];  // 2 * lambda_i / N_i
+  long long tbs, wbs, mbs;  // batch strides (elements) of target / weight / mask
+};
+
+template <typename T>
+__device__ __forceinline__ float ld(const T* p, size_t i);
+template <>
+__device__ __forceinline__ float ld<float>(const float* p, size_t i) { return p[i]; }
+template <>
+__device__ __forceinline__ float ld<__half>(const __half* p, size_t i) { return __half2float(p[i]); }
+
+__device__ __forceinline__ void st(float* p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void st(__half* p, size_t i, float v) { p[i] = __float2half(v); }
+
+// XCD-aware remap: hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
+// id % 8 labels the XCD group.  Give group g the contiguous logical tiles [g*tpx, (g+1)*tpx).
+__device__ __forceinline__ int logical_tile(const KParams& P) {
+  const int bid = blockIdx.x;
+  return (bid % kXcd) * P.tiles_per_xcd + bid / kXcd;
+}
+
+// neighbour of (z,y,x) displaced by o; returns flat index or -1 (CROP_ZERO, outside)
+__device__ __forceinline__ int neighbour(const KParams& P, int z, int y, int x, int oz, int oy, int ox) {
+  int zz = z + oz, yy = y + oy, xx = x + ox;
+  if (P.border == PEA_BORDER_CIRCULAR) {  // host guarantees |o| < dim
+    zz += (zz < 0) ? P.Z : 0; zz -= (zz >= P.Z) ? P.Z : 0;
+    yy += (yy < 0) ? P.Y : 0; yy -= (yy >= P.Y) ? P.Y : 0;
+    xx += (xx < 0) ? P.X : 0; xx -= (xx >= P.X) ? P.X : 0;
+  } else if ((unsigned)zz >= (unsigned)P.Z || (unsigned)yy >= (unsigned)P.Y || (unsigned)xx >= (unsigned)P.X) {
+    return -1;
+  }
+  return (zz * P.Y + yy) * P.X + xx;
+}
+
+__device__ __forceinline__ float inv_norm(float ss, float eps) { return 1.0f / fmaxf(sqrtf(ss), eps); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward (direct form): affs, (TRAIN) per-workgroup loss partials and g = d loss / d affs
+//   D_T > 0: channels unrolled, own pixel kept in registers;  D_T == 0: generic D, own pixel re-read (L1)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D_T, bool TRAIN>
+__global__ __launch_bounds__(kBlock) void k_fwd_direct(const KParams P, const T* __restrict__ e,
+                                                       const T* __restrict__ eo,
+                                                       const float* __restrict__ target,
+                                                       const float* __restrict__ weight,
+                                                       const uint8_t* __restrict__ mask,
+                                                       float* __restrict__ affs, float* __restrict__ gout,
+                                                       float* __restrict__ partials) {
+  extern __shared__ float s_acc[];  // [K][kBlock], TRAIN only
+  const int tile = logical_tile(P);
+  if (tile >= P.tiles) return;  // whole workgroup exits together (tile is uniform)
+  const int b = tile / P.chunks;
+  const int p = (tile - b * P.chunks) * kBlock + threadIdx.x;
+  const bool live = p < P.S;
+  const int D = D_T ? D_T : P.D;
+  const size_t S = (size_t)P.S;
+  const T* eb = e + (size_t)b * D * S;
+  const T* ob = eo + (size_t)b * D * S;
+  const size_t kb = (size_t)b * P.K * S;
+
+  int x = 0, y = 0, z = 0;
+  float ec[D_T ? D_T : 1];
+  float inv_p = 0.f;
+  if (live) {
+    const int yx = P.Y * P.X;
+    z = p / yx;
+    const int r = p - z * yx;
+    y = r / P.X;
+    x = r - y * P.X;
+    float ss = 0.f;
+    if (D_T) {
+#pragma unroll
+      for (int c = 0; c < D_T; ++c) {
+        ec[c] = ld(eb, c * S + p);
+        ss = fmaf(ec[c], ec[c], ss);
+      }
+    } else {
+      for (int c = 0; c < D; ++c) {
+        const float v = ld(eb, c * S + p);
+        ss = fmaf(v, v, ss);
+      }
+    }
+    inv_p = inv_norm(ss, P.eps);
+  }
+
+  for (int i = 0; i < P.K; ++i) {
+    float contrib = 0.f;
+    if (live) {
+      const int q = neighbour(P, z, y, x, P.off[i][0], P.off[i][1], P.off[i][2]);
+      float a = 0.f;
+      if (q >= 0) {
+        float dot = 0.f, sq = 0.f;
+        if (D_T) {
+#pragma unroll
+          for (int c = 0; c < D_T; ++c) {
+            const float v = ld(ob, c * S + q);
+            dot = fmaf(ec[c], v, dot);
+            sq = fmaf(v, v, sq);
+          }
+        } else {
+          for (int c = 0; c < D; ++c) {
+            const float v = ld(ob, c * S + q);
+            dot = fmaf(ld(eb, c * S + p), v, dot);
+            sq = fmaf(v, v, sq);
+          }
+        }
+        a = dot * inv_p * inv_norm(sq, P.eps);
+      }
+      const size_t in = (size_t)i * S + p;
+      if (affs) affs[kb + in] = (P.flags & PEA_FLAG_RELU_AFFS) ? fmaxf(a, 0.f) : a;
+      if (TRAIN) {
+        float g = 0.f;
+        if (q >= 0) {
+          const float m = mask ? (float)mask[(size_t)b * P.mbs + in] : 1.f;
+          const float r = a * m - target[(size_t)b * P.tbs + in] * m;
+          const float wr = weight[(size_t)b * P.wbs + in] * r;
+          contrib = wr * r;
+          g = P.gscale[i] * wr * m;
+        }
+        if (gout) gout[kb + in] = g;
+      }
+    }
+    if (TRAIN) s_acc[i * kBlock + threadIdx.x] = contrib;
+  }
+
+  if (TRAIN) {
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = wave; i < P.K; i += kBlock / 64) {
+      const float* row = s_acc + i * kBlock;
+      float v = (row[lane] + row[lane + 64]) + (row[lane + 128] + row[lane + 192]);
+      v = wave_sum(v);
+      if (lane == 0) partials[(size_t)i * P.tiles + tile] = v;  // [K][nparts]: coalesced for the finalize
+    }
+  }
+}
+
+// fixed-order f64 reduction of the per-workgroup partials ([K][nparts]): loss_out = {loss, L_0..L_{K-1}}.
+// All 16 waves work on every offset; per offset the order is: per-thread strided sum -> wave tree ->
+// waves in index order.  Nothing depends on timing, so the result is bit-reproducible.
+__global__ __launch_bounds__(1024) void k_loss_finalize(const KParams P, const float* __restrict__ partials,
+                                                        int nparts, float* __restrict__ loss_out) {
+  __shared__ double s_w[16][PEA_MAX_K];
+  __shared__ double s_l[PEA_MAX_K];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = 0; i < P.K; ++i) {
+    const float* row = partials + (size_t)i * nparts;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int t = threadIdx.x; t < nparts; t += 1024) acc += (double)row[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) s_w[wave][i] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < P.K) {
+    const int i = threadIdx.x;
+    double acc = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) acc += s_w[w][i];
+    const double Li = acc * (double)P.inv_n[i];
+    s_l[i] = Li;
+    loss_out[1 + i] = (float)Li;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < P.K; ++i) tot += (double)P.lam[i] * s_l[i];
+    loss_out[0] = (float)tot;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward (direct gather form).  x = the tensor being differentiated, g = d loss / d affs [B,K,S].
+//   ROLE_A: x is the first operand:  G(p) += g_i(p)       * nhat(p + o_i),  n = nbA (second operand)
+//   ROLE_B: x is the second operand: G(p) += g_i(p - o_i) * nhat(p - o_i),  n = nbB (first operand)
+//   self loss: both roles, nbA = nbB = x.
+//   dx(p) = dloss * (G - xhat <xhat, G>) / n(p)        (G / eps when |x(p)| < eps)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D_T, bool ROLE_A, bool ROLE_B>
+__global__ __launch_bounds__(kBlock) void k_bwd_direct(const KParams P, const T* __restrict__ xt,
+                                                       const T* __restrict__ nbA, const T* __restrict__ nbB,
+                                                       const float* __restrict__ gin,
+                                                       const float* __restrict__ dloss, T* __restrict__ dx) {
+  static_assert(D_T > 0, "backward is specialised on D");
+  const int tile = logical_tile(P);
+  if (tile >= P.tiles) return;
+  const int b = tile / P.chunks;
+  const int p = (tile - b * P.chunks) * kBlock + threadIdx.x;
+  if (p >= P.S) return;
+  const size_t S = (size_t)P.S;
+  const T* xb = xt + (size_t)b * D_T * S;
+  const float* gb = gin + (size_t)b * P.K * S;
+  const float dl = dloss ? dloss[0] : 1.f;
+
+  const int yx = P.Y * P.X;
+  const int z = p / yx;
+  const int r0 = p - z * yx;
+  const int y = r0 / P.X;
+  const int x = r0 - y * P.X;
+
+  float xc[D_T], G[D_T];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < D_T; ++c) {
+    xc[c] = ld(xb, c * S + p);
+    ss = fmaf(xc[c], xc[c], ss);
+    G[c] = 0.f;
+  }
+  const float nrm = sqrtf(ss);
+  const float inv_p = 1.0f / fmaxf(nrm, P.eps);
+
+  for (int i = 0; i < P.K; ++i) {
+    const int oz = P.off[i][0], oy = P.off[i][1], ox = P.off[i][2];
+#pragma unroll
+    for (int role = 0; role < 2; ++role) {
+      if (role == 0 ? !ROLE_A : !ROLE_B) continue;
+      const int sg = role == 0 ? 1 : -1;
+      const int q = neighbour(P, z, y, x, sg * oz, sg * oy, sg * ox);
+      if (q < 0) continue;
+      const T* nb = (role == 0 ? nbA : nbB) + (size_t)b * D_T * S;
+      float v[D_T], sq = 0.f;
+#pragma unroll
+      for (int c = 0; c < D_T; ++c) {
+        v[c] = ld(nb, c * S + q);
+        sq = fmaf(v[c], v[c], sq);
+      }
+      // the loss term lives at the first operand's pixel: p for role A, the neighbour for role B
+      const float g = gb[(size_t)i * S + (role == 0 ? p : q)] * inv_norm(sq, P.eps);
+#pragma unroll
+      for (int c = 0; c < D_T; ++c) G[c] = fmaf(g, v[c], G[c]);
+    }
+  }
+
+  float proj = 0.f;
+#pragma unroll
+  for (int c = 0; c < D_T; ++c) proj = fmaf(xc[c] * inv_p, G[c], proj);
+  if (nrm < P.eps) proj = 0.f;  // clamp_min branch of F.normalize: d ehat / d e = I / eps
+  T* db = dx + (size_t)b * D_T * S;
+  const float sc = dl * inv_p;
+#pragma unroll
+  for (int c = 0; c < D_T; ++c) st(db, c * S + p, (G[c] - xc[c] * inv_p * proj) * sc);
+}
+
+}  // namespace pea

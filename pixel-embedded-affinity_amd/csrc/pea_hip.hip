@@ -8,311 +8,27 @@
 // reduction) and one backward launch.  See include/pea.h for the contract and DESIGN.md for the
 // data layout, the per-kernel roofline and the algorithmic byte counts.
 //
-// Design notes (gfx950):
-//   * HBM-bound op (2-7 flop/B): no MFMA.  One lane = one pixel, D-loop in registers, NCHW planes
-//     => every stencil read is a coalesced row read shifted by dx elements.
-//   * the L2 norm of the neighbour is accumulated while its channels stream in for the dot product,
-//     so ehat is never materialised:  a = <e_p, e_q> / (max(|e_p|,eps) * max(|e_q|,eps)).
-//   * 8 XCDs with private L2s: the 1-D grid is remapped so each XCD walks a contiguous span of the
-//     batch/rows; stencil re-reads then hit that XCD's own L2 instead of crossing the fabric.
-//   * loss: per-lane LDS slots -> per-workgroup partials in a caller-provided workspace -> fixed-order
-//     f64 reduction.  No float atomics anywhere: results are bit-reproducible run to run.
-//   * backward is in gather form (each pixel pulls its 2K contributions): no atomics.
-#include <hip/hip_fp16.h>
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+// This file is the host side: descriptor validation, tile planning and kernel dispatch.
+//   pea_tiled.h   LDS-tiled kernels (fast path; D = 16 this round)
+//   pea_direct.h  global-memory kernels (general fallback) + the deterministic loss finalize
+// Common to both: HBM-bound op (2-7 flop/B) => no MFMA; the L2 norm of a neighbour is accumulated while
+// its channels stream in, so ehat is never materialised in HBM; the 1-D grid is remapped so each of the 8
+// XCDs walks a contiguous span of tiles (stencil re-reads hit that XCD's own L2); loss partials per
+// workgroup in a caller-provided workspace -> fixed-order f64 reduction; backward in gather form.  No
+// float atomics anywhere: results are bit-reproducible run to run.
+#include <stdlib.h>
 
-#include "../../include/pea.h"
+#include <algorithm>
+
+#include "pea_direct.h"
+#include "pea_tiled.h"
+
+using namespace pea;
 
 namespace {
 
-constexpr int kBlock = 256;  // 4 waves of 64
-constexpr int kXcd = 8;
-
-struct KParams {
-  int B, D, Z, Y, X, K;
-  int S;  // Z*Y*X (fits int32: checked on the host)
-  int border;
-  unsigned flags;
-  float eps;
-  int chunks;          // workgroups per batch item = ceil(S / kBlock)
-  int tiles;           // B * chunks
-  int tiles_per_xcd;   // ceil(tiles / 8)
-  int off[PEA_MAX_K][3];
-  float lam[PEA_MAX_K];
-  float inv_n[PEA_MAX_K];   // 1 / N_i
-  float gscale[PEA_MAX_K];  // 2 * lambda_i / N_i
-  long long tbs, wbs, mbs;  // batch strides (elements) of target / weight / mask
-};
-
-template <typename T>
-__device__ __forceinline__ float ld(const T* p, size_t i);
-template <>
-__device__ __forceinline__ float ld<float>(const float* p, size_t i) { return p[i]; }
-template <>
-__device__ __forceinline__ float ld<__half>(const __half* p, size_t i) { return __half2float(p[i]); }
-
-__device__ __forceinline__ void st(float* p, size_t i, float v) { p[i] = v; }
-__device__ __forceinline__ void st(__half* p, size_t i, float v) { p[i] = __float2half(v); }
-
-// XCD-aware remap: hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
-// id % 8 labels the XCD group.  Give group g the contiguous logical tiles [g*tpx, (g+1)*tpx).
-__device__ __forceinline__ int logical_tile(const KParams& P) {
-  const int bid = blockIdx.x;
-  return (bid % kXcd) * P.tiles_per_xcd + bid / kXcd;
-}
-
-// neighbour of (z,y,x) displaced by sign*o; returns flat index or -1 (CROP_ZERO, outside)
-__device__ __forceinline__ int neighbour(const KParams& P, int z, int y, int x, int oz, int oy, int ox) {
-  int zz = z + oz, yy = y + oy, xx = x + ox;
-  if (P.border == PEA_BORDER_CIRCULAR) {  // host guarantees |o| < dim
-    zz += (zz < 0) ? P.Z : 0; zz -= (zz >= P.Z) ? P.Z : 0;
-    yy += (yy < 0) ? P.Y : 0; yy -= (yy >= P.Y) ? P.Y : 0;
-    xx += (xx < 0) ? P.X : 0; xx -= (xx >= P.X) ? P.X : 0;
-  } else if ((unsigned)zz >= (unsigned)P.Z || (unsigned)yy >= (unsigned)P.Y || (unsigned)xx >= (unsigned)P.X) {
-    return -1;
-  }
-  return (zz * P.Y + yy) * P.X + xx;
-}
-
-__device__ __forceinline__ float inv_norm(float ss, float eps) { return 1.0f / fmaxf(sqrtf(ss), eps); }
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
-}
-
 // ------------------------------------------------------------------------------------------------
-// forward (direct form): affs, and (TRAIN) per-workgroup loss partials
-//   D_T > 0: channels unrolled, own pixel kept in registers;  D_T == 0: generic D, own pixel re-read (L1)
-// ------------------------------------------------------------------------------------------------
-template <typename T, int D_T, bool TRAIN>
-__global__ __launch_bounds__(kBlock) void k_fwd_direct(const KParams P, const T* __restrict__ e,
-                                                       const T* __restrict__ eo,
-                                                       const float* __restrict__ target,
-                                                       const float* __restrict__ weight,
-                                                       const uint8_t* __restrict__ mask,
-                                                       float* __restrict__ affs, float* __restrict__ partials) {
-  extern __shared__ float s_acc[];  // [K][kBlock], TRAIN only
-  const int tile = logical_tile(P);
-  if (tile >= P.tiles) return;  // whole workgroup exits together (tile is uniform)
-  const int b = tile / P.chunks;
-  const int p = (tile - b * P.chunks) * kBlock + threadIdx.x;
-  const bool live = p < P.S;
-  const int D = D_T ? D_T : P.D;
-  const size_t S = (size_t)P.S;
-  const T* eb = e + (size_t)b * D * S;
-  const T* ob = eo + (size_t)b * D * S;
-  const size_t kb = (size_t)b * P.K * S;
-
-  int x = 0, y = 0, z = 0;
-  float ec[D_T ? D_T : 1];
-  float inv_p = 0.f;
-  if (live) {
-    const int yx = P.Y * P.X;
-    z = p / yx;
-    const int r = p - z * yx;
-    y = r / P.X;
-    x = r - y * P.X;
-    float ss = 0.f;
-    if (D_T) {
-#pragma unroll
-      for (int c = 0; c < D_T; ++c) {
-        ec[c] = ld(eb, c * S + p);
-        ss = fmaf(ec[c], ec[c], ss);
-      }
-    } else {
-      for (int c = 0; c < D; ++c) {
-        const float v = ld(eb, c * S + p);
-        ss = fmaf(v, v, ss);
-      }
-    }
-    inv_p = inv_norm(ss, P.eps);
-  }
-
-  for (int i = 0; i < P.K; ++i) {
-    float contrib = 0.f;
-    if (live) {
-      const int q = neighbour(P, z, y, x, P.off[i][0], P.off[i][1], P.off[i][2]);
-      float a = 0.f;
-      if (q >= 0) {
-        float dot = 0.f, sq = 0.f;
-        if (D_T) {
-#pragma unroll
-          for (int c = 0; c < D_T; ++c) {
-            const float v = ld(ob, c * S + q);
-            dot = fmaf(ec[c], v, dot);
-            sq = fmaf(v, v, sq);
-          }
-        } else {
-          for (int c = 0; c < D; ++c) {
-            const float v = ld(ob, c * S + q);
-            dot = fmaf(ld(eb, c * S + p), v, dot);
-            sq = fmaf(v, v, sq);
-          }
-        }
-        a = dot * inv_p * inv_norm(sq, P.eps);
-      }
-      const size_t ki = kb + (size_t)i * S + p;
-      if (affs) affs[ki] = (P.flags & PEA_FLAG_RELU_AFFS) ? fmaxf(a, 0.f) : a;
-      if (TRAIN && q >= 0) {
-        const size_t in = (size_t)i * S + p;
-        const float m = mask ? (float)mask[(size_t)b * P.mbs + in] : 1.f;
-        const float r = a * m - target[(size_t)b * P.tbs + in] * m;
-        contrib = weight[(size_t)b * P.wbs + in] * r * r;
-      }
-    }
-    if (TRAIN) s_acc[i * kBlock + threadIdx.x] = contrib;
-  }
-
-  if (TRAIN) {
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = wave; i < P.K; i += kBlock / 64) {
-      const float* row = s_acc + i * kBlock;
-      float v = (row[lane] + row[lane + 64]) + (row[lane + 128] + row[lane + 192]);
-      v = wave_sum(v);
-      if (lane == 0) partials[(size_t)tile * P.K + i] = v;
-    }
-  }
-}
-
-// fixed-order f64 reduction of the per-workgroup partials: loss_out = {loss, L_0..L_{K-1}}
-__global__ __launch_bounds__(1024) void k_loss_finalize(const KParams P, const float* __restrict__ partials,
-                                                        int nparts, float* __restrict__ loss_out) {
-  __shared__ double s_l[PEA_MAX_K];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int i = wave; i < P.K; i += 16) {
-    double acc = 0.0;
-    for (int t = lane; t < nparts; t += 64) acc += (double)partials[(size_t)t * P.K + i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if (lane == 0) {
-      const double Li = acc * (double)P.inv_n[i];
-      s_l[i] = Li;
-      loss_out[1 + i] = (float)Li;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot = 0.0;
-    for (int i = 0; i < P.K; ++i) tot += (double)P.lam[i] * s_l[i];
-    loss_out[0] = (float)tot;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// backward (direct gather form).  x = the tensor being differentiated.
-//   ROLE_A: x is the first operand:  G(p) += g_i(p)       * nhat(p + o_i),  n = nb (second operand)
-//   ROLE_B: x is the second operand: G(p) += g_i(p - o_i) * nhat(p - o_i),  n = nb2 (first operand)
-//   self loss: both roles, nb = nb2 = x.   EXPLICIT: g_i = d_affs[b,i,.] (vjp for foreign criteria)
-//   de(p) = dloss * (G - xhat <xhat, G>) / n(p)        (G / eps when |x(p)| < eps)
-// ------------------------------------------------------------------------------------------------
-template <typename T, int D_T, bool ROLE_A, bool ROLE_B, bool EXPLICIT>
-__global__ __launch_bounds__(kBlock) void k_bwd_direct(const KParams P, const T* __restrict__ xt,
-                                                       const T* __restrict__ nbA, const T* __restrict__ nbB,
-                                                       const float* __restrict__ target,
-                                                       const float* __restrict__ weight,
-                                                       const uint8_t* __restrict__ mask,
-                                                       const float* __restrict__ d_affs,
-                                                       const float* __restrict__ dloss, T* __restrict__ dx) {
-  static_assert(D_T > 0, "backward is specialised on D");
-  const int tile = logical_tile(P);
-  if (tile >= P.tiles) return;
-  const int b = tile / P.chunks;
-  const int p = (tile - b * P.chunks) * kBlock + threadIdx.x;
-  if (p >= P.S) return;
-  const size_t S = (size_t)P.S;
-  const T* xb = xt + (size_t)b * D_T * S;
-  const size_t kb = (size_t)b * P.K * S;
-  const float dl = EXPLICIT ? 1.f : dloss[0];
-
-  const int yx = P.Y * P.X;
-  const int z = p / yx;
-  const int r0 = p - z * yx;
-  const int y = r0 / P.X;
-  const int x = r0 - y * P.X;
-
-  float xc[D_T], G[D_T];
-  float ss = 0.f;
-#pragma unroll
-  for (int c = 0; c < D_T; ++c) {
-    xc[c] = ld(xb, c * S + p);
-    ss = fmaf(xc[c], xc[c], ss);
-    G[c] = 0.f;
-  }
-  const float nrm = sqrtf(ss);
-  const float inv_p = 1.0f / fmaxf(nrm, P.eps);
-
-  for (int i = 0; i < P.K; ++i) {
-    const int oz = P.off[i][0], oy = P.off[i][1], ox = P.off[i][2];
-    if (ROLE_A) {
-      const int q = neighbour(P, z, y, x, oz, oy, ox);
-      if (q >= 0) {
-        const T* nb = nbA + (size_t)b * D_T * S;
-        float v[D_T], dot = 0.f, sq = 0.f;
-#pragma unroll
-        for (int c = 0; c < D_T; ++c) {
-          v[c] = ld(nb, c * S + q);
-          dot = fmaf(xc[c], v[c], dot);
-          sq = fmaf(v[c], v[c], sq);
-        }
-        const float inv_q = inv_norm(sq, P.eps);
-        const size_t in = (size_t)i * S + p;
-        float g;
-        if (EXPLICIT) {
-          g = d_affs[kb + in];
-        } else {
-          const float m = mask ? (float)mask[(size_t)b * P.mbs + in] : 1.f;
-          const float a = dot * inv_p * inv_q;
-          g = P.gscale[i] * weight[(size_t)b * P.wbs + in] * m * (a * m - target[(size_t)b * P.tbs + in] * m);
-        }
-        g *= inv_q;
-#pragma unroll
-        for (int c = 0; c < D_T; ++c) G[c] = fmaf(g, v[c], G[c]);
-      }
-    }
-    if (ROLE_B) {
-      const int q = neighbour(P, z, y, x, -oz, -oy, -ox);
-      if (q >= 0) {
-        const T* nb = nbB + (size_t)b * D_T * S;
-        float v[D_T], dot = 0.f, sq = 0.f;
-#pragma unroll
-        for (int c = 0; c < D_T; ++c) {
-          v[c] = ld(nb, c * S + q);
-          dot = fmaf(xc[c], v[c], dot);
-          sq = fmaf(v[c], v[c], sq);
-        }
-        const float inv_q = inv_norm(sq, P.eps);
-        const size_t in = (size_t)i * S + q;  // the loss term lives at the first operand's pixel
-        float g;
-        if (EXPLICIT) {
-          g = d_affs[kb + in];
-        } else {
-          const float m = mask ? (float)mask[(size_t)b * P.mbs + in] : 1.f;
-          const float a = dot * inv_p * inv_q;
-          g = P.gscale[i] * weight[(size_t)b * P.wbs + in] * m * (a * m - target[(size_t)b * P.tbs + in] * m);
-        }
-        g *= inv_q;
-#pragma unroll
-        for (int c = 0; c < D_T; ++c) G[c] = fmaf(g, v[c], G[c]);
-      }
-    }
-  }
-
-  float proj = 0.f;
-#pragma unroll
-  for (int c = 0; c < D_T; ++c) proj = fmaf(xc[c] * inv_p, G[c], proj);
-  if (nrm < P.eps) proj = 0.f;  // clamp_min branch of F.normalize: d ehat / d e = I / eps
-  T* db = dx + (size_t)b * D_T * S;
-  const float sc = dl * inv_p;
-#pragma unroll
-  for (int c = 0; c < D_T; ++c) st(db, c * S + p, (G[c] - xc[c] * inv_p * proj) * sc);
-}
-
-// ------------------------------------------------------------------------------------------------
-// host side
+// descriptor -> kernel parameters
 // ------------------------------------------------------------------------------------------------
 int validate(const PeaDesc* d) {
   if (!d) return PEA_E_NULL;
@@ -359,7 +75,7 @@ KParams make_params(const PeaDesc* d) {
       else if (d->norm == PEA_NORM_FULL) n = (double)d->B * P.S;
       else {
         n = d->B;
-        for (int a = 0; a < 3; ++a) n *= (double)(d->dims[a] - (d->offsets[i][a] < 0 ? -d->offsets[i][a] : d->offsets[i][a]));
+        for (int a = 0; a < 3; ++a) n *= (double)(d->dims[a] - abs(d->offsets[i][a]));
       }
     }
     for (int a = 0; a < 3; ++a) P.off[i][a] = on ? d->offsets[i][a] : 0;
@@ -370,78 +86,226 @@ KParams make_params(const PeaDesc* d) {
   return P;
 }
 
-inline dim3 grid_of(const KParams& P) { return dim3((unsigned)(P.tiles_per_xcd * kXcd)); }
-
 inline int hip_rc() {
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? PEA_OK : (int)e;
 }
 
-template <typename T, bool TRAIN>
-int launch_fwd(const KParams& P, const void* e, const void* eo, const float* t, const float* w, const uint8_t* m,
-               float* affs, float* partials, hipStream_t s) {
-  const T* ep = (const T*)e;
-  const T* op = eo ? (const T*)eo : ep;
-  const size_t lds = TRAIN ? (size_t)P.K * kBlock * sizeof(float) : 0;
-  const dim3 g = grid_of(P), blk(kBlock);
-  switch (P.D) {
-    case 16: hipLaunchKernelGGL((k_fwd_direct<T, 16, TRAIN>), g, blk, lds, s, P, ep, op, t, w, m, affs, partials); break;
-    case 32: hipLaunchKernelGGL((k_fwd_direct<T, 32, TRAIN>), g, blk, lds, s, P, ep, op, t, w, m, affs, partials); break;
-    case 64: hipLaunchKernelGGL((k_fwd_direct<T, 64, TRAIN>), g, blk, lds, s, P, ep, op, t, w, m, affs, partials); break;
-    default: hipLaunchKernelGGL((k_fwd_direct<T, 0, TRAIN>), g, blk, lds, s, P, ep, op, t, w, m, affs, partials); break;
-  }
-  return hip_rc();
-}
-
-template <typename T, int D_T, bool EXPLICIT>
-int launch_bwd_roles(const KParams& P, int roles, const T* x, const T* nbA, const T* nbB, const float* t,
-                     const float* w, const uint8_t* m, const float* da, const float* dl, T* dx, hipStream_t s) {
-  const dim3 g = grid_of(P), blk(kBlock);
-  if (roles == 3) hipLaunchKernelGGL((k_bwd_direct<T, D_T, true, true, EXPLICIT>), g, blk, 0, s, P, x, nbA, nbB, t, w, m, da, dl, dx);
-  else if (roles == 1) hipLaunchKernelGGL((k_bwd_direct<T, D_T, true, false, EXPLICIT>), g, blk, 0, s, P, x, nbA, nbB, t, w, m, da, dl, dx);
-  else hipLaunchKernelGGL((k_bwd_direct<T, D_T, false, true, EXPLICIT>), g, blk, 0, s, P, x, nbA, nbB, t, w, m, da, dl, dx);
-  return hip_rc();
-}
-
-template <typename T, bool EXPLICIT>
-int launch_bwd(const KParams& P, int roles, const void* x, const void* nbA, const void* nbB, const float* t,
-               const float* w, const uint8_t* m, const float* da, const float* dl, void* dx, hipStream_t s) {
-  switch (P.D) {
-    case 16: return launch_bwd_roles<T, 16, EXPLICIT>(P, roles, (const T*)x, (const T*)nbA, (const T*)nbB, t, w, m, da, dl, (T*)dx, s);
-    case 32: return launch_bwd_roles<T, 32, EXPLICIT>(P, roles, (const T*)x, (const T*)nbA, (const T*)nbB, t, w, m, da, dl, (T*)dx, s);
-    case 64: return launch_bwd_roles<T, 64, EXPLICIT>(P, roles, (const T*)x, (const T*)nbA, (const T*)nbB, t, w, m, da, dl, (T*)dx, s);
-    case 4: return launch_bwd_roles<T, 4, EXPLICIT>(P, roles, (const T*)x, (const T*)nbA, (const T*)nbB, t, w, m, da, dl, (T*)dx, s);
-    case 8: return launch_bwd_roles<T, 8, EXPLICIT>(P, roles, (const T*)x, (const T*)nbA, (const T*)nbB, t, w, m, da, dl, (T*)dx, s);
-    default: return PEA_E_UNSUPPORTED;  // training needs D in {4, 8, 16, 32, 64}
-  }
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
 }
 
 bool misaligned(const void* p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
 
-template <bool EXPLICIT>
-int bwd_common(const PeaDesc* desc, const void* e, const void* e_other, const float* target, const float* weight,
-               const uint8_t* mask, const float* d_affs, const float* dloss, void* de, void* de_other, void* stream) {
-  int rc = validate(desc);
-  if (rc) return rc;
-  if (!e || !de) return PEA_E_NULL;
-  if (EXPLICIT ? !d_affs : (!target || !weight || !dloss)) return PEA_E_NULL;
-  if (de_other && !e_other) return PEA_E_NULL;
-  const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
-  if (misaligned(e, es) || misaligned(e_other, es) || misaligned(de, es) || misaligned(de_other, es) ||
-      misaligned(target, 4) || misaligned(weight, 4) || misaligned(d_affs, 4) || misaligned(dloss, 4))
-    return PEA_E_ALIGN;
-  const KParams P = make_params(desc);
-  hipStream_t s = (hipStream_t)stream;
-  const bool h = desc->dtype == PEA_F16;
-  if (!e_other) {
-    return h ? launch_bwd<__half, EXPLICIT>(P, 3, e, e, e, target, weight, mask, d_affs, dloss, de, s)
-             : launch_bwd<float, EXPLICIT>(P, 3, e, e, e, target, weight, mask, d_affs, dloss, de, s);
+// ------------------------------------------------------------------------------------------------
+// tile planning
+// ------------------------------------------------------------------------------------------------
+struct TileCfg { int TH, TW, PLQ; };  // workgroup = TH*TW lanes (one per pixel); PLQ = LDS plane stride in pixels
+// compiled-in shapes; index chosen by PEA_FWD_CFG / PEA_BWD_CFG (defaults = the measured best, CVPPP stencil)
+constexpr TileCfg kFwdCfg[] = {{16, 32, 1040}, {32, 32, 1696}, {8, 64, 1248}};
+constexpr TileCfg kBwdCfg[] = {{32, 32, 2504}, {16, 32, 1712}};
+constexpr int kNumFwdCfg = sizeof(kFwdCfg) / sizeof(kFwdCfg[0]), kNumBwdCfg = sizeof(kBwdCfg) / sizeof(kBwdCfg[0]);
+constexpr int kFwdDefault = 0, kBwdDefault = 0;
+constexpr int kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may take all of it
+
+// Choose the "near" offsets (served from LDS): the largest in-plane radius whose halo'd region still fits the
+// LDS planes of this tile shape.  both_sides: the backward needs p - o as well as p + o.
+bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, TParams* Q) {
+  if ((long long)P.Y * P.X > (1LL << 29)) return false;                      // 32-bit byte offsets in a plane
+  if ((long long)std::max(P.D, P.K) * P.S * 4 > 0xFFFFFFFFLL) return false;  // buffer soffset is 32-bit
+  const int NT = c.TH * c.TW;
+  int radii[PEA_MAX_K], nr = 0;
+  for (int i = 0; i < P.K; ++i)
+    if (P.off[i][0] == 0) radii[nr++] = std::max(abs(P.off[i][1]), abs(P.off[i][2]));
+  std::sort(radii, radii + nr);
+  const int rcap = env_int("PEA_NEAR_R", 1 << 30);
+  for (int k = nr - 1; k >= 0; --k) {
+    const int rc = radii[k];
+    if (rc > rcap) continue;
+    TParams q = {};
+    unsigned near_mask = 0;
+    for (int i = 0; i < P.K; ++i) {
+      const int oy = P.off[i][1], ox = P.off[i][2];
+      if (P.off[i][0] != 0 || std::max(abs(oy), abs(ox)) > rc) continue;
+      near_mask |= 1u << i;
+      q.hy0 = std::max(q.hy0, both_sides ? abs(oy) : -oy);
+      q.hy1 = std::max(q.hy1, both_sides ? abs(oy) : oy);
+      q.hx0 = std::max(q.hx0, both_sides ? abs(ox) : -ox);
+      q.hx1 = std::max(q.hx1, both_sides ? abs(ox) : ox);
+    }
+    q.RH = c.TH + q.hy0 + q.hy1;
+    q.RW = c.TW + q.hx0 + q.hx1;
+    q.R = q.RH * q.RW;
+    if (q.R > c.PLQ) continue;
+    // the kernels wrap with one conditional add
+    if (P.Y < c.TH + q.hy1 || P.Y < q.hy0 || P.X < c.TW + q.hx1 || P.X < q.hx0) continue;
+    q.dr = NT / q.RW;
+    q.dc = NT % q.RW;
+    q.inv_rw = 1.0f / (float)q.RW;
+    q.inv_eps = 1.0f / P.eps;
+    q.tiles_y = (P.Y + c.TH - 1) / c.TH;
+    q.tiles_x = (P.X + c.TW - 1) / c.TW;
+    q.tiles_per_plane = q.tiles_y * q.tiles_x;
+    const long long nt = (long long)q.tiles_per_plane * P.Z * P.B;
+    if (nt > 0x7fffff00LL) return false;
+    q.ntiles = (int)nt;
+    q.tiles_per_xcd = (q.ntiles + kXcd - 1) / kXcd;
+    for (int i = 0; i < P.K; ++i) {
+      const int oy = P.off[i][1], ox = P.off[i][2];
+      const int oyx = (int)(((unsigned)oy << 16) | ((unsigned)ox & 0xffffu));
+      if (near_mask >> i & 1u) q.near[q.n_near++] = OffEnt{i, oy * q.RW + ox, oyx, P.gscale[i]};
+      else q.far[q.n_far++] = OffEnt{i, P.off[i][0], oyx, P.gscale[i]};
+    }
+    *Q = q;
+    return true;
   }
-  rc = h ? launch_bwd<__half, EXPLICIT>(P, 1, e, e_other, nullptr, target, weight, mask, d_affs, dloss, de, s)
-         : launch_bwd<float, EXPLICIT>(P, 1, e, e_other, nullptr, target, weight, mask, d_affs, dloss, de, s);
-  if (rc || !de_other) return rc;
-  return h ? launch_bwd<__half, EXPLICIT>(P, 2, e_other, nullptr, e, target, weight, mask, d_affs, dloss, de_other, s)
-           : launch_bwd<float, EXPLICIT>(P, 2, e_other, nullptr, e, target, weight, mask, d_affs, dloss, de_other, s);
+  return false;
+}
+
+template <auto KERNEL>
+void allow_lds(size_t bytes) {
+  static size_t cur = 64 * 1024;
+  if (bytes > cur) {
+    (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    cur = bytes;
+  }
+}
+
+size_t fwd_partials(const KParams& P) {
+  // worst case over the paths pea_affinity_fwd may take
+  size_t n = (size_t)P.tiles;
+  for (const TileCfg& c : kFwdCfg) {
+    TParams q;
+    if (plan_tiles(P, c, false, &q)) n = std::max(n, (size_t)q.ntiles);
+  }
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward dispatch
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D_T, bool TRAIN, bool SELF, int CI>
+void launch_fwd_cfg(const KParams& P, const TParams& Q, const T* e, const T* eo, const float* t, const float* w,
+                    const uint8_t* m, float* affs, float* gout, float* partials, hipStream_t s) {
+  constexpr TileCfg c = kFwdCfg[CI];
+  constexpr int NT = c.TH * c.TW;
+  const size_t lds = Lds<D_T, c.PLQ>::kBytes + (TRAIN ? (size_t)(NT / 64) * P.K * sizeof(float) : 0);
+  const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(NT);
+  if (P.border == PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_fwd_tiled<T, D_T, c.TH, c.TW, c.PLQ, false, TRAIN, SELF>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials);
+  } else {
+    constexpr auto kern = k_fwd_tiled<T, D_T, c.TH, c.TW, c.PLQ, true, TRAIN, SELF>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials);
+  }
+}
+
+// returns true if a tiled kernel was launched (nparts = number of partial rows written)
+template <typename T, int D_T, bool TRAIN>
+bool try_fwd_tiled(const KParams& P, const T* e, const T* eo, const float* t, const float* w, const uint8_t* m, float* affs,
+                   float* gout, float* partials, hipStream_t s, int* nparts) {
+  const int ci = env_int("PEA_FWD_CFG", kFwdDefault);
+  if (ci < 0 || ci >= kNumFwdCfg) return false;
+  TParams Q;
+  if (!plan_tiles(P, kFwdCfg[ci], false, &Q)) return false;
+  const bool self = (eo == e);
+#define PEA_FWD_CASE(CI)                                                                             \
+  case CI:                                                                                           \
+    if (self) launch_fwd_cfg<T, D_T, TRAIN, true, CI>(P, Q, e, eo, t, w, m, affs, gout, partials, s); \
+    else launch_fwd_cfg<T, D_T, TRAIN, false, CI>(P, Q, e, eo, t, w, m, affs, gout, partials, s);     \
+    break;
+  switch (ci) { PEA_FWD_CASE(0) PEA_FWD_CASE(1) PEA_FWD_CASE(2) default: return false; }
+#undef PEA_FWD_CASE
+  *nparts = Q.ntiles;
+  return true;
+}
+
+template <typename T, bool TRAIN>
+int launch_fwd(const KParams& P, const void* e, const void* eo, const float* t, const float* w, const uint8_t* m,
+               float* affs, float* gout, float* partials, hipStream_t s, int* nparts) {
+  const T* ep = (const T*)e;
+  const T* op = eo ? (const T*)eo : ep;
+  if (env_int("PEA_FORCE_DIRECT", 0) == 0) {
+    bool done = false;
+    if (P.D == 16) done = try_fwd_tiled<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
+    if (done) return hip_rc();
+  }
+  const size_t lds = TRAIN ? (size_t)P.K * kBlock * sizeof(float) : 0;
+  const dim3 g((unsigned)(P.tiles_per_xcd * kXcd)), blk(kBlock);
+  *nparts = P.tiles;
+  switch (P.D) {
+    case 16: hipLaunchKernelGGL((k_fwd_direct<T, 16, TRAIN>), g, blk, lds, s, P, ep, op, t, w, m, affs, gout, partials); break;
+    case 32: hipLaunchKernelGGL((k_fwd_direct<T, 32, TRAIN>), g, blk, lds, s, P, ep, op, t, w, m, affs, gout, partials); break;
+    case 64: hipLaunchKernelGGL((k_fwd_direct<T, 64, TRAIN>), g, blk, lds, s, P, ep, op, t, w, m, affs, gout, partials); break;
+    default: hipLaunchKernelGGL((k_fwd_direct<T, 0, TRAIN>), g, blk, lds, s, P, ep, op, t, w, m, affs, gout, partials); break;
+  }
+  return hip_rc();
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward dispatch
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D_T, bool RA, bool RB, int CI>
+void launch_bwd_cfg(const KParams& P, const TParams& Q, const T* x, const T* nb, const float* g, const float* dl, T* dx,
+                    hipStream_t s) {
+  constexpr TileCfg c = kBwdCfg[CI];
+  const size_t lds = Lds<D_T, c.PLQ>::kBytes;
+  const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(c.TH * c.TW);
+  if (P.border == PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_bwd_tiled<T, D_T, c.TH, c.TW, c.PLQ, false, RA, RB>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, x, nb, g, dl, dx);
+  } else {
+    constexpr auto kern = k_bwd_tiled<T, D_T, c.TH, c.TW, c.PLQ, true, RA, RB>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, x, nb, g, dl, dx);
+  }
+}
+
+template <typename T, int D_T, bool RA, bool RB>
+bool try_bwd_tiled(const KParams& P, const T* x, const T* nb, const float* g, const float* dl, T* dx, hipStream_t s) {
+  const int ci = env_int("PEA_BWD_CFG", kBwdDefault);
+  if (ci < 0 || ci >= kNumBwdCfg) return false;
+  TParams Q;
+  if (!plan_tiles(P, kBwdCfg[ci], true, &Q)) return false;
+#define PEA_BWD_CASE(CI) \
+  case CI: launch_bwd_cfg<T, D_T, RA, RB, CI>(P, Q, x, nb, g, dl, dx, s); break;
+  switch (ci) { PEA_BWD_CASE(0) PEA_BWD_CASE(1) default: return false; }
+#undef PEA_BWD_CASE
+  return true;
+}
+
+template <typename T, int D_T>
+int launch_bwd_roles(const KParams& P, int roles, const T* x, const T* nbA, const T* nbB, const float* g, const float* dl,
+                     T* dx, hipStream_t s) {
+  if (D_T == 16 && env_int("PEA_FORCE_DIRECT", 0) == 0) {
+    bool done = false;
+    if (roles == 3) done = try_bwd_tiled<T, 16, true, true>(P, x, nbA, g, dl, dx, s);
+    else if (roles == 1) done = try_bwd_tiled<T, 16, true, false>(P, x, nbA, g, dl, dx, s);
+    else done = try_bwd_tiled<T, 16, false, true>(P, x, nbB, g, dl, dx, s);
+    if (done) return hip_rc();
+  }
+  const dim3 grid((unsigned)(P.tiles_per_xcd * kXcd)), blk(kBlock);
+  if (roles == 3) hipLaunchKernelGGL((k_bwd_direct<T, D_T, true, true>), grid, blk, 0, s, P, x, nbA, nbB, g, dl, dx);
+  else if (roles == 1) hipLaunchKernelGGL((k_bwd_direct<T, D_T, true, false>), grid, blk, 0, s, P, x, nbA, nbB, g, dl, dx);
+  else hipLaunchKernelGGL((k_bwd_direct<T, D_T, false, true>), grid, blk, 0, s, P, x, nbA, nbB, g, dl, dx);
+  return hip_rc();
+}
+
+template <typename T>
+int launch_bwd(const KParams& P, int roles, const void* x, const void* nbA, const void* nbB, const float* g, const float* dl,
+               void* dx, hipStream_t s) {
+  switch (P.D) {
+    case 16: return launch_bwd_roles<T, 16>(P, roles, (const T*)x, (const T*)nbA, (const T*)nbB, g, dl, (T*)dx, s);
+    case 32: return launch_bwd_roles<T, 32>(P, roles, (const T*)x, (const T*)nbA, (const T*)nbB, g, dl, (T*)dx, s);
+    case 64: return launch_bwd_roles<T, 64>(P, roles, (const T*)x, (const T*)nbA, (const T*)nbB, g, dl, (T*)dx, s);
+    case 4: return launch_bwd_roles<T, 4>(P, roles, (const T*)x, (const T*)nbA, (const T*)nbB, g, dl, (T*)dx, s);
+    case 8: return launch_bwd_roles<T, 8>(P, roles, (const T*)x, (const T*)nbA, (const T*)nbB, g, dl, (T*)dx, s);
+    default: return PEA_E_UNSUPPORTED;  // training needs D in {4, 8, 16, 32, 64}
+  }
 }
 
 }  // namespace
@@ -467,7 +331,7 @@ int pea_desc_validate(const PeaDesc* desc) { return validate(desc); }
 size_t pea_workspace_bytes(const PeaDesc* desc) {
   if (validate(desc)) return 0;
   const KParams P = make_params(desc);
-  return (size_t)P.tiles * P.K * sizeof(float);
+  return fwd_partials(P) * P.K * sizeof(float);
 }
 
 int pea_affinity_infer(const PeaDesc* desc, const void* e, const void* e_other, float* affs, void* stream) {
@@ -478,41 +342,59 @@ int pea_affinity_infer(const PeaDesc* desc, const void* e, const void* e_other, 
   if (misaligned(e, es) || misaligned(e_other, es) || misaligned(affs, 4)) return PEA_E_ALIGN;
   const KParams P = make_params(desc);
   hipStream_t s = (hipStream_t)stream;
+  int nparts = 0;
   return desc->dtype == PEA_F16
-             ? launch_fwd<__half, false>(P, e, e_other, nullptr, nullptr, nullptr, affs, nullptr, s)
-             : launch_fwd<float, false>(P, e, e_other, nullptr, nullptr, nullptr, affs, nullptr, s);
+             ? launch_fwd<__half, false>(P, e, e_other, nullptr, nullptr, nullptr, affs, nullptr, nullptr, s, &nparts)
+             : launch_fwd<float, false>(P, e, e_other, nullptr, nullptr, nullptr, affs, nullptr, nullptr, s, &nparts);
 }
 
 int pea_affinity_fwd(const PeaDesc* desc, const void* e, const void* e_other, const float* target,
-                     const float* weight, const uint8_t* mask, float* affs, float* loss_out, void* workspace,
-                     size_t workspace_bytes, void* stream) {
+                     const float* weight, const uint8_t* mask, float* affs, float* g_out, float* loss_out,
+                     void* workspace, size_t workspace_bytes, void* stream) {
   int rc = validate(desc);
   if (rc) return rc;
   if (!e || !target || !weight || !loss_out) return PEA_E_NULL;
   const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
-  if (misaligned(e, es) || misaligned(e_other, es) || misaligned(affs, 4) || misaligned(target, 4) ||
-      misaligned(weight, 4) || misaligned(loss_out, 4) || misaligned(workspace, 4))
+  if (misaligned(e, es) || misaligned(e_other, es) || misaligned(affs, 4) || misaligned(g_out, 4) ||
+      misaligned(target, 4) || misaligned(weight, 4) || misaligned(loss_out, 4) || misaligned(workspace, 4))
     return PEA_E_ALIGN;
   const KParams P = make_params(desc);
-  if (!workspace || workspace_bytes < (size_t)P.tiles * P.K * sizeof(float)) return PEA_E_WORKSPACE;
+  if (!workspace || workspace_bytes < fwd_partials(P) * P.K * sizeof(float)) return PEA_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   float* partials = (float*)workspace;
-  rc = desc->dtype == PEA_F16 ? launch_fwd<__half, true>(P, e, e_other, target, weight, mask, affs, partials, s)
-                              : launch_fwd<float, true>(P, e, e_other, target, weight, mask, affs, partials, s);
+  int nparts = 0;
+  rc = desc->dtype == PEA_F16
+           ? launch_fwd<__half, true>(P, e, e_other, target, weight, mask, affs, g_out, partials, s, &nparts)
+           : launch_fwd<float, true>(P, e, e_other, target, weight, mask, affs, g_out, partials, s, &nparts);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P, partials, P.tiles, loss_out);
+  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P, partials, nparts, loss_out);
   return hip_rc();
 }
 
-int pea_affinity_bwd(const PeaDesc* desc, const void* e, const void* e_other, const float* target,
-                     const float* weight, const uint8_t* mask, const float* dloss, void* de, void* de_other,
-                     void* stream) {
-  return bwd_common<false>(desc, e, e_other, target, weight, mask, nullptr, dloss, de, de_other, stream);
-}
-
-int pea_affinity_vjp(const PeaDesc* desc, const void* e, const void* e_other, const float* d_affs, void* de,
-                     void* de_other, void* stream) {
-  return bwd_common<true>(desc, e, e_other, nullptr, nullptr, nullptr, d_affs, nullptr, de, de_other, stream);
+int pea_affinity_bwd(const PeaDesc* desc, const void* e, const void* e_other, const float* g, const float* dloss,
+                     void* de, void* de_other, void* stream) {
+  int rc = validate(desc);
+  if (rc) return rc;
+  if (!e || !g || (!de && !de_other)) return PEA_E_NULL;
+  if (de_other && !e_other) return PEA_E_NULL;
+  const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
+  if (misaligned(e, es) || misaligned(e_other, es) || misaligned(de, es) || misaligned(de_other, es) ||
+      misaligned(g, 4) || misaligned(dloss, 4))
+    return PEA_E_ALIGN;
+  const KParams P = make_params(desc);
+  hipStream_t s = (hipStream_t)stream;
+  const bool h = desc->dtype == PEA_F16;
+  if (!e_other) {
+    return h ? launch_bwd<__half>(P, 3, e, e, e, g, dloss, de, s) : launch_bwd<float>(P, 3, e, e, e, g, dloss, de, s);
+  }
+  if (de) {
+    rc = h ? launch_bwd<__half>(P, 1, e, e_other, nullptr, g, dloss, de, s)
+           : launch_bwd<float>(P, 1, e, e_other, nullptr, g, dloss, de, s);
+    if (rc) return rc;
+  }
+  if (!de_other) return PEA_OK;
+  return h ? launch_bwd<__half>(P, 2, e_other, nullptr, e, g, dloss, de_other, s)
+           : launch_bwd<float>(P, 2, e_other, nullptr, e, g, dloss, de_other, s);
 }
 
 }  // extern "C"

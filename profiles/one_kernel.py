@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Run one entry point (fwd | bwd | inf) a few times at the CVPPP bench shape, for rocprofv3 --pmc passes.
+Usage: python profiles/one_kernel.py <fwd|bwd|inf> [iters] [B]   (tile config via PEA_* env vars)"""
+import ctypes
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+
+pkg = ge.load_package()
+synth = importlib.import_module(ge.PKG_NAME + ".utils.synth")
+which = sys.argv[1]
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+D, H, W = 16, 544, 544
+dev = torch.device("cuda:0")
+offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+K = len(offsets)
+e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 555)
+E, T, Wt, M = (torch.from_numpy(x).to(dev) for x in (e, t, w, m))
+op, L = pkg.affinity_op, pkg._lib.lib()
+desc = op.make_desc(op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX), E)
+affs = torch.empty(B, K, H, W, device=dev)
+G = torch.empty(B, K, H, W, device=dev)
+lossv = torch.empty(1 + K, device=dev)
+wsb = L.pea_workspace_bytes(ctypes.byref(desc))
+work = torch.empty(max(wsb, 4) // 4, device=dev)
+dE = torch.empty_like(E)
+one = torch.ones((), device=dev)
+P = lambda x: ctypes.c_void_p(x.data_ptr())
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+fns = {
+    "fwd": lambda: L.pea_affinity_fwd(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), P(G), P(lossv), P(work), wsb, st),
+    "bwd": lambda: L.pea_affinity_bwd(ctypes.byref(desc), P(E), None, P(G), P(one), P(dE), None, st),
+    "inf": lambda: L.pea_affinity_infer(ctypes.byref(desc), P(E), None, P(affs), st),
+}
+if which == "bwd":
+    fns["fwd"]()
+for _ in range(iters):
+    assert fns[which]() == 0
+torch.cuda.synchronize()

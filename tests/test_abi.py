@@ -23,7 +23,7 @@ def lib(pkg):
 
 def test_header_declares_the_expected_entry_points():
     assert declared_symbols() == sorted(["pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes",
-                                         "pea_affinity_infer", "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_vjp"])
+                                         "pea_affinity_infer", "pea_affinity_fwd", "pea_affinity_bwd"])
 
 
 def test_library_exports_every_declared_symbol(pkg, lib):
@@ -57,8 +57,8 @@ def _desc(pkg, **kw):
 def test_validate_and_workspace(pkg, lib):
     d = _desc(pkg)
     assert lib.pea_desc_validate(ctypes.byref(d)) == 0
-    # one partial per 256-pixel workgroup per offset
-    assert lib.pea_workspace_bytes(ctypes.byref(d)) == 2 * ((32 * 48 + 255) // 256) * 2 * 4
+    # at least one f32 partial per workgroup per offset, whichever kernel shape is chosen
+    assert lib.pea_workspace_bytes(ctypes.byref(d)) >= 2 * ((32 * 48 + 255) // 256) * 2 * 4
     assert lib.pea_strerror(0) == b"ok"
     for bad in (dict(abi=7), dict(K=0), dict(K=33), dict(B=0), dict(D=0), dict(border=5), dict(dtype=3), dict(norm=9),
                 dict(eps=0.0), dict(ndim=4), dict(target_bstride=-1)):
@@ -76,10 +76,11 @@ def test_validate_and_workspace(pkg, lib):
 def test_null_and_alignment_errors_need_no_gpu(pkg, lib):
     d = _desc(pkg)
     assert lib.pea_affinity_infer(ctypes.byref(d), None, None, None, None) == -1
-    assert lib.pea_affinity_fwd(ctypes.byref(d), None, None, None, None, None, None, None, None, 0, None) == -1
-    assert lib.pea_affinity_bwd(ctypes.byref(d), None, None, None, None, None, None, None, None, None) == -1
-    assert lib.pea_affinity_vjp(ctypes.byref(d), None, None, None, None, None, None) == -1
+    assert lib.pea_affinity_fwd(ctypes.byref(d), None, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert lib.pea_affinity_bwd(ctypes.byref(d), None, None, None, None, None, None, None) == -1
     assert lib.pea_affinity_infer(ctypes.byref(d), ctypes.c_void_p(0x1002), None, ctypes.c_void_p(0x2000), None) == -5
     # workspace too small is reported before anything is launched
     p = ctypes.c_void_p(0x1000)
-    assert lib.pea_affinity_fwd(ctypes.byref(d), p, None, p, p, None, p, p, p, 8, None) == -4
+    assert lib.pea_affinity_fwd(ctypes.byref(d), p, None, p, p, None, p, p, p, p, 8, None) == -4
+    # a gradient output for the second operand needs that operand
+    assert lib.pea_affinity_bwd(ctypes.byref(d), p, None, p, None, p, p, None) == -1

@@ -203,7 +203,7 @@ def test_packed_down_tensor_slices_need_no_copy(pkg, dev, orc, synth):
 
 def test_foreign_criterion_uses_vjp(pkg, dev, orc, synth):
     """criterion is a parameter of the reference API: a non-fused criterion runs on a differentiable
-    affinity map (pea_affinity_vjp) and must match torch autograd of the reference op sequence"""
+    affinity map (pea_affinity_bwd with an upstream d_affs) and must match torch autograd of the reference op sequence"""
     offsets = pkg.multi_offset([1, 3, 9], 8)
     B, D, H, W = 2, 16, 30, 44
     e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 11)
