@@ -11,7 +11,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libpea_hip.so")
+SO_PATH = os.environ.get("PEA_HIP_LIB") or os.path.join(CSRC, "libpea_hip.so")  # PEA_HIP_LIB: debugging override
 HEADER = os.path.join(HERE, "..", "include", "pea.h")
 
 PEA_ABI_VERSION = 1

@@ -103,6 +103,7 @@ bool misaligned(const void* p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0;
 // ------------------------------------------------------------------------------------------------
 struct TileCfg { int TH, TW, PLQ; };  // workgroup = TH*TW lanes (one per pixel); PLQ = LDS plane stride in pixels
 // compiled-in shapes; index chosen by PEA_FWD_CFG / PEA_BWD_CFG (defaults = the measured best, CVPPP stencil)
+constexpr TileCfg kFwdV_decl = {32, 32, 1696};
 constexpr TileCfg kFwdCfg[] = {{16, 32, 1040}, {32, 32, 1696}, {8, 64, 1248}};
 constexpr TileCfg kBwdCfg[] = {{32, 32, 2504}, {16, 32, 1712}};
 constexpr int kNumFwdCfg = sizeof(kFwdCfg) / sizeof(kFwdCfg[0]), kNumBwdCfg = sizeof(kBwdCfg) / sizeof(kBwdCfg[0]);
@@ -111,8 +112,8 @@ constexpr int kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup ma
 
 // Choose the "near" offsets (served from LDS): the largest in-plane radius whose halo'd region still fits the
 // LDS planes of this tile shape.  both_sides: the backward needs p - o as well as p + o.
-bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, TParams* Q) {
-  if ((long long)P.Y * P.X > (1LL << 29)) return false;                      // 32-bit byte offsets in a plane
+bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, bool can_pair, TParams* Q) {
+  if ((long long)P.Y * P.X >= (1LL << 29)) return false;                     // plane byte offsets stay below 2^31 (kOOB)
   if ((long long)std::max(P.D, P.K) * P.S * 4 > 0xFFFFFFFFLL) return false;  // buffer soffset is 32-bit
   const int NT = c.TH * c.TW;
   int radii[PEA_MAX_K], nr = 0;
@@ -135,6 +136,15 @@ bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, TParams* Q) {
       q.hx1 = std::max(q.hx1, both_sides ? abs(ox) : ox);
     }
     q.RH = c.TH + q.hy0 + q.hy1;
+    // paired staging (dwordx2) wants an even left halo and an even region width: take it if it still fits
+    if (can_pair && P.X % 2 == 0 && env_int("PEA_PAIR", 0) != 0) {  // experimental, off by default
+      const int h0 = (q.hx0 + 1) & ~1, rw = (c.TW + h0 + q.hx1 + 1) & ~1;
+      if (q.RH * rw <= c.PLQ && P.X >= h0) {
+        q.pair = 1;
+        q.hx0 = h0;
+        q.hx1 = rw - c.TW - h0;
+      }
+    }
     q.RW = c.TW + q.hx0 + q.hx1;
     q.R = q.RH * q.RW;
     if (q.R > c.PLQ) continue;
@@ -144,6 +154,11 @@ bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, TParams* Q) {
     q.dc = NT % q.RW;
     q.inv_rw = 1.0f / (float)q.RW;
     q.inv_eps = 1.0f / P.eps;
+    q.RWq = q.RW / 2;
+    q.R2 = q.RH * q.RWq;
+    q.dr2 = q.RWq ? NT / q.RWq : 0;
+    q.dc2 = q.RWq ? NT % q.RWq : 0;
+    q.inv_rwq = q.RWq ? 1.0f / (float)q.RWq : 0.f;
     q.tiles_y = (P.Y + c.TH - 1) / c.TH;
     q.tiles_x = (P.X + c.TW - 1) / c.TW;
     q.tiles_per_plane = q.tiles_y * q.tiles_x;
@@ -177,8 +192,10 @@ size_t fwd_partials(const KParams& P) {
   size_t n = (size_t)P.tiles;
   for (const TileCfg& c : kFwdCfg) {
     TParams q;
-    if (plan_tiles(P, c, false, &q)) n = std::max(n, (size_t)q.ntiles);
+    if (plan_tiles(P, c, false, false, &q)) n = std::max(n, (size_t)q.ntiles);
   }
+  TParams qv;
+  if (plan_tiles(P, kFwdV_decl, false, false, &qv)) n = std::max(n, (size_t)qv.ntiles);
   return n;
 }
 
@@ -203,6 +220,44 @@ void launch_fwd_cfg(const KParams& P, const TParams& Q, const T* e, const T* eo,
   }
 }
 
+// forward with the LDS-transposed, dwordx4 epilogue (k_fwd_tiled_v): the default when its preconditions hold
+constexpr TileCfg kFwdV = kFwdV_decl;
+
+template <typename T, int D_T, bool TRAIN, bool SELF>
+void launch_fwd_v(const KParams& P, const TParams& Q, size_t lds, const T* e, const T* eo, const float* t, const float* w,
+                  const uint8_t* m, float* affs, float* gout, float* partials, hipStream_t s) {
+  constexpr TileCfg c = kFwdV;
+  const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(c.TH * c.TW);
+  if (P.border == PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_fwd_tiled_v<T, D_T, c.TH, c.TW, c.PLQ, false, TRAIN, SELF>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials);
+  } else {
+    constexpr auto kern = k_fwd_tiled_v<T, D_T, c.TH, c.TW, c.PLQ, true, TRAIN, SELF>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials);
+  }
+}
+
+template <typename T, int D_T, bool TRAIN>
+bool try_fwd_v(const KParams& P, const T* e, const T* eo, const float* t, const float* w, const uint8_t* m, float* affs,
+               float* gout, float* partials, hipStream_t s, int* nparts) {
+  if (env_int("PEA_FWD_V", 1) == 0) return false;
+  if (P.K > kKV || P.X % 4) return false;
+  if (misaligned(t, 16) || misaligned(w, 16) || misaligned(affs, 16) || misaligned(gout, 16) || misaligned(m, 4)) return false;
+  if ((P.tbs | P.wbs | P.mbs | (long long)P.S) & 3) return false;
+  constexpr TileCfg c = kFwdV;
+  const size_t tp = (size_t)c.TH * c.TW;
+  const size_t lds = Lds<D_T, c.PLQ>::kBytes + (size_t)P.K * tp * 4 + (size_t)P.K * (tp / 256) * 4;
+  if (lds > (size_t)kLdsMax) return false;
+  TParams Q;
+  if (!plan_tiles(P, c, false, false, &Q)) return false;
+  if (eo == e) launch_fwd_v<T, D_T, TRAIN, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
+  else launch_fwd_v<T, D_T, TRAIN, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
+  *nparts = Q.ntiles;
+  return true;
+}
+
 // returns true if a tiled kernel was launched (nparts = number of partial rows written)
 template <typename T, int D_T, bool TRAIN>
 bool try_fwd_tiled(const KParams& P, const T* e, const T* eo, const float* t, const float* w, const uint8_t* m, float* affs,
@@ -210,7 +265,7 @@ bool try_fwd_tiled(const KParams& P, const T* e, const T* eo, const float* t, co
   const int ci = env_int("PEA_FWD_CFG", kFwdDefault);
   if (ci < 0 || ci >= kNumFwdCfg) return false;
   TParams Q;
-  if (!plan_tiles(P, kFwdCfg[ci], false, &Q)) return false;
+  if (!plan_tiles(P, kFwdCfg[ci], false, !misaligned(eo, 8), &Q)) return false;
   const bool self = (eo == e);
 #define PEA_FWD_CASE(CI)                                                                             \
   case CI:                                                                                           \
@@ -230,7 +285,8 @@ int launch_fwd(const KParams& P, const void* e, const void* eo, const float* t, 
   const T* op = eo ? (const T*)eo : ep;
   if (env_int("PEA_FORCE_DIRECT", 0) == 0) {
     bool done = false;
-    if (P.D == 16) done = try_fwd_tiled<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
+    if (P.D == 16 && TRAIN) done = try_fwd_v<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
+    if (!done && P.D == 16) done = try_fwd_tiled<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
     if (done) return hip_rc();
   }
   const size_t lds = TRAIN ? (size_t)P.K * kBlock * sizeof(float) : 0;
@@ -270,7 +326,7 @@ bool try_bwd_tiled(const KParams& P, const T* x, const T* nb, const float* g, co
   const int ci = env_int("PEA_BWD_CFG", kBwdDefault);
   if (ci < 0 || ci >= kNumBwdCfg) return false;
   TParams Q;
-  if (!plan_tiles(P, kBwdCfg[ci], true, &Q)) return false;
+  if (!plan_tiles(P, kBwdCfg[ci], true, !misaligned(nb, 8), &Q)) return false;
 #define PEA_BWD_CASE(CI) \
   case CI: launch_bwd_cfg<T, D_T, RA, RB, CI>(P, Q, x, nb, g, dl, dx, s); break;
   switch (ci) { PEA_BWD_CASE(0) PEA_BWD_CASE(1) default: return false; }

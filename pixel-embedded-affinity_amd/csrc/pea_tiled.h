@@ -48,6 +48,9 @@ struct TParams {
   int RH, RW, R;           // staged region (rows, columns, pixels)
   int dr, dc;              // NT / RW, NT % RW: (row, col) advance of one staging step
   float inv_rw;            // 1 / RW
+  int pair;                // 1: stage two x-adjacent pixels per lane (X, hx0, RW even; 8-byte aligned tensors)
+  int RWq, R2, dr2, dc2;   // the same staging constants in units of pixel pairs
+  float inv_rwq;
   float inv_eps;           // 1 / eps
   int tiles_y, tiles_x, tiles_per_plane;
   int ntiles, tiles_per_xcd;
@@ -61,12 +64,13 @@ struct TParams {
 __device__ __forceinline__ float rnorm(float ss, float inv_eps) { return fminf(__builtin_amdgcn_rsqf(ss), inv_eps); }
 
 // Buffer access to one tensor of one batch item.  vo = per-lane byte offset inside a plane (kOOB for lanes
-// that must not touch memory: out of range => load returns 0 / store dropped), so = uniform byte offset of
+// that must not touch memory: out of range => load returns 0 / store dropped; every legal offset is < 2^31
+// because a plane is, see plan_tiles), so = uniform byte offset of
 // the plane (channel / offset index and z).  NTL: non-temporal (streamed-once operands).
 constexpr int kAuxNT = 2;
-constexpr unsigned kOOB = 0xFFFFFFFFu;
+constexpr unsigned kOOB = 0x80000000u;  // == num_records: never near 2^32, so a 16-byte access cannot wrap past the check
 __device__ __forceinline__ rsrc_t mkbuf(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)kOOB, 0x00020000);
 }
 template <bool NTL = false>
 __device__ __forceinline__ float bl32(rsrc_t r, unsigned vo, unsigned so) {
@@ -184,6 +188,60 @@ __device__ __forceinline__ void stage_region(const KParams& P, const TParams& Q,
   }
 }
 
+// Same, two x-adjacent region pixels per lane and step (dwordx2 loads: half the vector-memory instructions,
+// which is what these kernels are bound by).  Host guarantees: X even, hx0 even, RW even, 8-byte aligned base.
+template <typename T, int D_T, int PLQ, int NT, bool CROP>
+__device__ __forceinline__ void stage_region_pair(const KParams& P, const TParams& Q, rsrc_t eb, unsigned zo, unsigned cs,
+                                                  int y0, int x0, char* __restrict__ lds) {
+  typedef Lds<D_T, PLQ> L;
+  int idx = threadIdx.x;
+  int r = (int)(((float)idx + 0.5f) * Q.inv_rwq);
+  int c = idx - r * Q.RWq;
+#pragma unroll 2
+  for (; idx < Q.R2; idx += NT) {
+    bool oky, okx;
+    const int gy = wrap1<CROP>(y0 - Q.hy0 + r, P.Y, oky);
+    const int gx = wrap1<CROP>(x0 - Q.hx0 + 2 * c, P.X, okx);  // even: the pair never straddles the border
+    const unsigned vo = (oky && okx) ? (unsigned)(gy * P.X + gx) * (unsigned)sizeof(T) : kOOB;
+    float v0[D_T], v1[D_T];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < D_T; ++ch) {
+      if (sizeof(T) == 4) {
+        const auto t = __builtin_amdgcn_raw_buffer_load_b64(eb, vo, zo + ch * cs, 0);
+        v0[ch] = __builtin_bit_cast(float, t[0]);
+        v1[ch] = __builtin_bit_cast(float, t[1]);
+      } else {
+        const unsigned t = __builtin_amdgcn_raw_buffer_load_b32(eb, vo, zo + ch * cs, 0);
+        v0[ch] = __half2float(__builtin_bit_cast(__half, (unsigned short)(t & 0xffffu)));
+        v1[ch] = __half2float(__builtin_bit_cast(__half, (unsigned short)(t >> 16)));
+      }
+      s0 = fmaf(v0[ch], v0[ch], s0);
+      s1 = fmaf(v1[ch], v1[ch], s1);
+    }
+    const float i0 = rnorm(s0, Q.inv_eps), i1 = rnorm(s1, Q.inv_eps);
+    char* dst = lds + (r * Q.RW + 2 * c) * 16;
+#pragma unroll
+    for (int q = 0; q < L::S; ++q) {
+      f4 a, b;
+      a.x = v0[4 * q] * i0; a.y = v0[4 * q + 1] * i0; a.z = v0[4 * q + 2] * i0; a.w = v0[4 * q + 3] * i0;
+      b.x = v1[4 * q] * i1; b.y = v1[4 * q + 1] * i1; b.z = v1[4 * q + 2] * i1; b.w = v1[4 * q + 3] * i1;
+      *(f4*)(dst + q * L::kPlaneB) = a;
+      *(f4*)(dst + q * L::kPlaneB + 16) = b;
+    }
+    r += Q.dr2;
+    c += Q.dc2;
+    if (c >= Q.RWq) { c -= Q.RWq; r += 1; }
+  }
+}
+
+template <typename T, int D_T, int PLQ, int NT, bool CROP>
+__device__ __forceinline__ void stage(const KParams& P, const TParams& Q, rsrc_t eb, unsigned zo, unsigned cs, int y0, int x0,
+                                      char* __restrict__ lds) {
+  if (Q.pair) stage_region_pair<T, D_T, PLQ, NT, CROP>(P, Q, eb, zo, cs, y0, x0, lds);
+  else stage_region<T, D_T, PLQ, NT, CROP>(P, Q, eb, zo, cs, y0, x0, lds);
+}
+
 // lane -> its pixel of the tile (one pixel per lane)
 template <int TW>
 __device__ __forceinline__ void lane_pixel(int& ly, int& lx) {
@@ -244,7 +302,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled(const KParams P, const 
                                                          float* __restrict__ gout, float* __restrict__ partials) {
   typedef Lds<D_T, PLQ> L;
   constexpr int NT = TH * TW, NW = NT / 64;
-  constexpr int KN = 4;  // near offsets per chunk
+  constexpr int KN = 8;  // near offsets per chunk (chunk 0 is requested before the staging loads)
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   float* s_part = (float*)(lds + L::kBytes);  // [NW][K]
@@ -283,9 +341,12 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled(const KParams P, const 
   const unsigned pe = live ? po * (unsigned)sizeof(T) : kOOB;
   const int pr = (ly + Q.hy0) * Q.RW + lx + Q.hx0;
 
-  // (1) streaming operands of the first near chunk: in flight during the whole staging phase
+  // (1) ALL streaming operands of the first near chunk (KN offsets) and of the first two far offsets: in flight
+  //     during the whole staging phase.  Exposed memory round trips per tile: one (the staging loads).
   Twm<KN> sa;
+  Twm<2> sf;
   if (TRAIN && Q.n_near > 0) fwd_load_twm<KN>(sa, U, Q.near, 0, Q.n_near, pb, pm);
+  if (TRAIN && Q.n_far > 0) fwd_load_twm<2>(sf, U, Q.far, 0, Q.n_far, pb, pm);
   float own[D_T];
   if (!SELF) {
 #pragma unroll
@@ -293,13 +354,12 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled(const KParams P, const 
   }
 
   // (2) stage the region
-  stage_region<T, D_T, PLQ, NT, CROP>(P, Q, oB, ezo, ecs, y0, x0, lds);
+  stage<T, D_T, PLQ, NT, CROP>(P, Q, oB, ezo, ecs, y0, x0, lds);
 
-  // (3) first far offset: neighbour vector + its streaming operands, in flight across the barrier
-  float fv[D_T];
-  Twm<1> sf;
-  bool fok = false;
-#define PEA_FWD_LOAD_FAR(k)                                                                        \
+  // (3) the first two far neighbour vectors: in flight across the barrier and the near-offset work
+  float fvA[D_T], fvB[D_T];
+  bool fokA = false, fokB = false;
+#define PEA_FWD_LOAD_FAR(fv, fok, k)                                                               \
   {                                                                                                \
     const OffEnt fe_ = Q.far[k];                                                                   \
     bool okz_, oky_, okx_;                                                                         \
@@ -310,9 +370,19 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled(const KParams P, const 
     const unsigned zo_ = (unsigned)(CROP ? min(max(zz_, 0), P.Z - 1) : zz_) * YX * (unsigned)sizeof(T); \
     const unsigned vo_ = fok ? (unsigned)(yy_ * P.X + xx_) * (unsigned)sizeof(T) : kOOB;           \
     _Pragma("unroll") for (int c = 0; c < D_T; ++c) fv[c] = bl_emb<T>(oB, vo_, zo_ + c * ecs);     \
-    if (TRAIN) fwd_load_twm<1>(sf, U, Q.far, k, Q.n_far, pb, pm);                                  \
   }
-  if (Q.n_far > 0) PEA_FWD_LOAD_FAR(0)
+#define PEA_FWD_FAR(fv, fok, k, u)                                                                 \
+  {                                                                                                \
+    float dot_ = 0.f, sq_ = 0.f;                                                                   \
+    _Pragma("unroll") for (int c = 0; c < D_T; ++c) {                                              \
+      dot_ = fmaf(own[c], fv[c], dot_);                                                            \
+      sq_ = fmaf(fv[c], fv[c], sq_);                                                               \
+    }                                                                                              \
+    const float a_ = fok ? dot_ * rnorm(sq_, Q.inv_eps) : 0.f;                                     \
+    fwd_finish<TRAIN>(U, P.K, s_part, Q.far[k], a_, fok, sf.t[u], sf.w[u], sf.m[u], pb);           \
+  }
+  if (Q.n_far > 0) PEA_FWD_LOAD_FAR(fvA, fokA, 0)
+  if (Q.n_far > 1) PEA_FWD_LOAD_FAR(fvB, fokB, 1)
 
   if (!SELF) {
     float ss = 0.f;
@@ -348,19 +418,18 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled(const KParams P, const 
     }
   }
 
-  // ---- far offsets: neighbour vector straight from global (L2) ---------------------------------------
-  for (int k = 0; k < Q.n_far; ++k) {
-    if (k > 0) PEA_FWD_LOAD_FAR(k)
-    float dot = 0.f, sq = 0.f;
-#pragma unroll
-    for (int c = 0; c < D_T; ++c) {
-      dot = fmaf(own[c], fv[c], dot);
-      sq = fmaf(fv[c], fv[c], sq);
+  // ---- far offsets: neighbour vectors straight from global (L2), two at a time ------------------------
+  for (int k = 0; k < Q.n_far; k += 2) {
+    if (k > 0) {
+      if (TRAIN) fwd_load_twm<2>(sf, U, Q.far, k, Q.n_far, pb, pm);
+      PEA_FWD_LOAD_FAR(fvA, fokA, k)
+      if (k + 1 < Q.n_far) PEA_FWD_LOAD_FAR(fvB, fokB, k + 1)
     }
-    const float a = fok ? dot * rnorm(sq, Q.inv_eps) : 0.f;
-    fwd_finish<TRAIN>(U, P.K, s_part, Q.far[k], a, fok, sf.t[0], sf.w[0], sf.m[0], pb);
+    PEA_FWD_FAR(fvA, fokA, k, 0)
+    if (k + 1 < Q.n_far) PEA_FWD_FAR(fvB, fokB, k + 1, 1)
   }
 #undef PEA_FWD_LOAD_FAR
+#undef PEA_FWD_FAR
 
   if (TRAIN) {
     __syncthreads();
@@ -368,6 +437,220 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled(const KParams P, const 
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += s_part[w * P.K + threadIdx.x];
+      partials[(size_t)threadIdx.x * Q.ntiles + tile] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, tiled, with the epilogue TRANSPOSED THROUGH LDS (the default forward).
+//
+// These kernels are bound by the vector-memory pipe: one wave-level load/store costs it ~16-20 cycles whatever
+// its width (measured: ~1.2 us of kernel time per VMEM instruction per pixel at this size; a plain 4 B/lane
+// streaming kernel with the same access pattern runs at exactly that rate, profiles/microbench).  Reading
+// target / weight / mask and writing affs / g one pixel per lane costs 5 VMEM instructions per (pixel, offset).
+// Here the dot products are parked in LDS as [offset][tile pixel] instead, and a second phase walks that array
+// four x-adjacent pixels per lane: every streaming access becomes a 16-byte-per-lane dwordx4 (one dword for the
+// four u8 masks), 1.25 VMEM instructions per (pixel, offset).  The operands of that phase are requested at the
+// very top of the kernel (their addresses do not depend on anything computed), so they are in flight during
+// staging and the dot products.
+// Needs: K <= kKV, X % 4 == 0, 16-byte aligned target / weight / affs / g planes, 4-byte aligned mask planes.
+// ------------------------------------------------------------------------------------------------
+constexpr int kKV = 12;
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+// 16-byte buffer store.  HAZARD (gfx950, ROCm 7.2): a VALU write to one of the store's data VGPRs in the very
+// next instruction corrupts that dword.  LLVM's hazard recognizer skips the ">64-bit VMEM store data" wait state
+// when soffset is an SGPR (as it always is here); seen as affs[..].y == the mask byte converted one instruction
+// later.  An explicit s_nop after the store restores the wait states.
+template <bool NTL>
+__device__ __forceinline__ void bs128(rsrc_t r, f4 v, unsigned vo, unsigned so) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, vo, so, NTL ? kAuxNT : 0);
+  asm volatile("s_nop 1" ::: "memory");
+}
+
+template <typename T, int D_T, int TH, int TW, int PLQ, bool CROP, bool TRAIN, bool SELF>
+__global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled_v(const KParams P, const TParams Q, const T* __restrict__ e,
+                                                           const T* __restrict__ eo, const float* __restrict__ target,
+                                                           const float* __restrict__ weight,
+                                                           const uint8_t* __restrict__ mask, float* __restrict__ affs,
+                                                           float* __restrict__ gout, float* __restrict__ partials) {
+  typedef Lds<D_T, PLQ> L;
+  constexpr int NT = TH * TW, TP = NT, QP = TP / 4, NSL = QP / 64;
+  constexpr int ITEMS = (kKV * QP + NT - 1) / NT;
+  static_assert(QP % 64 == 0 && TW % 4 == 0, "a wave must cover quads of one offset plane");
+  extern __shared__ f4 lds4[];
+  char* lds = (char*)lds4;
+  float* sA = (float*)(lds + L::kBytes);       // [K][TP] dot products
+  float* s_part = sA + (size_t)P.K * TP;       // [K][NSL]
+  const int tile = tile_id(Q);
+  if (tile >= Q.ntiles) return;
+  const int plane = tile / Q.tiles_per_plane;
+  const int rem = tile - plane * Q.tiles_per_plane;
+  const int ty = rem / Q.tiles_x;
+  const int y0 = ty * TH, x0 = (rem - ty * Q.tiles_x) * TW;
+  const int b = plane / P.Z, z = plane - b * P.Z;
+  const size_t S = (size_t)P.S;
+  const unsigned YX = (unsigned)(P.Y * P.X);
+  const rsrc_t eB = mkbuf(e + (size_t)b * D_T * S), oB = mkbuf(eo + (size_t)b * D_T * S);
+  const rsrc_t aB = mkbuf(affs ? affs + (size_t)b * P.K * S : nullptr), gB = mkbuf(gout ? gout + (size_t)b * P.K * S : nullptr);
+  const rsrc_t tB = mkbuf(target + (size_t)b * P.tbs), wB = mkbuf(weight + (size_t)b * P.wbs);
+  const rsrc_t mB = mkbuf(mask ? mask + (size_t)b * P.mbs : nullptr);
+  const unsigned kcs = (unsigned)P.S * 4u, kzo = (unsigned)z * YX * 4u;
+  const bool has_a = affs != nullptr, has_g = gout != nullptr, has_m = mask != nullptr;
+  const bool relu = P.flags & PEA_FLAG_RELU_AFFS;
+  const unsigned ecs = (unsigned)P.S * (unsigned)sizeof(T);
+  const unsigned ezo = (unsigned)z * YX * (unsigned)sizeof(T);
+
+  // ---- (0) the epilogue's operands: item = (offset slot, quad of 4 x-adjacent tile pixels), wave-uniform slot
+  OffEnt ien[ITEMS];
+  bool ion[ITEMS];
+  unsigned ivo[ITEMS];   // byte offset of the quad in an f32 plane, kOOB if the quad is outside / slot unused
+  int iqd[ITEMS], igy[ITEMS], igx[ITEMS], ioz[ITEMS];
+  f4 t4[ITEMS], w4[ITEMS];
+  unsigned m4[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int tt = it * NT + (int)threadIdx.x;
+    const int s = __builtin_amdgcn_readfirstlane(tt / QP);
+    ion[it] = s < P.K;
+    const int sc = min(s, P.K - 1);
+    ien[it] = sc < Q.n_near ? Q.near[sc] : Q.far[max(sc - Q.n_near, 0)];
+    ioz[it] = sc < Q.n_near ? 0 : ien[it].d;  // far entries keep oz in d
+    const int qd = tt - (tt / QP) * QP;
+    iqd[it] = qd;
+    const int l4 = qd * 4;
+    igy[it] = y0 + l4 / TW;
+    igx[it] = x0 + l4 % TW;
+    const bool lv = ion[it] && igy[it] < P.Y && igx[it] < P.X;  // X % 4 == 0: a quad is inside or outside as a whole
+    ivo[it] = lv ? (unsigned)(igy[it] * P.X + igx[it]) * 4u : kOOB;
+    if (TRAIN) {
+      const unsigned so = kzo + (unsigned)ien[it].i * kcs;
+      t4[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(tB, ivo[it], so, kAuxNT));
+      w4[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wB, ivo[it], so, kAuxNT));
+      m4[it] = has_m ? __builtin_amdgcn_raw_buffer_load_b32(mB, lv ? ivo[it] >> 2 : kOOB, (kzo >> 2) + (unsigned)ien[it].i * (unsigned)P.S, kAuxNT)
+                     : 0x01010101u;
+    }
+  }
+
+  int ly, lx;
+  lane_pixel<TW>(ly, lx);
+  const int py = y0 + ly, px = x0 + lx;
+  const bool live = py < P.Y && px < P.X;
+  const unsigned po = (unsigned)(py * P.X + px);
+  const unsigned pe = live ? po * (unsigned)sizeof(T) : kOOB;
+  const int pr = (ly + Q.hy0) * Q.RW + lx + Q.hx0;
+  float* myA = sA + ly * TW + lx;
+
+  float own[D_T];
+  if (!SELF) {
+#pragma unroll
+    for (int c = 0; c < D_T; ++c) own[c] = bl_emb<T>(eB, pe, ezo + c * ecs);
+  }
+
+  // ---- (1) stage the region; (2) first two far vectors in flight across the barrier
+  stage<T, D_T, PLQ, NT, CROP>(P, Q, oB, ezo, ecs, y0, x0, lds);
+  float fvA[D_T], fvB[D_T];
+  bool fokA = false, fokB = false;
+#define PEA_FWDV_LOAD_FAR(fv, fok, k)                                                              \
+  {                                                                                                \
+    const OffEnt fe_ = Q.far[k];                                                                   \
+    bool okz_, oky_, okx_;                                                                         \
+    const int zz_ = wrap1<CROP>(z + fe_.d, P.Z, okz_);                                             \
+    const int yy_ = wrap1<CROP>(py + ent_oy(fe_), P.Y, oky_);                                      \
+    const int xx_ = wrap1<CROP>(px + ent_ox(fe_), P.X, okx_);                                      \
+    fok = live && okz_ && oky_ && okx_;                                                            \
+    const unsigned zo_ = (unsigned)(CROP ? min(max(zz_, 0), P.Z - 1) : zz_) * YX * (unsigned)sizeof(T); \
+    const unsigned vo_ = fok ? (unsigned)(yy_ * P.X + xx_) * (unsigned)sizeof(T) : kOOB;           \
+    _Pragma("unroll") for (int c = 0; c < D_T; ++c) fv[c] = bl_emb<T>(oB, vo_, zo_ + c * ecs);     \
+  }
+#define PEA_FWDV_FAR(fv, fok, k)                                                                   \
+  {                                                                                                \
+    float dot_ = 0.f, sq_ = 0.f;                                                                   \
+    _Pragma("unroll") for (int c = 0; c < D_T; ++c) {                                              \
+      dot_ = fmaf(own[c], fv[c], dot_);                                                            \
+      sq_ = fmaf(fv[c], fv[c], sq_);                                                               \
+    }                                                                                              \
+    myA[Q.far[k].i * TP] = fok ? dot_ * rnorm(sq_, Q.inv_eps) : 0.f;                               \
+  }
+  if (Q.n_far > 0) PEA_FWDV_LOAD_FAR(fvA, fokA, 0)
+  if (Q.n_far > 1) PEA_FWDV_LOAD_FAR(fvB, fokB, 1)
+  if (!SELF) {
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < D_T; ++c) ss = fmaf(own[c], own[c], ss);
+    const float inv = rnorm(ss, Q.inv_eps);
+#pragma unroll
+    for (int c = 0; c < D_T; ++c) own[c] *= inv;
+  }
+  __syncthreads();
+  if (SELF) lds_pixel<D_T, PLQ>(lds, pr, own);
+
+  // ---- (3) dot products -> sA[offset][tile pixel]
+  for (int k = 0; k < Q.n_near; ++k) {
+    const OffEnt en = Q.near[k];
+    float v[D_T];
+    lds_pixel<D_T, PLQ>(lds, pr + en.d, v);
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < D_T; ++c) a = fmaf(own[c], v[c], a);
+    if (CROP) {
+      const bool inside = (unsigned)(py + ent_oy(en)) < (unsigned)P.Y && (unsigned)(px + ent_ox(en)) < (unsigned)P.X;
+      a = inside ? a : 0.f;
+    }
+    myA[en.i * TP] = a;
+  }
+  for (int k = 0; k < Q.n_far; k += 2) {
+    if (k > 0) {
+      PEA_FWDV_LOAD_FAR(fvA, fokA, k)
+      if (k + 1 < Q.n_far) PEA_FWDV_LOAD_FAR(fvB, fokB, k + 1)
+    }
+    PEA_FWDV_FAR(fvA, fokA, k)
+    if (k + 1 < Q.n_far) PEA_FWDV_FAR(fvB, fokB, k + 1)
+  }
+#undef PEA_FWDV_LOAD_FAR
+#undef PEA_FWDV_FAR
+  __syncthreads();
+
+  // ---- (4) epilogue: 4 x-adjacent pixels of one offset per lane, dwordx4 everywhere
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    if (!ion[it]) continue;  // wave-uniform
+    const OffEnt en = ien[it];
+    const f4 a4 = *(const f4*)(sA + en.i * TP + iqd[it] * 4);
+    const unsigned so = kzo + (unsigned)en.i * kcs;
+    if (has_a) {
+      f4 o = a4;
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      bs128<true>(aB, o, ivo[it], so);
+    }
+    if (TRAIN) {
+      float acc = 0.f;
+      f4 g4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float m = (float)((m4[it] >> (8 * j)) & 0xffu);
+        const float r = a4[j] * m - t4[it][j] * m;
+        float wr = w4[it][j] * r;
+        if (CROP) {  // a cropped-away neighbour carries no loss term (its a is already 0)
+          const bool inside = (unsigned)(igy[it] + ent_oy(en)) < (unsigned)P.Y && (unsigned)(igx[it] + j + ent_ox(en)) < (unsigned)P.X;
+          const bool inz = (unsigned)(z + ioz[it]) < (unsigned)P.Z;
+          wr = (inside && inz) ? wr : 0.f;
+        }
+        g4[j] = en.gscale * wr * m;
+        acc = fmaf(wr, r, acc);
+      }
+      if (has_g) bs128<false>(gB, g4, ivo[it], so);
+      const float red = wave_sum63(acc);
+      if ((threadIdx.x & 63) == 63) s_part[en.i * NSL + (iqd[it] >> 6)] = red;
+    }
+  }
+  if (TRAIN) {
+    __syncthreads();
+    if (threadIdx.x < P.K) {
+      float v = 0.f;
+#pragma unroll
+      for (int s = 0; s < NSL; ++s) v += s_part[threadIdx.x * NSL + s];
       partials[(size_t)threadIdx.x * Q.ntiles + tile] = v;
     }
   }
@@ -387,7 +670,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_tiled(const KParams P, const 
                                                          const float* __restrict__ dloss, T* __restrict__ dx) {
   constexpr int NT = TH * TW;
   constexpr int NR = (ROLE_A ? 1 : 0) + (ROLE_B ? 1 : 0);
-  constexpr int KN = 4;  // near offsets per chunk (x NR roles of g values)
+  constexpr int KN = 8;  // near offsets per chunk (x NR roles of g values; chunk 0 requested before staging)
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   const int tile = tile_id(Q);
@@ -438,12 +721,13 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_tiled(const KParams P, const 
   if (Q.n_near > 0) PEA_BWD_LOAD_GN(0)
 
   // (2) stage
-  stage_region<T, D_T, PLQ, NT, CROP>(P, Q, nB, ezo, ecs, y0, x0, lds);
+  stage<T, D_T, PLQ, NT, CROP>(P, Q, nB, ezo, ecs, y0, x0, lds);
 
-  // (3) first far (offset, role) pair: in flight across the barrier.  Pair j = (far offset j / NR, role j % NR).
+  // (3) far (offset, role) pairs, two at a time: pair j = (far offset j / NR, role j % NR).  Vectors and g of
+  //     the first two pairs are in flight across the barrier and the near-pair work.
   const int n_farp = Q.n_far * NR;
-  float fv[D_T], fg = 0.f;
-#define PEA_BWD_LOAD_FAR(j)                                                                                   \
+  float fvA[D_T], fvB[D_T], fgA = 0.f, fgB = 0.f;
+#define PEA_BWD_LOAD_FAR(fv, fg, j)                                                                           \
   {                                                                                                           \
     const OffEnt fe_ = Q.far[(j) / NR];                                                                       \
     const int sg_ = (ROLE_A && ((j) % NR) == 0) ? 1 : -1;                                                     \
@@ -458,7 +742,15 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_tiled(const KParams P, const 
     _Pragma("unroll") for (int c = 0; c < D_T; ++c) fv[c] = bl_emb<T>(nB, vo_, zc_ * YX * (unsigned)sizeof(T) + c * ecs); \
     fg = bl32(gB, ok_ ? (sg_ > 0 ? po : qo_) * 4u : kOOB, (sg_ > 0 ? kzo : zc_ * YX * 4u) + (unsigned)fe_.i * kcs); \
   }
-  if (n_farp > 0) PEA_BWD_LOAD_FAR(0)
+#define PEA_BWD_FAR(fv, fg)                                                       \
+  {                                                                               \
+    float sq_ = 0.f;                                                              \
+    _Pragma("unroll") for (int c = 0; c < D_T; ++c) sq_ = fmaf(fv[c], fv[c], sq_); \
+    const float g_ = fg * rnorm(sq_, Q.inv_eps);                                  \
+    _Pragma("unroll") for (int c = 0; c < D_T; ++c) G[c] = fmaf(g_, fv[c], G[c]); \
+  }
+  if (n_farp > 0) PEA_BWD_LOAD_FAR(fvA, fgA, 0)
+  if (n_farp > 1) PEA_BWD_LOAD_FAR(fvB, fgB, 1)
 
   float G[D_T];
   float ss = 0.f;
@@ -496,16 +788,16 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_tiled(const KParams P, const 
 #undef PEA_BWD_LOAD_GN
 
   // ---- far pairs (an out-of-range pair read zeros: g = 0, vector = 0) --------------------------------------
-  for (int j = 0; j < n_farp; ++j) {
-    if (j > 0) PEA_BWD_LOAD_FAR(j)
-    float sq = 0.f;
-#pragma unroll
-    for (int c = 0; c < D_T; ++c) sq = fmaf(fv[c], fv[c], sq);
-    const float g = fg * rnorm(sq, Q.inv_eps);
-#pragma unroll
-    for (int c = 0; c < D_T; ++c) G[c] = fmaf(g, fv[c], G[c]);
+  for (int j = 0; j < n_farp; j += 2) {
+    if (j > 0) {
+      PEA_BWD_LOAD_FAR(fvA, fgA, j)
+      if (j + 1 < n_farp) PEA_BWD_LOAD_FAR(fvB, fgB, j + 1)
+    }
+    PEA_BWD_FAR(fvA, fgA)
+    if (j + 1 < n_farp) PEA_BWD_FAR(fvB, fgB)
   }
 #undef PEA_BWD_LOAD_FAR
+#undef PEA_BWD_FAR
 
   float proj = 0.f;
 #pragma unroll
