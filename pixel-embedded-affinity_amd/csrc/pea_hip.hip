@@ -112,7 +112,7 @@ constexpr int kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup ma
 
 // Choose the "near" offsets (served from LDS): the largest in-plane radius whose halo'd region still fits the
 // LDS planes of this tile shape.  both_sides: the backward needs p - o as well as p + o.
-bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, bool can_pair, TParams* Q) {
+bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, TParams* Q) {
   if ((long long)P.Y * P.X >= (1LL << 29)) return false;                     // plane byte offsets stay below 2^31 (kOOB)
   if ((long long)std::max(P.D, P.K) * P.S * 4 > 0xFFFFFFFFLL) return false;  // buffer soffset is 32-bit
   const int NT = c.TH * c.TW;
@@ -136,15 +136,6 @@ bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, bool can_pair, TPa
       q.hx1 = std::max(q.hx1, both_sides ? abs(ox) : ox);
     }
     q.RH = c.TH + q.hy0 + q.hy1;
-    // paired staging (dwordx2) wants an even left halo and an even region width: take it if it still fits
-    if (can_pair && P.X % 2 == 0 && env_int("PEA_PAIR", 0) != 0) {  // experimental, off by default
-      const int h0 = (q.hx0 + 1) & ~1, rw = (c.TW + h0 + q.hx1 + 1) & ~1;
-      if (q.RH * rw <= c.PLQ && P.X >= h0) {
-        q.pair = 1;
-        q.hx0 = h0;
-        q.hx1 = rw - c.TW - h0;
-      }
-    }
     q.RW = c.TW + q.hx0 + q.hx1;
     q.R = q.RH * q.RW;
     if (q.R > c.PLQ) continue;
@@ -154,11 +145,6 @@ bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, bool can_pair, TPa
     q.dc = NT % q.RW;
     q.inv_rw = 1.0f / (float)q.RW;
     q.inv_eps = 1.0f / P.eps;
-    q.RWq = q.RW / 2;
-    q.R2 = q.RH * q.RWq;
-    q.dr2 = q.RWq ? NT / q.RWq : 0;
-    q.dc2 = q.RWq ? NT % q.RWq : 0;
-    q.inv_rwq = q.RWq ? 1.0f / (float)q.RWq : 0.f;
     q.tiles_y = (P.Y + c.TH - 1) / c.TH;
     q.tiles_x = (P.X + c.TW - 1) / c.TW;
     q.tiles_per_plane = q.tiles_y * q.tiles_x;
@@ -192,10 +178,10 @@ size_t fwd_partials(const KParams& P) {
   size_t n = (size_t)P.tiles;
   for (const TileCfg& c : kFwdCfg) {
     TParams q;
-    if (plan_tiles(P, c, false, false, &q)) n = std::max(n, (size_t)q.ntiles);
+    if (plan_tiles(P, c, false, &q)) n = std::max(n, (size_t)q.ntiles);
   }
   TParams qv;
-  if (plan_tiles(P, kFwdV_decl, false, false, &qv)) n = std::max(n, (size_t)qv.ntiles);
+  if (plan_tiles(P, kFwdV_decl, false, &qv)) n = std::max(n, (size_t)qv.ntiles);
   return n;
 }
 
@@ -251,7 +237,7 @@ bool try_fwd_v(const KParams& P, const T* e, const T* eo, const float* t, const 
   const size_t lds = Lds<D_T, c.PLQ>::kBytes + (size_t)P.K * tp * 4 + (size_t)P.K * (tp / 256) * 4;
   if (lds > (size_t)kLdsMax) return false;
   TParams Q;
-  if (!plan_tiles(P, c, false, false, &Q)) return false;
+  if (!plan_tiles(P, c, false, &Q)) return false;
   if (eo == e) launch_fwd_v<T, D_T, TRAIN, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
   else launch_fwd_v<T, D_T, TRAIN, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
   *nparts = Q.ntiles;
@@ -265,7 +251,7 @@ bool try_fwd_tiled(const KParams& P, const T* e, const T* eo, const float* t, co
   const int ci = env_int("PEA_FWD_CFG", kFwdDefault);
   if (ci < 0 || ci >= kNumFwdCfg) return false;
   TParams Q;
-  if (!plan_tiles(P, kFwdCfg[ci], false, !misaligned(eo, 8), &Q)) return false;
+  if (!plan_tiles(P, kFwdCfg[ci], false, &Q)) return false;
   const bool self = (eo == e);
 #define PEA_FWD_CASE(CI)                                                                             \
   case CI:                                                                                           \
@@ -326,7 +312,7 @@ bool try_bwd_tiled(const KParams& P, const T* x, const T* nb, const float* g, co
   const int ci = env_int("PEA_BWD_CFG", kBwdDefault);
   if (ci < 0 || ci >= kNumBwdCfg) return false;
   TParams Q;
-  if (!plan_tiles(P, kBwdCfg[ci], true, !misaligned(nb, 8), &Q)) return false;
+  if (!plan_tiles(P, kBwdCfg[ci], true, &Q)) return false;
 #define PEA_BWD_CASE(CI) \
   case CI: launch_bwd_cfg<T, D_T, RA, RB, CI>(P, Q, x, nb, g, dl, dx, s); break;
   switch (ci) { PEA_BWD_CASE(0) PEA_BWD_CASE(1) default: return false; }

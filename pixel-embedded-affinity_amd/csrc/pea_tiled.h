@@ -48,9 +48,6 @@ struct TParams {
   int RH, RW, R;           // staged region (rows, columns, pixels)
   int dr, dc;              // NT / RW, NT % RW: (row, col) advance of one staging step
   float inv_rw;            // 1 / RW
-  int pair;                // 1: stage two x-adjacent pixels per lane (X, hx0, RW even; 8-byte aligned tensors)
-  int RWq, R2, dr2, dc2;   // the same staging constants in units of pixel pairs
-  float inv_rwq;
   float inv_eps;           // 1 / eps
   int tiles_y, tiles_x, tiles_per_plane;
   int ntiles, tiles_per_xcd;
@@ -188,60 +185,6 @@ __device__ __forceinline__ void stage_region(const KParams& P, const TParams& Q,
   }
 }
 
-// Same, two x-adjacent region pixels per lane and step (dwordx2 loads: half the vector-memory instructions,
-// which is what these kernels are bound by).  Host guarantees: X even, hx0 even, RW even, 8-byte aligned base.
-template <typename T, int D_T, int PLQ, int NT, bool CROP>
-__device__ __forceinline__ void stage_region_pair(const KParams& P, const TParams& Q, rsrc_t eb, unsigned zo, unsigned cs,
-                                                  int y0, int x0, char* __restrict__ lds) {
-  typedef Lds<D_T, PLQ> L;
-  int idx = threadIdx.x;
-  int r = (int)(((float)idx + 0.5f) * Q.inv_rwq);
-  int c = idx - r * Q.RWq;
-#pragma unroll 2
-  for (; idx < Q.R2; idx += NT) {
-    bool oky, okx;
-    const int gy = wrap1<CROP>(y0 - Q.hy0 + r, P.Y, oky);
-    const int gx = wrap1<CROP>(x0 - Q.hx0 + 2 * c, P.X, okx);  // even: the pair never straddles the border
-    const unsigned vo = (oky && okx) ? (unsigned)(gy * P.X + gx) * (unsigned)sizeof(T) : kOOB;
-    float v0[D_T], v1[D_T];
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < D_T; ++ch) {
-      if (sizeof(T) == 4) {
-        const auto t = __builtin_amdgcn_raw_buffer_load_b64(eb, vo, zo + ch * cs, 0);
-        v0[ch] = __builtin_bit_cast(float, t[0]);
-        v1[ch] = __builtin_bit_cast(float, t[1]);
-      } else {
-        const unsigned t = __builtin_amdgcn_raw_buffer_load_b32(eb, vo, zo + ch * cs, 0);
-        v0[ch] = __half2float(__builtin_bit_cast(__half, (unsigned short)(t & 0xffffu)));
-        v1[ch] = __half2float(__builtin_bit_cast(__half, (unsigned short)(t >> 16)));
-      }
-      s0 = fmaf(v0[ch], v0[ch], s0);
-      s1 = fmaf(v1[ch], v1[ch], s1);
-    }
-    const float i0 = rnorm(s0, Q.inv_eps), i1 = rnorm(s1, Q.inv_eps);
-    char* dst = lds + (r * Q.RW + 2 * c) * 16;
-#pragma unroll
-    for (int q = 0; q < L::S; ++q) {
-      f4 a, b;
-      a.x = v0[4 * q] * i0; a.y = v0[4 * q + 1] * i0; a.z = v0[4 * q + 2] * i0; a.w = v0[4 * q + 3] * i0;
-      b.x = v1[4 * q] * i1; b.y = v1[4 * q + 1] * i1; b.z = v1[4 * q + 2] * i1; b.w = v1[4 * q + 3] * i1;
-      *(f4*)(dst + q * L::kPlaneB) = a;
-      *(f4*)(dst + q * L::kPlaneB + 16) = b;
-    }
-    r += Q.dr2;
-    c += Q.dc2;
-    if (c >= Q.RWq) { c -= Q.RWq; r += 1; }
-  }
-}
-
-template <typename T, int D_T, int PLQ, int NT, bool CROP>
-__device__ __forceinline__ void stage(const KParams& P, const TParams& Q, rsrc_t eb, unsigned zo, unsigned cs, int y0, int x0,
-                                      char* __restrict__ lds) {
-  if (Q.pair) stage_region_pair<T, D_T, PLQ, NT, CROP>(P, Q, eb, zo, cs, y0, x0, lds);
-  else stage_region<T, D_T, PLQ, NT, CROP>(P, Q, eb, zo, cs, y0, x0, lds);
-}
-
 // lane -> its pixel of the tile (one pixel per lane)
 template <int TW>
 __device__ __forceinline__ void lane_pixel(int& ly, int& lx) {
@@ -354,7 +297,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled(const KParams P, const 
   }
 
   // (2) stage the region
-  stage<T, D_T, PLQ, NT, CROP>(P, Q, oB, ezo, ecs, y0, x0, lds);
+  stage_region<T, D_T, PLQ, NT, CROP>(P, Q, oB, ezo, ecs, y0, x0, lds);
 
   // (3) the first two far neighbour vectors: in flight across the barrier and the near-offset work
   float fvA[D_T], fvB[D_T];
@@ -549,7 +492,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled_v(const KParams P, cons
   }
 
   // ---- (1) stage the region; (2) first two far vectors in flight across the barrier
-  stage<T, D_T, PLQ, NT, CROP>(P, Q, oB, ezo, ecs, y0, x0, lds);
+  stage_region<T, D_T, PLQ, NT, CROP>(P, Q, oB, ezo, ecs, y0, x0, lds);
   float fvA[D_T], fvB[D_T];
   bool fokA = false, fokB = false;
 #define PEA_FWDV_LOAD_FAR(fv, fok, k)                                                              \
@@ -721,7 +664,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_tiled(const KParams P, const 
   if (Q.n_near > 0) PEA_BWD_LOAD_GN(0)
 
   // (2) stage
-  stage<T, D_T, PLQ, NT, CROP>(P, Q, nB, ezo, ecs, y0, x0, lds);
+  stage_region<T, D_T, PLQ, NT, CROP>(P, Q, nB, ezo, ecs, y0, x0, lds);
 
   // (3) far (offset, role) pairs, two at a time: pair j = (far offset j / NR, role j % NR).  Vectors and g of
   //     the first two pairs are in flight across the barrier and the near-pair work.
@@ -765,6 +708,13 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_tiled(const KParams P, const 
   for (int c = 0; c < D_T; ++c) xh[c] *= invp;
   __syncthreads();
 
+  // Far pairs 0 and 1 were requested before the barrier: consume them first, then request pairs 2 and 3 so that
+  // their round trip hides under the LDS-served near pairs, and consume those last.
+  if (n_farp > 0) PEA_BWD_FAR(fvA, fgA)
+  if (n_farp > 1) PEA_BWD_FAR(fvB, fgB)
+  if (n_farp > 2) PEA_BWD_LOAD_FAR(fvA, fgA, 2)
+  if (n_farp > 3) PEA_BWD_LOAD_FAR(fvB, fgB, 3)
+
   // ---- near pairs ------------------------------------------------------------------------------------
   for (int k0 = 0; k0 < Q.n_near; k0 += KN) {
     if (k0 > 0) PEA_BWD_LOAD_GN(k0)
@@ -787,12 +737,12 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_tiled(const KParams P, const 
   }
 #undef PEA_BWD_LOAD_GN
 
-  // ---- far pairs (an out-of-range pair read zeros: g = 0, vector = 0) --------------------------------------
-  for (int j = 0; j < n_farp; j += 2) {
-    if (j > 0) {
-      PEA_BWD_LOAD_FAR(fvA, fgA, j)
-      if (j + 1 < n_farp) PEA_BWD_LOAD_FAR(fvB, fgB, j + 1)
-    }
+  // ---- remaining far pairs (an out-of-range pair read zeros: g = 0, vector = 0) ------------------------------
+  if (n_farp > 2) PEA_BWD_FAR(fvA, fgA)
+  if (n_farp > 3) PEA_BWD_FAR(fvB, fgB)
+  for (int j = 4; j < n_farp; j += 2) {
+    PEA_BWD_LOAD_FAR(fvA, fgA, j)
+    if (j + 1 < n_farp) PEA_BWD_LOAD_FAR(fvB, fgB, j + 1)
     PEA_BWD_FAR(fvA, fgA)
     if (j + 1 < n_farp) PEA_BWD_FAR(fvB, fgB)
   }
