@@ -171,31 +171,32 @@ __global__ __launch_bounds__(kBlock) void k_fwd_direct(const KParams P, const T*
 }
 
 // fixed-order f64 reduction of the per-workgroup partials ([K][nparts]): loss_out = {loss, L_0..L_{K-1}}.
-// All 16 waves work on every offset; per offset the order is: per-thread strided sum -> wave tree ->
-// waves in index order.  Nothing depends on timing, so the result is bit-reproducible.
+// One wave per offset (16 waves work on 16 offsets at once); inside a wave every lane sums a strided slice with
+// four independent accumulators (the loads of a row are independent, so they pipeline), then a fixed wave tree.
+// Nothing depends on timing, so the result is bit-reproducible.
 __global__ __launch_bounds__(1024) void k_loss_finalize(const KParams P, const float* __restrict__ partials,
                                                         int nparts, float* __restrict__ loss_out) {
-  __shared__ double s_w[16][PEA_MAX_K];
   __shared__ double s_l[PEA_MAX_K];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int i = 0; i < P.K; ++i) {
+  for (int i = wave; i < P.K; i += 16) {
     const float* row = partials + (size_t)i * nparts;
-    double acc = 0.0;
-#pragma unroll 4
-    for (int t = threadIdx.x; t < nparts; t += 1024) acc += (double)row[t];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int t = lane;
+    for (; t + 192 < nparts; t += 256) {
+      a0 += (double)row[t];
+      a1 += (double)row[t + 64];
+      a2 += (double)row[t + 128];
+      a3 += (double)row[t + 192];
+    }
+    for (; t < nparts; t += 64) a0 += (double)row[t];
+    double acc = (a0 + a1) + (a2 + a3);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if (lane == 0) s_w[wave][i] = acc;
-  }
-  __syncthreads();
-  if (threadIdx.x < P.K) {
-    const int i = threadIdx.x;
-    double acc = 0.0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) acc += s_w[w][i];
-    const double Li = acc * (double)P.inv_n[i];
-    s_l[i] = Li;
-    loss_out[1 + i] = (float)Li;
+    if (lane == 0) {
+      const double Li = acc * (double)P.inv_n[i];
+      s_l[i] = Li;
+      loss_out[1 + i] = (float)Li;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
