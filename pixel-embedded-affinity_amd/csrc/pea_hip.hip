@@ -181,7 +181,7 @@ size_t fwd_partials(const KParams& P) {
     if (plan_tiles(P, c, false, &q)) n = std::max(n, (size_t)q.ntiles);
   }
   TParams qv;
-  if (plan_tiles(P, kFwdV_decl, false, &qv)) n = std::max(n, (size_t)qv.ntiles);
+  if (plan_tiles(P, kFwdV_decl, false, &qv)) n = std::max(n, (size_t)qv.ntiles);  // (the 16x32 shape is in kFwdCfg)
   return n;
 }
 
@@ -207,19 +207,20 @@ void launch_fwd_cfg(const KParams& P, const TParams& Q, const T* e, const T* eo,
 }
 
 // forward with the LDS-transposed, dwordx4 epilogue (k_fwd_tiled_v): the default when its preconditions hold
-constexpr TileCfg kFwdV = kFwdV_decl;
+constexpr TileCfg kFwdV = kFwdV_decl;       // 32x32 tile, dot products next to the region: 1 workgroup of 16 waves per CU
+constexpr TileCfg kFwdVO = {16, 32, 1040};  // 16x32 tile, dot products laid over the region: 2 workgroups of 8 waves per CU
 
-template <typename T, int D_T, bool TRAIN, bool SELF>
+template <typename T, int D_T, bool TRAIN, bool SELF, bool OVL>
 void launch_fwd_v(const KParams& P, const TParams& Q, size_t lds, const T* e, const T* eo, const float* t, const float* w,
                   const uint8_t* m, float* affs, float* gout, float* partials, hipStream_t s) {
-  constexpr TileCfg c = kFwdV;
+  constexpr TileCfg c = OVL ? kFwdVO : kFwdV;
   const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(c.TH * c.TW);
   if (P.border == PEA_BORDER_CIRCULAR) {
-    constexpr auto kern = k_fwd_tiled_v<T, D_T, c.TH, c.TW, c.PLQ, false, TRAIN, SELF>;
+    constexpr auto kern = k_fwd_tiled_v<T, D_T, c.TH, c.TW, c.PLQ, OVL, false, TRAIN, SELF>;
     allow_lds<kern>(lds);
     hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials);
   } else {
-    constexpr auto kern = k_fwd_tiled_v<T, D_T, c.TH, c.TW, c.PLQ, true, TRAIN, SELF>;
+    constexpr auto kern = k_fwd_tiled_v<T, D_T, c.TH, c.TW, c.PLQ, OVL, true, TRAIN, SELF>;
     allow_lds<kern>(lds);
     hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials);
   }
@@ -232,14 +233,23 @@ bool try_fwd_v(const KParams& P, const T* e, const T* eo, const float* t, const 
   if (P.K > kKV || P.X % 4) return false;
   if (misaligned(t, 16) || misaligned(w, 16) || misaligned(affs, 16) || misaligned(gout, 16) || misaligned(m, 4)) return false;
   if ((P.tbs | P.wbs | P.mbs | (long long)P.S) & 3) return false;
-  constexpr TileCfg c = kFwdV;
+  const bool ovl = env_int("PEA_FWD_OVL", 1) != 0;
+  const TileCfg c = ovl ? kFwdVO : kFwdV;
   const size_t tp = (size_t)c.TH * c.TW;
-  const size_t lds = Lds<D_T, c.PLQ>::kBytes + (size_t)P.K * tp * 4 + (size_t)P.K * (tp / 256) * 4;
+  const size_t region = Lds<D_T, 1>::kBytes * (size_t)c.PLQ, dots = (size_t)P.K * tp * 4, parts = (size_t)P.K * (tp / 256) * 4;
+  if (ovl && dots > region) return false;
+  const size_t lds = ovl ? region + parts : region + dots + parts;
   if (lds > (size_t)kLdsMax) return false;
   TParams Q;
-  if (!plan_tiles(P, c, false, &Q)) return false;
-  if (eo == e) launch_fwd_v<T, D_T, TRAIN, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
-  else launch_fwd_v<T, D_T, TRAIN, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
+  if (!plan_tiles(P, c, false, &Q) || Q.n_near > kKV || Q.n_far > kFV) return false;
+  const bool self = eo == e;
+  if (ovl) {
+    if (self) launch_fwd_v<T, D_T, TRAIN, true, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
+    else launch_fwd_v<T, D_T, TRAIN, false, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
+  } else {
+    if (self) launch_fwd_v<T, D_T, TRAIN, true, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
+    else launch_fwd_v<T, D_T, TRAIN, false, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
+  }
   *nparts = Q.ntiles;
   return true;
 }

@@ -399,7 +399,8 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled(const KParams P, const 
 // staging and the dot products.
 // Needs: K <= kKV, X % 4 == 0, 16-byte aligned target / weight / affs / g planes, 4-byte aligned mask planes.
 // ------------------------------------------------------------------------------------------------
-constexpr int kKV = 12;
+constexpr int kKV = 12;  // max offsets (near) the register-resident / transposed epilogue handles
+constexpr int kFV = 4;   // max far offsets
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 // 16-byte buffer store.  HAZARD (gfx950, ROCm 7.2): a VALU write to one of the store's data VGPRs in the very
@@ -412,7 +413,7 @@ __device__ __forceinline__ void bs128(rsrc_t r, f4 v, unsigned vo, unsigned so) 
   asm volatile("s_nop 1" ::: "memory");
 }
 
-template <typename T, int D_T, int TH, int TW, int PLQ, bool CROP, bool TRAIN, bool SELF>
+template <typename T, int D_T, int TH, int TW, int PLQ, bool OVL, bool CROP, bool TRAIN, bool SELF>
 __global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled_v(const KParams P, const TParams Q, const T* __restrict__ e,
                                                            const T* __restrict__ eo, const float* __restrict__ target,
                                                            const float* __restrict__ weight,
@@ -424,8 +425,10 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled_v(const KParams P, cons
   static_assert(QP % 64 == 0 && TW % 4 == 0, "a wave must cover quads of one offset plane");
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
-  float* sA = (float*)(lds + L::kBytes);       // [K][TP] dot products
-  float* s_part = sA + (size_t)P.K * TP;       // [K][NSL]
+  // [K][TP] dot products: OVL = laid over the staged region once every wave is done reading it (smaller LDS
+  // footprint: two workgroups per CU), else next to it
+  float* sA = OVL ? (float*)lds : (float*)(lds + L::kBytes);
+  float* s_part = OVL ? (float*)(lds + L::kBytes) : sA + (size_t)P.K * TP;  // [K][NSL]
   const int tile = tile_id(Q);
   if (tile >= Q.ntiles) return;
   const int plane = tile / Q.tiles_per_plane;
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled_v(const KParams P, cons
       dot_ = fmaf(own[c], fv[c], dot_);                                                            \
       sq_ = fmaf(fv[c], fv[c], sq_);                                                               \
     }                                                                                              \
-    myA[Q.far[k].i * TP] = fok ? dot_ * rnorm(sq_, Q.inv_eps) : 0.f;                               \
+    afar[k] = fok ? dot_ * rnorm(sq_, Q.inv_eps) : 0.f;                                            \
   }
   if (Q.n_far > 0) PEA_FWDV_LOAD_FAR(fvA, fokA, 0)
   if (Q.n_far > 1) PEA_FWDV_LOAD_FAR(fvB, fokB, 1)
@@ -529,30 +532,40 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled_v(const KParams P, cons
   __syncthreads();
   if (SELF) lds_pixel<D_T, PLQ>(lds, pr, own);
 
-  // ---- (3) dot products -> sA[offset][tile pixel]
-  for (int k = 0; k < Q.n_near; ++k) {
-    const OffEnt en = Q.near[k];
-    float v[D_T];
-    lds_pixel<D_T, PLQ>(lds, pr + en.d, v);
-    float a = 0.f;
+  // ---- (3) dot products, kept in registers (host guarantees n_near <= kKV, n_far <= kFV)
+  float anear[kKV], afar[kFV];
 #pragma unroll
-    for (int c = 0; c < D_T; ++c) a = fmaf(own[c], v[c], a);
-    if (CROP) {
-      const bool inside = (unsigned)(py + ent_oy(en)) < (unsigned)P.Y && (unsigned)(px + ent_ox(en)) < (unsigned)P.X;
-      a = inside ? a : 0.f;
+  for (int k = 0; k < kKV; ++k) {
+    if (k < Q.n_near) {  // uniform
+      const OffEnt en = Q.near[k];
+      float v[D_T];
+      lds_pixel<D_T, PLQ>(lds, pr + en.d, v);
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < D_T; ++c) a = fmaf(own[c], v[c], a);
+      if (CROP) {
+        const bool inside = (unsigned)(py + ent_oy(en)) < (unsigned)P.Y && (unsigned)(px + ent_ox(en)) < (unsigned)P.X;
+        a = inside ? a : 0.f;
+      }
+      anear[k] = a;
     }
-    myA[en.i * TP] = a;
   }
-  for (int k = 0; k < Q.n_far; k += 2) {
-    if (k > 0) {
-      PEA_FWDV_LOAD_FAR(fvA, fokA, k)
-      if (k + 1 < Q.n_far) PEA_FWDV_LOAD_FAR(fvB, fokB, k + 1)
-    }
-    PEA_FWDV_FAR(fvA, fokA, k)
-    if (k + 1 < Q.n_far) PEA_FWDV_FAR(fvB, fokB, k + 1)
-  }
+  if (Q.n_far > 0) PEA_FWDV_FAR(fvA, fokA, 0)
+  if (Q.n_far > 1) PEA_FWDV_FAR(fvB, fokB, 1)
+  if (Q.n_far > 2) PEA_FWDV_LOAD_FAR(fvA, fokA, 2)
+  if (Q.n_far > 3) PEA_FWDV_LOAD_FAR(fvB, fokB, 3)
+  if (Q.n_far > 2) PEA_FWDV_FAR(fvA, fokA, 2)
+  if (Q.n_far > 3) PEA_FWDV_FAR(fvB, fokB, 3)
 #undef PEA_FWDV_LOAD_FAR
 #undef PEA_FWDV_FAR
+  // -> sA[offset][tile pixel]; with OVL the region must be dead first
+  if (OVL) __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kKV; ++k)
+    if (k < Q.n_near) myA[Q.near[k].i * TP] = anear[k];
+#pragma unroll
+  for (int k = 0; k < kFV; ++k)
+    if (k < Q.n_far) myA[Q.far[k].i * TP] = afar[k];
   __syncthreads();
 
   // ---- (4) epilogue: 4 x-adjacent pixels of one offset per lane, dwordx4 everywhere
