@@ -315,3 +315,71 @@ def test_random_shapes_and_stencils_vs_oracle(pkg, dev, orc, synth):
         assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL, ctx
         if ema is not None:
             assert relmax(em.grad.cpu().numpy(), o_grad_e) < GRAD_RTOL, ctx
+
+
+def test_tiled_crop_3d_norm5_and_ema_vs_oracle(pkg, dev, orc, synth):
+    """3D shapes wide enough for the LDS-tiled CROP_ZERO kernels (the golden 3D fixtures are narrower than a tile
+    and take the direct kernels): norm5 (z offsets and +-27 are 'far', the rest 'near'), self and EMA."""
+    B, D, Z, Y, X = 2, 16, 5, 40, 64
+    sh = [1, 1, 1, 2, 3, 3, 3, 9, 9, 4, 27, 27]
+    offs = orc.norm_offsets(sh)
+    e, t, w = synth.synth_inputs_3d(B, D, Z, Y, X, offs, 17)
+    ema = synth.synth_embedding((B, D, Z, Y, X), 18)
+    crit = pkg.WeightedMSE()
+    for use_ema in (False, True):
+        et = cu(e, dev).requires_grad_(True)
+        if use_ema:
+            loss, affs = pkg.ema_embedding_loss_norm5(et, cu(ema, dev), cu(t, dev), cu(w, dev), crit, affs0_weight=2)
+        else:
+            loss, affs = pkg.embedding_loss_norm5(et, cu(t, dev), cu(w, dev), crit, affs0_weight=2)
+        (loss * 0.25).backward()
+        d = orc.desc_3d(e, sh, orc.affs0_lambda_3d(12, 2, 3))
+        o_affs, o_loss = orc.c_fwd(d, e, ema if use_ema else None, t, w, None)
+        o_grad, _ = orc.c_bwd(d, e, ema if use_ema else None, t, w, None, dloss=0.25)
+        assert np.abs(affs.cpu().numpy() - o_affs).max() < AFFS_ATOL
+        assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+        assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL
+    inf = pkg.inf_embedding_loss_norm5(cu(e, dev))
+    d = orc.desc_3d(e, sh)
+    assert np.abs(inf.cpu().numpy() - orc.c_fwd(d, e)[0]).max() < AFFS_ATOL
+
+
+def test_tiled_fp16_d16_vs_oracle(pkg, dev, orc, synth):
+    """f16 storage through the LDS-tiled kernels (D=16): f32 arithmetic on exactly the rounded inputs"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    B, D, H, W = 2, 16, 48, 96
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 23)
+    e16 = e.astype(np.float16)
+    et = torch.from_numpy(e16).to(dev).requires_grad_(True)
+    loss, affs, _ = pkg.embedding_loss(et, cu(t, dev), cu(w, dev), cu(m, dev), pkg.WeightedMSE(), offsets)
+    loss.backward()
+    e_r = e16.astype(np.float32)
+    d = orc.desc_2d(e_r, offsets)
+    o_affs, o_loss = orc.c_fwd(d, e_r, None, t, w, m)
+    o_grad, _ = orc.c_bwd(d, e_r, None, t, w, m)
+    assert np.abs(affs.cpu().numpy() - o_affs).max() < AFFS_ATOL
+    assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+    assert relmax(et.grad.float().cpu().numpy(), o_grad) < 2e-3  # f16 rounding of the stored gradient
+    inf = pkg.embedding2affs(et.detach(), offsets)
+    assert np.abs(inf.cpu().numpy() - o_affs).max() < AFFS_ATOL
+
+
+def test_tiled_and_direct_kernels_agree(pkg, dev, synth, monkeypatch):
+    """the LDS-tiled kernels against the global-memory kernels on the same inputs (PEA_FORCE_DIRECT switches)"""
+    offsets = pkg.multi_offset([1, 3, 9], 8)  # diagonal and mixed-sign offsets: two-sided halos in x
+    B, D, H, W = 2, 16, 70, 132
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 29)
+
+    def run():
+        et = cu(e, dev).requires_grad_(True)
+        loss, affs, parts = pkg.embedding_loss(et, cu(t, dev), cu(w, dev), cu(m, dev), pkg.WeightedMSE(), offsets)
+        loss.backward()
+        return loss.item(), affs.cpu().numpy(), et.grad.cpu().numpy()
+
+    monkeypatch.delenv("PEA_FORCE_DIRECT", raising=False)
+    l1, a1, g1 = run()
+    monkeypatch.setenv("PEA_FORCE_DIRECT", "1")
+    l0, a0, g0 = run()
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    assert np.abs(a1 - a0).max() < 2e-6
+    assert relmax(g1, g0) < 1e-5
