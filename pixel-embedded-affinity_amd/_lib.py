@@ -46,7 +46,7 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
 def build(force=False, verbose=False):
     """Compile csrc/pea_hip.hip -> csrc/libpea_hip.so for gfx950."""
     src = os.path.join(CSRC, "pea_hip.hip")
-    deps = [src, HEADER]
+    deps = [src, HEADER] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
         return SO_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
