@@ -18,6 +18,7 @@
  *                          scripts_ac3ac4/loss/loss_embedding_mse.py:169-194 embedding_loss_norm5
  *                          scripts_ac3ac4/loss/loss_embedding_mse.py:30-51,263-289 ema_..._norm1/5
  *                          with loss/loss.py:106-124 WeightedMSE (same in all three script trees) fused in
+ *   pea_affinity_fwd_bwd <- pea_affinity_fwd and pea_affinity_bwd of the same call in one launch (default criterion)
  *   pea_affinity_bwd    <- the torch.autograd backward of the functions above (also the vjp for foreign criteria)
  *                          (the reference has no explicit backward; loss.backward() at
  *                          scripts_cvppp/main.py:311, scripts_ac3ac4/main.py:232)
@@ -47,7 +48,7 @@
 extern "C" {
 #endif
 
-#define PEA_ABI_VERSION 1
+#define PEA_ABI_VERSION 1 /* version of PeaDesc and of the semantics of the existing calls; new entry points do not bump it */
 #define PEA_MAX_K 32 /* 26-neighbourhood (BASELINE config 4) fits */
 
 /* border modes */
@@ -126,6 +127,24 @@ int pea_affinity_fwd(const PeaDesc *desc, const void *e, const void *e_other, co
  * w.r.t. e_other; de may be NULL when only de_other is wanted.  Gather form, no atomics, bit-reproducible. */
 int pea_affinity_bwd(const PeaDesc *desc, const void *e, const void *e_other, const float *g, const float *dloss,
                      void *de, void *de_other, void *stream);
+
+/* Training step in ONE launch (the fused WeightedMSE path): the outputs of pea_affinity_fwd -- affs (nullable) and
+ * loss_out[1 + K] -- and de = dloss * d loss / d e (same dtype / layout as e) without the g round trip through HBM.
+ * Replaces, for the default criterion, the pair embedding_loss(...) + loss.backward()
+ * (scripts_cvppp/main.py:284-293,311; scripts_ac3ac4/main.py:219-232).  e_other: NULL (self loss) or the DETACHED
+ * second operand (ema_embedding_loss after convert_consistency_flip, scripts_cvppp/data/data_consistency.py:36);
+ * a second operand that needs its own gradient takes pea_affinity_fwd + pea_affinity_bwd.  dloss: device scalar or
+ * NULL (= 1; scale later with pea_scale_inplace).  Returns PEA_E_UNSUPPORTED when no fused kernel covers the
+ * descriptor (D != 16, stencil too wide for the LDS tile): call pea_affinity_fwd + pea_affinity_bwd instead.
+ * workspace: as pea_affinity_fwd. */
+int pea_affinity_fwd_bwd(const PeaDesc *desc, const void *e, const void *e_other, const float *target,
+                         const float *weight, const uint8_t *mask, float *affs, float *loss_out, const float *dloss,
+                         void *de, void *workspace, size_t workspace_bytes, void *stream);
+
+/* buf[0..n) *= scale[0] in place (dtype PEA_F32 / PEA_F16; f32 buffers 16-byte aligned).  `scale` is a DEVICE scalar
+ * (autograd's grad_output): the kernel reads it and returns without touching buf when it is exactly 1, which is
+ * what a plain loss.backward() hands to the gradient pea_affinity_fwd_bwd produced for dloss = 1. */
+int pea_scale_inplace(void *buf, int dtype, size_t n, const float *scale, void *stream);
 
 #ifdef __cplusplus
 }

@@ -16,13 +16,14 @@ HEADER = os.path.join(HERE, "..", "include", "pea.h")
 
 PEA_ABI_VERSION = 1
 PEA_MAX_K = 32
+E_UNSUPPORTED = -3
 BORDER_CIRCULAR, BORDER_CROP_ZERO = 0, 1
 F32, F16 = 0, 1
 NORM_BX, NORM_CROPPED, NORM_FULL = 0, 1, 2
 FLAG_RELU_AFFS = 1
 
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",
-           "pea_affinity_fwd", "pea_affinity_bwd")
+           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_bwd", "pea_scale_inplace")
 
 
 class PeaLibraryError(RuntimeError):
@@ -94,6 +95,10 @@ def lib():
     L.pea_affinity_fwd.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.pea_affinity_bwd.restype = ctypes.c_int
     L.pea_affinity_bwd.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp]
+    L.pea_affinity_fwd_bwd.restype = ctypes.c_int
+    L.pea_affinity_fwd_bwd.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.pea_scale_inplace.restype = ctypes.c_int
+    L.pea_scale_inplace.argtypes = [vp, ctypes.c_int, ctypes.c_size_t, vp, vp]
     if L.pea_version() != PEA_ABI_VERSION:
         raise PeaLibraryError("ABI mismatch: library %d, binding %d" % (L.pea_version(), PEA_ABI_VERSION))
     _lib = L

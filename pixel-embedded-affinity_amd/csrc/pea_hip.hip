@@ -24,6 +24,7 @@
 #include "pea_direct.h"
 #include "pea_tiled.h"
 #include "pea_phased.h"
+#include "pea_fused.h"
 #include "pea_plan.h"
 
 using namespace pea;
@@ -101,14 +102,28 @@ int env_int(const char* name, int dflt) {
 
 bool misaligned(const void* p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
 
+int device_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n = v;
+    else
+      n = 256;
+    (void)hipGetLastError();
+  }
+  return n;
+}
+
 // ------------------------------------------------------------------------------------------------
 // tile planning
 // ------------------------------------------------------------------------------------------------
 struct TileCfg { int TH, TW, PLQ; };  // workgroup = TH*TW lanes (one per pixel); PLQ = LDS plane stride in pixels
 // compiled-in shapes; index chosen by PEA_FWD_CFG / PEA_BWD_CFG (defaults = the measured best, CVPPP stencil)
-constexpr TileCfg kFwdV_decl = {32, 32, 1696};
-constexpr TileCfg kFwdCfg[] = {{16, 32, 1040}, {32, 32, 1696}, {8, 64, 1248}};
-constexpr TileCfg kBwdCfg[] = {{32, 32, 2504}, {16, 32, 1712}};
+constexpr TileCfg kFwdV_decl = {32, 32, 1697};
+constexpr TileCfg kFwdCfg[] = {{16, 32, 1041}, {32, 32, 1697}, {8, 64, 1249}};
+constexpr TileCfg kBwdCfg[] = {{32, 32, 2505}, {16, 32, 1713}};
 constexpr int kNumFwdCfg = sizeof(kFwdCfg) / sizeof(kFwdCfg[0]), kNumBwdCfg = sizeof(kBwdCfg) / sizeof(kBwdCfg[0]);
 constexpr int kFwdDefault = 0, kBwdDefault = 0;
 constexpr int kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may take all of it
@@ -211,7 +226,7 @@ void launch_fwd_cfg(const KParams& P, const TParams& Q, const T* e, const T* eo,
 
 // forward with the LDS-transposed, dwordx4 epilogue (k_fwd_tiled_v): the default when its preconditions hold
 constexpr TileCfg kFwdV = kFwdV_decl;       // 32x32 tile, dot products next to the region: 1 workgroup of 16 waves per CU
-constexpr TileCfg kFwdVO = {16, 32, 1040};  // 16x32 tile, dot products laid over the region: 2 workgroups of 8 waves per CU
+constexpr TileCfg kFwdVO = {16, 32, 1041};  // 16x32 tile, dot products laid over the region: 2 workgroups of 8 waves per CU
 
 template <typename T, int D_T, bool TRAIN, bool SELF, bool OVL>
 void launch_fwd_v(const KParams& P, const TParams& Q, size_t lds, const T* e, const T* eo, const float* t, const float* w,
@@ -333,20 +348,6 @@ bool try_bwd_tiled(const KParams& P, const T* x, const T* nb, const float* g, co
   return true;
 }
 
-int device_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      n = v;
-    else
-      n = 256;
-    (void)hipGetLastError();
-  }
-  return n;
-}
-
 long long* g_stamps = nullptr;  // diagnostic: device buffer [grid][64] for s_memtime stamps (pea_debug_stamps)
 
 // phase-machine backward (pea_phased.h): experimental, PEA_BWD_PHASED=1
@@ -413,6 +414,49 @@ int launch_bwd(const KParams& P, int roles, const void* x, const void* nbA, cons
     case 4: return launch_bwd_roles<T, 4>(P, roles, (const T*)x, (const T*)nbA, (const T*)nbB, g, dl, (T*)dx, s);
     case 8: return launch_bwd_roles<T, 8>(P, roles, (const T*)x, (const T*)nbA, (const T*)nbB, g, dl, (T*)dx, s);
     default: return PEA_E_UNSUPPORTED;  // training needs D in {4, 8, 16, 32, 64}
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// fused forward + backward dispatch (pea_fused.h): same tile plan as the tiled backward
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D_T, bool RB>
+bool try_fused(const KParams& P, const T* x, const T* nb, const float* t, const float* w, const uint8_t* m, float* affs,
+               float* partials, const float* dl, T* dx, hipStream_t s, int* nparts) {
+  constexpr TileCfg c = kBwdCfg[0];
+  TParams Q;
+  if (!plan_tiles(P, c, RB, &Q)) return false;
+  const size_t lds = Lds<D_T, c.PLQ>::kBytes + (size_t)(c.TH * c.TW / 64) * P.K * sizeof(float);
+  if (lds > (size_t)kLdsMax) return false;
+  const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(c.TH * c.TW);
+  if (P.border == PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_fused_tiled<T, D_T, c.TH, c.TW, c.PLQ, false, RB>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, x, nb, t, w, m, affs, partials, dl, dx);
+  } else {
+    constexpr auto kern = k_fused_tiled<T, D_T, c.TH, c.TW, c.PLQ, true, RB>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, x, nb, t, w, m, affs, partials, dl, dx);
+  }
+  *nparts = Q.ntiles;
+  return true;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_scale_inplace(T* __restrict__ buf, size_t n4, size_t n, const float* __restrict__ scale) {
+  const float sc = scale[0];
+  if (sc == 1.0f) return;  // the common loss.backward() case: nothing to do, nothing touched
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (sizeof(T) == 4) {
+    if (i < n4) {
+      f4 v = ((f4*)buf)[i];
+      v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+      ((f4*)buf)[i] = v;
+    }
+    if (i < n - 4 * n4) ((float*)buf)[4 * n4 + i] *= sc;
+  } else {
+    for (size_t k = i * 4; k < min(n, i * 4 + 4); ++k) st(buf, k, ld(buf, k) * sc);
   }
 }
 
@@ -506,6 +550,54 @@ int pea_affinity_bwd(const PeaDesc* desc, const void* e, const void* e_other, co
   if (!de_other) return PEA_OK;
   return h ? launch_bwd<__half>(P, 2, e_other, nullptr, e, g, dloss, de_other, s)
            : launch_bwd<float>(P, 2, e_other, nullptr, e, g, dloss, de_other, s);
+}
+
+int pea_affinity_fwd_bwd(const PeaDesc* desc, const void* e, const void* e_other, const float* target,
+                         const float* weight, const uint8_t* mask, float* affs, float* loss_out, const float* dloss,
+                         void* de, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = validate(desc);
+  if (rc) return rc;
+  if (!e || !target || !weight || !loss_out || !de) return PEA_E_NULL;
+  const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
+  if (misaligned(e, es) || misaligned(e_other, es) || misaligned(de, es) || misaligned(affs, 4) || misaligned(target, 4) ||
+      misaligned(weight, 4) || misaligned(loss_out, 4) || misaligned(dloss, 4) || misaligned(workspace, 4))
+    return PEA_E_ALIGN;
+  const KParams P = make_params(desc);
+  if (!workspace || workspace_bytes < fwd_partials(P) * P.K * sizeof(float)) return PEA_E_WORKSPACE;
+  if (P.D != 16 || env_int("PEA_FORCE_DIRECT", 0) != 0) return PEA_E_UNSUPPORTED;  // caller: pea_affinity_fwd + pea_affinity_bwd
+  hipStream_t s = (hipStream_t)stream;
+  float* partials = (float*)workspace;
+  int nparts = 0;
+  bool done;
+  if (desc->dtype == PEA_F16) {
+    const __half *x = (const __half*)e, *nb = (const __half*)e_other;
+    done = nb ? try_fused<__half, 16, false>(P, x, nb, target, weight, mask, affs, partials, dloss, (__half*)de, s, &nparts)
+              : try_fused<__half, 16, true>(P, x, x, target, weight, mask, affs, partials, dloss, (__half*)de, s, &nparts);
+  } else {
+    const float *x = (const float*)e, *nb = (const float*)e_other;
+    done = nb ? try_fused<float, 16, false>(P, x, nb, target, weight, mask, affs, partials, dloss, (float*)de, s, &nparts)
+              : try_fused<float, 16, true>(P, x, x, target, weight, mask, affs, partials, dloss, (float*)de, s, &nparts);
+  }
+  if (!done) return PEA_E_UNSUPPORTED;
+  rc = hip_rc();
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P, partials, nparts, loss_out);
+  return hip_rc();
+}
+
+int pea_scale_inplace(void* buf, int dtype, size_t n, const float* scale, void* stream) {
+  if (!buf || !scale) return PEA_E_NULL;
+  if (dtype != PEA_F32 && dtype != PEA_F16) return PEA_E_DESC;
+  if (misaligned(buf, dtype == PEA_F32 ? 16 : 2) || misaligned(scale, 4)) return PEA_E_ALIGN;
+  if (n == 0) return PEA_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n4 = dtype == PEA_F32 ? n / 4 : 0;
+  const size_t items = dtype == PEA_F32 ? std::max(n4, n - 4 * n4) : (n + 3) / 4;
+  const size_t blocks = (items + 255) / 256;
+  if (blocks > 0x7fffffffULL) return PEA_E_UNSUPPORTED;
+  if (dtype == PEA_F32) hipLaunchKernelGGL(k_scale_inplace<float>, dim3((unsigned)blocks), dim3(256), 0, s, (float*)buf, n4, n, scale);
+  else hipLaunchKernelGGL(k_scale_inplace<__half>, dim3((unsigned)blocks), dim3(256), 0, s, (__half*)buf, n4, n, scale);
+  return hip_rc();
 }
 
 }  // extern "C"

@@ -34,6 +34,7 @@ one = torch.ones((), device=dev)
 P = lambda x: ctypes.c_void_p(x.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 fns = {
+    "fused": lambda: L.pea_affinity_fwd_bwd(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), P(lossv), None, P(dE), P(work), wsb, st),
     "fwd": lambda: L.pea_affinity_fwd(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), P(G), P(lossv), P(work), wsb, st),
     "bwd": lambda: L.pea_affinity_bwd(ctypes.byref(desc), P(E), None, P(G), P(one), P(dE), None, st),
     "inf": lambda: L.pea_affinity_infer(ctypes.byref(desc), P(E), None, P(affs), st),
