@@ -125,6 +125,12 @@ constexpr TileCfg kFwdV_decl = {32, 32, 1697};
 constexpr TileCfg kFwdCfg[] = {{16, 32, 1041}, {32, 32, 1697}, {8, 64, 1249}};
 constexpr TileCfg kBwdCfg[] = {{32, 32, 2505}, {16, 32, 1713}};
 constexpr int kNumFwdCfg = sizeof(kFwdCfg) / sizeof(kFwdCfg[0]), kNumBwdCfg = sizeof(kBwdCfg) / sizeof(kBwdCfg[0]);
+// D = 32: 128 B of LDS per region pixel, so one shape: 16x32 tiles, 1041 region pixels (133 KB, one workgroup of 8 waves per CU)
+constexpr TileCfg kCfg32 = {16, 32, 1041};
+template <int D_T> constexpr TileCfg fwd_cfg(int ci) { return D_T == 32 ? kCfg32 : kFwdCfg[ci]; }
+constexpr TileCfg kCfg32B = {16, 32, 1093};  // backward: two-sided halo of 5 (26 x 42 region pixels, 140 KB)
+template <int D_T> constexpr TileCfg bwd_cfg(int ci) { return D_T == 32 ? kCfg32B : kBwdCfg[ci]; }
+template <int D_T> constexpr TileCfg fwdv_cfg(bool ovl) { return D_T == 32 ? kCfg32 : (ovl ? TileCfg{16, 32, 1041} : TileCfg{32, 32, 1697}); }
 constexpr int kFwdDefault = 0, kBwdDefault = 0;
 constexpr int kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may take all of it
 
@@ -209,7 +215,7 @@ size_t fwd_partials(const KParams& P) {
 template <typename T, int D_T, bool TRAIN, bool SELF, int CI>
 void launch_fwd_cfg(const KParams& P, const TParams& Q, const T* e, const T* eo, const float* t, const float* w,
                     const uint8_t* m, float* affs, float* gout, float* partials, hipStream_t s) {
-  constexpr TileCfg c = kFwdCfg[CI];
+  constexpr TileCfg c = fwd_cfg<D_T>(CI);
   constexpr int NT = c.TH * c.TW;
   const size_t lds = Lds<D_T, c.PLQ>::kBytes + (TRAIN ? (size_t)(NT / 64) * P.K * sizeof(float) : 0);
   const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(NT);
@@ -231,7 +237,7 @@ constexpr TileCfg kFwdVO = {16, 32, 1041};  // 16x32 tile, dot products laid ove
 template <typename T, int D_T, bool TRAIN, bool SELF, bool OVL>
 void launch_fwd_v(const KParams& P, const TParams& Q, size_t lds, const T* e, const T* eo, const float* t, const float* w,
                   const uint8_t* m, float* affs, float* gout, float* partials, hipStream_t s) {
-  constexpr TileCfg c = OVL ? kFwdVO : kFwdV;
+  constexpr TileCfg c = fwdv_cfg<D_T>(OVL);
   const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(c.TH * c.TW);
   if (P.border == PEA_BORDER_CIRCULAR) {
     constexpr auto kern = k_fwd_tiled_v<T, D_T, c.TH, c.TW, c.PLQ, OVL, false, TRAIN, SELF>;
@@ -251,8 +257,8 @@ bool try_fwd_v(const KParams& P, const T* e, const T* eo, const float* t, const 
   if (P.K > kKV || P.X % 4) return false;
   if (misaligned(t, 16) || misaligned(w, 16) || misaligned(affs, 16) || misaligned(gout, 16) || misaligned(m, 4)) return false;
   if ((P.tbs | P.wbs | P.mbs | (long long)P.S) & 3) return false;
-  const bool ovl = env_int("PEA_FWD_OVL", 1) != 0;
-  const TileCfg c = ovl ? kFwdVO : kFwdV;
+  const bool ovl = D_T == 32 || env_int("PEA_FWD_OVL", 1) != 0;
+  const TileCfg c = fwdv_cfg<D_T>(ovl);
   const size_t tp = (size_t)c.TH * c.TW;
   const size_t region = Lds<D_T, 1>::kBytes * (size_t)c.PLQ, dots = (size_t)P.K * tp * 4, parts = (size_t)P.K * (tp / 256) * 4;
   if (ovl && dots > region) return false;
@@ -279,7 +285,7 @@ bool try_fwd_tiled(const KParams& P, const T* e, const T* eo, const float* t, co
   const int ci = env_int("PEA_FWD_CFG", kFwdDefault);
   if (ci < 0 || ci >= kNumFwdCfg) return false;
   TParams Q;
-  if (!plan_tiles(P, kFwdCfg[ci], false, &Q)) return false;
+  if (!plan_tiles(P, fwd_cfg<D_T>(ci), false, &Q)) return false;
   const bool self = (eo == e);
 #define PEA_FWD_CASE(CI)                                                                             \
   case CI:                                                                                           \
@@ -301,6 +307,8 @@ int launch_fwd(const KParams& P, const void* e, const void* eo, const float* t, 
     bool done = false;
     if (P.D == 16 && TRAIN) done = try_fwd_v<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
     if (!done && P.D == 16) done = try_fwd_tiled<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
+    if (P.D == 32 && TRAIN) done = try_fwd_v<T, 32, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
+    if (!done && P.D == 32) done = try_fwd_tiled<T, 32, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
     if (done) return hip_rc();
   }
   const size_t lds = TRAIN ? (size_t)P.K * kBlock * sizeof(float) : 0;
@@ -321,7 +329,7 @@ int launch_fwd(const KParams& P, const void* e, const void* eo, const float* t, 
 template <typename T, int D_T, bool RA, bool RB, int CI>
 void launch_bwd_cfg(const KParams& P, const TParams& Q, const T* x, const T* nb, const float* g, const float* dl, T* dx,
                     hipStream_t s) {
-  constexpr TileCfg c = kBwdCfg[CI];
+  constexpr TileCfg c = bwd_cfg<D_T>(CI);
   const size_t lds = Lds<D_T, c.PLQ>::kBytes;
   const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(c.TH * c.TW);
   if (P.border == PEA_BORDER_CIRCULAR) {
@@ -340,7 +348,7 @@ bool try_bwd_tiled(const KParams& P, const T* x, const T* nb, const float* g, co
   const int ci = env_int("PEA_BWD_CFG", kBwdDefault);
   if (ci < 0 || ci >= kNumBwdCfg) return false;
   TParams Q;
-  if (!plan_tiles(P, kBwdCfg[ci], true, &Q)) return false;
+  if (!plan_tiles(P, bwd_cfg<D_T>(ci), true, &Q)) return false;
 #define PEA_BWD_CASE(CI) \
   case CI: launch_bwd_cfg<T, D_T, RA, RB, CI>(P, Q, x, nb, g, dl, dx, s); break;
   switch (ci) { PEA_BWD_CASE(0) PEA_BWD_CASE(1) default: return false; }
@@ -389,12 +397,13 @@ bool try_bwd_phased(const KParams& P, int roles, const T* x, const T* nb, const 
 template <typename T, int D_T>
 int launch_bwd_roles(const KParams& P, int roles, const T* x, const T* nbA, const T* nbB, const float* g, const float* dl,
                      T* dx, hipStream_t s) {
-  if (D_T == 16 && env_int("PEA_FORCE_DIRECT", 0) == 0) {
-    bool done = try_bwd_phased<T, 16>(P, roles, x, roles == 2 ? nbB : nbA, g, dl, dx, s);
+  if ((D_T == 16 || D_T == 32) && env_int("PEA_FORCE_DIRECT", 0) == 0) {
+    constexpr int DT = D_T == 32 ? 32 : 16;
+    bool done = D_T == 16 && try_bwd_phased<T, 16>(P, roles, x, roles == 2 ? nbB : nbA, g, dl, dx, s);
     if (done) return hip_rc();
-    if (roles == 3) done = try_bwd_tiled<T, 16, true, true>(P, x, nbA, g, dl, dx, s);
-    else if (roles == 1) done = try_bwd_tiled<T, 16, true, false>(P, x, nbA, g, dl, dx, s);
-    else done = try_bwd_tiled<T, 16, false, true>(P, x, nbB, g, dl, dx, s);
+    if (roles == 3) done = try_bwd_tiled<T, DT, true, true>(P, x, nbA, g, dl, dx, s);
+    else if (roles == 1) done = try_bwd_tiled<T, DT, true, false>(P, x, nbA, g, dl, dx, s);
+    else done = try_bwd_tiled<T, DT, false, true>(P, x, nbB, g, dl, dx, s);
     if (done) return hip_rc();
   }
   const dim3 grid((unsigned)(P.tiles_per_xcd * kXcd)), blk(kBlock);

@@ -244,7 +244,7 @@ __device__ __forceinline__ void fwd_finish(const FwdU U, int K, float* s_part, c
 // forward, tiled.  SELF: e_other == e (own pixel comes out of LDS too).
 // ------------------------------------------------------------------------------------------------
 template <typename T, int D_T, int TH, int TW, int PLQ, bool CROP, bool TRAIN, bool SELF>
-__global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled(const KParams P, const TParams Q, const T* __restrict__ e,
+__global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled(const KParams P, const TParams Q, const T* __restrict__ e,
                                                          const T* __restrict__ eo, const float* __restrict__ target,
                                                          const float* __restrict__ weight,
                                                          const uint8_t* __restrict__ mask, float* __restrict__ affs,
@@ -420,7 +420,7 @@ __device__ __forceinline__ void bs128(rsrc_t r, f4 v, unsigned vo, unsigned so) 
 }
 
 template <typename T, int D_T, int TH, int TW, int PLQ, bool OVL, bool CROP, bool TRAIN, bool SELF>
-__global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled_v(const KParams P, const TParams Q, const T* __restrict__ e,
+__global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled_v(const KParams P, const TParams Q, const T* __restrict__ e,
                                                            const T* __restrict__ eo, const float* __restrict__ target,
                                                            const float* __restrict__ weight,
                                                            const uint8_t* __restrict__ mask, float* __restrict__ affs,
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_tiled_v(const KParams P, cons
 //   self loss: nb == x, both roles.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int D_T, int TH, int TW, int PLQ, bool CROP, bool ROLE_A, bool ROLE_B>
-__global__ __launch_bounds__(TH* TW, 4) void k_bwd_tiled(const KParams P, const TParams Q, const T* __restrict__ xt,
+__global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_bwd_tiled(const KParams P, const TParams Q, const T* __restrict__ xt,
                                                          const T* __restrict__ nbt, const float* __restrict__ gin,
                                                          const float* __restrict__ dloss, T* __restrict__ dx) {
   constexpr int NT = TH * TW;

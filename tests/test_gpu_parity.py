@@ -470,3 +470,29 @@ def test_fused_second_backward_over_retained_graph(pkg, dev, synth, monkeypatch)
     g1 = g1.clone()
     (g2,) = torch.autograd.grad(loss * 2.0, et)
     assert relmax(g2.cpu().numpy(), 2.0 * g1.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("ema", [False, True])
+def test_tiled_d32_vs_oracle(pkg, dev, orc, synth, ema):
+    """D = 32 (BBBC039V1 backbone) through the LDS-tiled kernels: 16x32 tiles, 128 B of LDS per
+    region pixel, shifts 1,3,5,9,11 (scripts_bbbc/config/bbbc039v1.yaml) on a shape wider than tile + halo"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 11], 4)
+    B, D, H, W = 2, 32, 72, 104
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 53)
+    other = synth.synth_embedding((B, D, H, W), 54) if ema else None
+    et = cu(e, dev).requires_grad_(True)
+    crit = pkg.WeightedMSE()
+    if ema:
+        loss, affs = pkg.ema_embedding_loss(et, cu(other, dev), cu(t, dev), cu(w, dev), cu(m, dev), crit, offsets)
+    else:
+        loss, affs, _ = pkg.embedding_loss(et, cu(t, dev), cu(w, dev), cu(m, dev), crit, offsets)
+    (loss * 1.5).backward()
+    d = orc.desc_2d(e, offsets)
+    o_affs, o_loss = orc.c_fwd(d, e, other, t, w, m)
+    o_grad, _ = orc.c_bwd(d, e, other, t, w, m, dloss=1.5)
+    assert np.abs(affs.cpu().numpy() - o_affs).max() < AFFS_ATOL
+    assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+    assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL
+    inf = pkg.embedding2affs(et.detach(), offsets) if not ema else None
+    if inf is not None:
+        assert np.abs(inf.cpu().numpy() - o_affs).max() < AFFS_ATOL
