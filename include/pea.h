@@ -146,6 +146,12 @@ int pea_affinity_fwd_bwd(const PeaDesc *desc, const void *e, const void *e_other
  * what a plain loss.backward() hands to the gradient pea_affinity_fwd_bwd produced for dloss = 1. */
 int pea_scale_inplace(void *buf, int dtype, size_t n, const float *scale, void *stream);
 
+/* Caller epilogue of the 3D path, in place on affs [B,K,Z,Y,X] (scripts_ac3ac4/main.py:233-237, 296-300;
+ * scripts_ac3ac4/inference.py:160-164): pred[:,0,:s] = pred[:,0,s:2s] (z), pred[:,1,:,:s] = pred[:,1,:,s:2s] (y),
+ * pred[:,2,:,:,:s] = pred[:,2,:,:,s:2s] (x) for s = shift (0 = skip), then F.relu when relu != 0.  Also the plain
+ * F.relu(pred) of the 2D callers (scripts_cvppp/main.py:312) with shift = 0. */
+int pea_fill_border_relu(float *affs, int B, int K, int Z, int Y, int X, int shift, int relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

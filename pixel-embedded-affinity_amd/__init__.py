@@ -17,10 +17,14 @@ from .loss.loss_embedding_mse import ema_embedding_loss, embedding2affs, embeddi
 from .loss.loss_embedding_mse_3d import (ema_embedding_loss_norm1, ema_embedding_loss_norm5, embedding_loss_norm1,
                                          embedding_loss_norm5, inf_embedding_loss_norm1, inf_embedding_loss_norm5)
 from .utils.affinity_ours import gen_offsets, multi_offset
+from .utils.postproc import fill_border_relu_, relu_
+from .harness.loss_section import (ac3ac4_loss_section, cvppp_loss_section, deep_weight_factor, finish_pred_2d_,
+                                   finish_pred_3d_)
 
 __all__ = [
     "PeaLibraryError", "build", "AffinityMap", "AffinitySpec", "FusedAffinityMSE", "affinity_infer", "WeightedMSE",
     "embedding_loss", "ema_embedding_loss", "embedding2affs", "embedding_loss_norm1", "embedding_loss_norm5",
     "ema_embedding_loss_norm1", "ema_embedding_loss_norm5", "inf_embedding_loss_norm1", "inf_embedding_loss_norm5",
-    "gen_offsets", "multi_offset",
+    "gen_offsets", "multi_offset", "fill_border_relu_", "relu_", "cvppp_loss_section", "ac3ac4_loss_section",
+    "deep_weight_factor", "finish_pred_2d_", "finish_pred_3d_",
 ]

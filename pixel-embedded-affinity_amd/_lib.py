@@ -23,7 +23,7 @@ NORM_BX, NORM_CROPPED, NORM_FULL = 0, 1, 2
 FLAG_RELU_AFFS = 1
 
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",
-           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_bwd", "pea_scale_inplace")
+           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_bwd", "pea_scale_inplace", "pea_fill_border_relu")
 
 
 class PeaLibraryError(RuntimeError):
@@ -99,6 +99,8 @@ def lib():
     L.pea_affinity_fwd_bwd.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.pea_scale_inplace.restype = ctypes.c_int
     L.pea_scale_inplace.argtypes = [vp, ctypes.c_int, ctypes.c_size_t, vp, vp]
+    L.pea_fill_border_relu.restype = ctypes.c_int
+    L.pea_fill_border_relu.argtypes = [vp] + [ctypes.c_int] * 7 + [vp]
     if L.pea_version() != PEA_ABI_VERSION:
         raise PeaLibraryError("ABI mismatch: library %d, binding %d" % (L.pea_version(), PEA_ABI_VERSION))
     _lib = L

@@ -469,6 +469,27 @@ __global__ __launch_bounds__(256) void k_scale_inplace(T* __restrict__ buf, size
   }
 }
 
+// Caller epilogue of the 3D path (scripts_ac3ac4/main.py:233-237,296-300; inference.py:160-164): for c in {0,1,2} the
+// first `shift` slices of affs[:, c] along axis c (z, y, x) are overwritten with slices shift .. 2*shift-1, then relu.
+__global__ __launch_bounds__(256) void k_fill_border_relu(float* __restrict__ affs, int B, int K, int Z, int Y, int X, int shift,
+                                                          int relu) {
+  const size_t S = (size_t)Z * Y * X, n = (size_t)B * K * S;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)((i / S) % (size_t)K);
+  const size_t p = i % S;
+  const int z = (int)(p / ((size_t)Y * X)), y = (int)((p / X) % Y), x = (int)(p % X);
+  size_t src = i;
+  if (shift > 0 && c < 3) {
+    const int a = c == 0 ? z : c == 1 ? y : x;
+    const size_t stride = c == 0 ? (size_t)Y * X : c == 1 ? (size_t)X : 1;
+    if (a < shift) src = i + (size_t)shift * stride;  // pred[..., :shift] = pred[..., shift:2*shift]
+  }
+  float v = affs[src];
+  if (relu) v = fmaxf(v, 0.f);
+  if (src != i || relu) affs[i] = v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -606,6 +627,18 @@ int pea_scale_inplace(void* buf, int dtype, size_t n, const float* scale, void* 
   if (blocks > 0x7fffffffULL) return PEA_E_UNSUPPORTED;
   if (dtype == PEA_F32) hipLaunchKernelGGL(k_scale_inplace<float>, dim3((unsigned)blocks), dim3(256), 0, s, (float*)buf, n4, n, scale);
   else hipLaunchKernelGGL(k_scale_inplace<__half>, dim3((unsigned)blocks), dim3(256), 0, s, (__half*)buf, n4, n, scale);
+  return hip_rc();
+}
+
+int pea_fill_border_relu(float* affs, int B, int K, int Z, int Y, int X, int shift, int relu, void* stream) {
+  if (!affs) return PEA_E_NULL;
+  if (B < 1 || K < 1 || Z < 1 || Y < 1 || X < 1 || shift < 0) return PEA_E_DESC;
+  if (shift > 0 && K >= 3 && (2 * shift > Z || 2 * shift > Y || 2 * shift > X)) return PEA_E_DESC;
+  if (misaligned(affs, 4)) return PEA_E_ALIGN;
+  const size_t n = (size_t)B * K * Z * Y * X, blocks = (n + 255) / 256;
+  if (blocks > 0x7fffffffULL) return PEA_E_UNSUPPORTED;
+  // source slices [shift, 2*shift) are never themselves rewritten (relu is idempotent), so in place is race-free
+  hipLaunchKernelGGL(k_fill_border_relu, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, affs, B, K, Z, Y, X, shift, relu);
   return hip_rc();
 }
 

@@ -496,3 +496,108 @@ def test_tiled_d32_vs_oracle(pkg, dev, orc, synth, ema):
     inf = pkg.embedding2affs(et.detach(), offsets) if not ema else None
     if inf is not None:
         assert np.abs(inf.cpu().numpy() - o_affs).max() < AFFS_ATOL
+
+
+def test_fill_border_relu_matches_reference_statements(pkg, dev):
+    """scripts_ac3ac4/main.py:233-237 verbatim in torch against pea_fill_border_relu (in place, one launch)"""
+    torch.manual_seed(3)
+    pred = torch.randn(2, 12, 6, 20, 24, device=dev)
+    ref = pred.clone()
+    shift = 1
+    ref[:, 1, :, :shift, :] = ref[:, 1, :, shift:shift * 2, :]
+    ref[:, 2, :, :, :shift] = ref[:, 2, :, :, shift:shift * 2]
+    ref[:, 0, :shift, :, :] = ref[:, 0, shift:shift * 2, :, :]
+    ref = torch.nn.functional.relu(ref)
+    out = pkg.fill_border_relu_(pred, shift=1, relu=True)
+    assert out is pred and torch.equal(pred, ref)
+    p2 = torch.randn(2, 10, 40, 48, device=dev)
+    r2 = torch.nn.functional.relu(p2)
+    assert torch.equal(pkg.relu_(p2), r2)
+    with pytest.raises(RuntimeError):
+        pkg.relu_(torch.zeros(1, 2, 4, 4))
+
+
+def _section_inputs(synth, offsets, nb_half, B, D, H, W, seed):
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, seed)
+    ema = synth.synth_embedding((B, D, H, W), seed + 1)
+    emds, downs = [], []
+    for j in range(4):
+        k = nb_half * (4 - j)
+        h, ww = H >> (j + 1), W >> (j + 1)
+        ej, tj, wj, mj = synth.synth_inputs_2d(B, D, h, ww, offsets[:k], seed + 2 + j)
+        emds.append(ej)
+        downs.append(np.concatenate([tj, wj, mj.astype(np.float32)], axis=1))  # packed thirds, mask as float like the reference
+    return e, ema, t, w, m, emds, downs
+
+
+def test_cvppp_loss_section_matches_oracle(pkg, dev, orc, synth):
+    """the six calls of scripts_cvppp/main.py:284-293 with their slicing and weighting, against the oracle per call"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    nb_half, B, D, H, W = 2, 2, 16, 96, 96
+    e, ema, t, w, m, emds, downs = _section_inputs(synth, offsets, nb_half, B, D, H, W, 61)
+    et = cu(e, dev).requires_grad_(True)
+    emd_t = [cu(x, dev).requires_grad_(True) for x in emds]
+    down_t = [cu(x, dev) for x in downs]
+    loss, pred, parts = pkg.cvppp_loss_section(et, emd_t, cu(ema, dev), cu(t, dev), cu(w, dev), cu(m, dev), down_t,
+                                               pkg.WeightedMSE(), offsets, nb_half, deep_weight=2, self_emb=0.7, cross_emb=1.3)
+    loss.backward()
+    pkg.finish_pred_2d_(pred)
+    dwf = pkg.deep_weight_factor(2)
+    d = orc.desc_2d(e, offsets)
+    a_self, l_self = orc.c_fwd(d, e, None, t, w, m)
+    _, l_cross = orc.c_fwd(d, e, ema, t, w, m)
+    g_self, _ = orc.c_bwd(d, e, None, t, w, m, dloss=dwf[0] * 0.7)
+    g_cross, _ = orc.c_bwd(d, e, ema, t, w, m, dloss=dwf[0] * 1.3)
+    want = dwf[0] * 0.7 * l_self[0] + dwf[0] * 1.3 * l_cross[0]
+    for j in range(4):
+        k = nb_half * (4 - j)
+        dj = orc.desc_2d(emds[j], offsets[:k])
+        tj, wj, mj = downs[j][:, :k], downs[j][:, k:2 * k], downs[j][:, 2 * k:].astype(np.uint8)
+        _, lj = orc.c_fwd(dj, emds[j], None, np.ascontiguousarray(tj), np.ascontiguousarray(wj), np.ascontiguousarray(mj))
+        gj, _ = orc.c_bwd(dj, emds[j], None, np.ascontiguousarray(tj), np.ascontiguousarray(wj), np.ascontiguousarray(mj),
+                          dloss=dwf[j + 1] * 0.7)
+        want += dwf[j + 1] * 0.7 * lj[0]
+        assert relmax(emd_t[j].grad.cpu().numpy(), gj) < GRAD_RTOL
+    assert abs(loss.item() - want) <= LOSS_RTOL * want
+    assert relmax(et.grad.cpu().numpy(), g_self + g_cross) < GRAD_RTOL
+    assert np.abs(pred.cpu().numpy() - np.maximum(a_self, 0)).max() < AFFS_ATOL
+
+
+def test_loss_section_graph_replay(pkg, dev, synth):
+    """no host synchronisation inside the loss section: capture it (forward + backward) in a HIP graph, replay it on
+    new data in the same buffers, compare with an eager run"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    nb_half, B, D, H, W = 2, 2, 16, 96, 96
+    crit = pkg.WeightedMSE()
+
+    def tensors(seed):
+        e, ema, t, w, m, emds, downs = _section_inputs(synth, offsets, nb_half, B, D, H, W, seed)
+        return [cu(e, dev)] + [cu(x, dev) for x in emds] + [cu(ema, dev), cu(t, dev), cu(w, dev), cu(m, dev)] + [cu(x, dev) for x in downs]
+
+    def section(bufs):
+        et = bufs[0].detach().requires_grad_(True)
+        emd_t = [b.detach().requires_grad_(True) for b in bufs[1:5]]
+        loss, pred, _ = pkg.cvppp_loss_section(et, emd_t, bufs[5], bufs[6], bufs[7], bufs[8], bufs[9:13], crit, offsets, nb_half)
+        grads = torch.autograd.grad(loss, [et] + emd_t)
+        return loss, pred, grads
+
+    static = tensors(71)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            section(static)  # warm-up: kernel attributes, plan cache, allocator pools
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        g_loss, g_pred, g_grads = section(static)
+    fresh = tensors(73)
+    for dst, src in zip(static, fresh):
+        dst.copy_(src)
+    graph.replay()
+    torch.cuda.synchronize()
+    e_loss, e_pred, e_grads = section(fresh)
+    assert abs(g_loss.item() - e_loss.item()) <= 1e-6 * abs(e_loss.item())
+    assert torch.equal(g_pred, e_pred)
+    for a, b in zip(g_grads, e_grads):
+        assert torch.equal(a, b)
