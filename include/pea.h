@@ -152,6 +152,22 @@ int pea_scale_inplace(void *buf, int dtype, size_t n, const float *scale, void *
  * F.relu(pred) of the 2D callers (scripts_cvppp/main.py:312) with shift = 0. */
 int pea_fill_border_relu(float *affs, int B, int K, int Z, int Y, int X, int shift, int relu, void *stream);
 
+/* ---- the step feeding the path: label image -> target / mask / class-balance weight ----
+ * Replaces, per batch, gen_affs_ours(labels, offsets, ignore=False, padding=...) and the per-channel
+ * weight_binary_ratio(lb_affs[i]) of the reference's data providers (scripts_cvppp/utils/affinity_ours.py:17-39,
+ * scripts_cvppp/data/data_segmentation.py:205-228, called at scripts_cvppp/data/data_provider.py:204-225).
+ *   labels [B,Z,Y,X] int32 (0 = background);  uses desc->B, dims, K, offsets only
+ *   target [B,K,Z,Y,X] f32 = 1 iff label(p) == label(p + o_i)  (PEA_TGT_BOTH_FOREGROUND: and both > 0, seg_to_aff,
+ *          scripts_ac3ac4/data/data_affinity.py:53-102); neighbour outside: PEA_TGT_PADDING ? 1 : 0
+ *   mask   [B,K,Z,Y,X] u8  = 1 iff p + o_i lies inside the image (nullable)
+ *   weight [B,K,Z,Y,X] f32 = class balance per (b, channel) (nullable)
+ * workspace: pea_targets_workspace_bytes(desc) bytes (integer counts; zeroed by the call). */
+#define PEA_TGT_PADDING 1u
+#define PEA_TGT_BOTH_FOREGROUND 2u
+size_t pea_targets_workspace_bytes(const PeaDesc *desc);
+int pea_gen_targets(const PeaDesc *desc, const int32_t *labels, unsigned flags, float *target, uint8_t *mask,
+                    float *weight, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -283,3 +283,61 @@ def torch_embedding_loss_3d(e, target, weight, shifts, ema=None, affs0_weight=1,
             loss = loss + torch_weighted_mse(a, t, w) * (affs0_weight if i < first else 1.0)
         affs[:, i:i + 1].narrow(ax, s, n - s).copy_(a.detach())
     return loss, affs
+
+
+# ---------------------------------------------------------------------------------------------------
+# label image -> target / mask / class-balance weight  (the checker of pea_gen_targets; test infrastructure)
+# ---------------------------------------------------------------------------------------------------
+def np_gen_targets(labels, offsets, padding=True, both_foreground=False):
+    """labels [B,Z,Y,X] int -> target f32 [B,K,Z,Y,X], mask u8 [B,K,Z,Y,X].
+
+    Follows gen_affs_ours(labels, offsets, ignore=False, padding=...) (scripts_cvppp/utils/affinity_ours.py:17-39):
+    shifted = scipy shift(labels, -off, order=0) = labels(p + off), zero outside; t = 1 iff labels == shifted;
+    where the neighbour is outside the image mask = 0 and t = 1 (padding) or 0.  both_foreground: t = 1 only if both
+    labels are > 0 (seg_to_aff, scripts_ac3ac4/data/data_affinity.py:53-102, interior).  Pinned by
+    tests/golden/gtgt_*.npz, which hold the reference's own outputs."""
+    labels = np.asarray(labels)
+    B, Z, Y, X = labels.shape
+    offs = offsets3(offsets)
+    t = np.zeros((B, len(offs), Z, Y, X), np.float32)
+    m = np.zeros((B, len(offs), Z, Y, X), np.uint8)
+    for i, (dz, dy, dx) in enumerate(offs):
+        for z in range(Z):
+            zz = z + dz
+            for y in range(Y):
+                yy = y + dy
+                inside_zy = 0 <= zz < Z and 0 <= yy < Y
+                for x in range(X):
+                    xx = x + dx
+                    if inside_zy and 0 <= xx < X:
+                        a, b = labels[:, z, y, x], labels[:, zz, yy, xx]
+                        eq = a == b
+                        if both_foreground:
+                            eq = eq & (a > 0) & (b > 0)
+                        t[:, i, z, y, x] = eq
+                        m[:, i, z, y, x] = 1
+                    else:
+                        t[:, i, z, y, x] = 1.0 if padding else 0.0
+    return t, m
+
+
+def np_weight_binary_ratio(target, alpha=1.0):
+    """per (b, channel) weight_binary_ratio(lb_affs[i]) with mask=None
+    (scripts_cvppp/data/data_segmentation.py:205-228, called per channel at data_provider.py:216-225): uniform 1 for a
+    single-valued channel; else f = clip(mean(label != 0), 0.05, 0.99), the minority class gets max(f,1-f)/min(f,1-f),
+    the majority 1; float64 arithmetic, float32 result."""
+    target = np.asarray(target)
+    w = np.ones(target.shape, np.float32)
+    for b in range(target.shape[0]):
+        for i in range(target.shape[1]):
+            lab = target[b, i]
+            if lab.max() == lab.min():
+                continue
+            lab = (lab != 0).astype(int)
+            f = float(lab.sum()) / np.prod(lab.shape)
+            f = np.clip(f, 5e-2, 0.99)
+            if f > 0.5:
+                w[b, i] = (lab + alpha * f / (1 - f) * (1 - lab)).astype(np.float32)
+            else:
+                w[b, i] = (alpha * (1 - f) / f * lab + (1 - lab)).astype(np.float32)
+    return w

@@ -21,9 +21,11 @@ BORDER_CIRCULAR, BORDER_CROP_ZERO = 0, 1
 F32, F16 = 0, 1
 NORM_BX, NORM_CROPPED, NORM_FULL = 0, 1, 2
 FLAG_RELU_AFFS = 1
+TGT_PADDING, TGT_BOTH_FOREGROUND = 1, 2
 
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",
-           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_bwd", "pea_scale_inplace", "pea_fill_border_relu")
+           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_bwd", "pea_scale_inplace", "pea_fill_border_relu",
+           "pea_targets_workspace_bytes", "pea_gen_targets")
 
 
 class PeaLibraryError(RuntimeError):
@@ -99,6 +101,10 @@ def lib():
     L.pea_affinity_fwd_bwd.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.pea_scale_inplace.restype = ctypes.c_int
     L.pea_scale_inplace.argtypes = [vp, ctypes.c_int, ctypes.c_size_t, vp, vp]
+    L.pea_targets_workspace_bytes.restype = ctypes.c_size_t
+    L.pea_targets_workspace_bytes.argtypes = [dp]
+    L.pea_gen_targets.restype = ctypes.c_int
+    L.pea_gen_targets.argtypes = [dp, vp, ctypes.c_uint, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.pea_fill_border_relu.restype = ctypes.c_int
     L.pea_fill_border_relu.argtypes = [vp] + [ctypes.c_int] * 7 + [vp]
     if L.pea_version() != PEA_ABI_VERSION:

@@ -25,6 +25,7 @@
 #include "pea_tiled.h"
 #include "pea_phased.h"
 #include "pea_fused.h"
+#include "pea_targets.h"
 #include "pea_plan.h"
 
 using namespace pea;
@@ -639,6 +640,36 @@ int pea_fill_border_relu(float* affs, int B, int K, int Z, int Y, int X, int shi
   if (blocks > 0x7fffffffULL) return PEA_E_UNSUPPORTED;
   // source slices [shift, 2*shift) are never themselves rewritten (relu is idempotent), so in place is race-free
   hipLaunchKernelGGL(k_fill_border_relu, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, affs, B, K, Z, Y, X, shift, relu);
+  return hip_rc();
+}
+
+size_t pea_targets_workspace_bytes(const PeaDesc* desc) {
+  if (validate(desc)) return 0;
+  return (size_t)desc->B * desc->K * sizeof(unsigned);
+}
+
+int pea_gen_targets(const PeaDesc* desc, const int32_t* labels, unsigned flags, float* target, uint8_t* mask, float* weight,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  const int rc = validate(desc);
+  if (rc) return rc;
+  if (!labels || !target) return PEA_E_NULL;
+  if (misaligned(labels, 4) || misaligned(target, 4) || misaligned(weight, 4) || misaligned(workspace, 4)) return PEA_E_ALIGN;
+  if (flags & ~(PEA_TGT_PADDING | PEA_TGT_BOTH_FOREGROUND)) return PEA_E_DESC;
+  const size_t need = (size_t)desc->B * desc->K * sizeof(unsigned);
+  if (!workspace || workspace_bytes < need) return PEA_E_WORKSPACE;
+  GParams G;
+  G.B = desc->B; G.Z = desc->dims[0]; G.Y = desc->dims[1]; G.X = desc->dims[2]; G.K = desc->K;
+  G.S = G.Z * G.Y * G.X;
+  G.flags = flags;
+  for (int i = 0; i < PEA_MAX_K; ++i)
+    for (int a = 0; a < 3; ++a) G.off[i][a] = i < desc->K ? desc->offsets[i][a] : 0;
+  if (desc->B > 65535 || (long long)desc->B * desc->K > 65535) return PEA_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, need, s) != hipSuccess) return hip_rc();
+  const unsigned chunks = (unsigned)((G.S + 255) / 256);
+  hipLaunchKernelGGL(k_gen_targets, dim3(chunks, (unsigned)G.B), dim3(256), 0, s, G, labels, target, mask, (unsigned*)workspace);
+  if (weight)
+    hipLaunchKernelGGL(k_gen_weights, dim3(chunks, (unsigned)(G.B * G.K)), dim3(256), 0, s, G, target, (const unsigned*)workspace, weight);
   return hip_rc();
 }
 

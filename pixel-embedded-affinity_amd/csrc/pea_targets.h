@@ -1,0 +1,76 @@
+// pea_targets.h -- label image -> target / mask / class-balance weight on the GPU.
+//
+// What the reference's data providers compute per sample in DataLoader workers with scipy.ndimage.shift and numpy
+// (scripts_cvppp/data/data_provider.py:204-225 -> utils/affinity_ours.py:17-39 gen_affs_ours and
+// data/data_segmentation.py:205-228 weight_binary_ratio), then ship to the GPU as ~40 MB of f32 per 544^2 sample.
+// From an int32 label image it is a trivially parallel integer stencil plus one count per (sample, channel):
+//   t_i(p) = [label(p) == label(p + o_i)]  (and both > 0 with PEA_TGT_BOTH_FOREGROUND: seg_to_aff);
+//   a neighbour outside the image: mask = 0 and t = 1 (PEA_TGT_PADDING) or 0;
+//   f_i = clip(count(t_i != 0) / (Z*Y*X), 0.05, 0.99); the minority class gets max(f,1-f)/min(f,1-f), the majority 1;
+//   a single-valued channel gets weight 1 everywhere.
+// Integer counts (one u32 atomic per workgroup and channel): bit-reproducible.  The ratio is evaluated in f64 like
+// numpy does and rounded to f32 once.
+#pragma once
+#include "pea_direct.h"
+
+namespace pea {
+
+struct GParams {
+  int B, Z, Y, X, K, S;
+  unsigned flags;
+  int off[PEA_MAX_K][3];
+};
+
+__global__ __launch_bounds__(256) void k_gen_targets(const GParams G, const int32_t* __restrict__ labels,
+                                                     float* __restrict__ target, uint8_t* __restrict__ mask,
+                                                     unsigned* __restrict__ counts) {
+  __shared__ unsigned s_cnt[PEA_MAX_K];
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x < PEA_MAX_K) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const bool live = p < G.S;
+  const int yx = G.Y * G.X;
+  const int z = live ? p / yx : 0, r = live ? p - z * yx : 0, y = r / G.X, x = r - y * G.X;
+  const int32_t* lb = labels + (size_t)b * G.S;
+  const int a = live ? lb[p] : 0;
+  const bool pad = G.flags & PEA_TGT_PADDING, fg = G.flags & PEA_TGT_BOTH_FOREGROUND;
+  for (int i = 0; i < G.K; ++i) {
+    const int zz = z + G.off[i][0], yy = y + G.off[i][1], xx = x + G.off[i][2];
+    const bool inside = live && (unsigned)zz < (unsigned)G.Z && (unsigned)yy < (unsigned)G.Y && (unsigned)xx < (unsigned)G.X;
+    bool t = pad;
+    if (inside) {
+      const int nb = lb[(zz * G.Y + yy) * G.X + xx];
+      t = a == nb && (!fg || (a > 0 && nb > 0));
+    }
+    if (live) {
+      const size_t o = ((size_t)b * G.K + i) * G.S + p;
+      target[o] = t ? 1.f : 0.f;
+      if (mask) mask[o] = inside ? 1 : 0;
+    }
+    const unsigned long long bal = __ballot(live && t);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt[i], (unsigned)__popcll(bal));
+  }
+  __syncthreads();
+  if (threadIdx.x < G.K && s_cnt[threadIdx.x]) atomicAdd(&counts[b * G.K + threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_gen_weights(const GParams G, const float* __restrict__ target,
+                                                     const unsigned* __restrict__ counts, float* __restrict__ weight) {
+  const int bi = blockIdx.y;  // b * K + i
+  const unsigned n = counts[bi];
+  float wpos = 1.f, wneg = 1.f;
+  if (n != 0 && n != (unsigned)G.S) {
+    double f = (double)n / (double)G.S;
+    f = fmin(fmax(f, 5e-2), 0.99);
+    if (f > 0.5) wneg = (float)(f / (1.0 - f));
+    else wpos = (float)((1.0 - f) / f);
+  }
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < G.S) {
+    const size_t o = (size_t)bi * G.S + p;
+    weight[o] = target[o] != 0.f ? wpos : wneg;
+  }
+}
+
+}  // namespace pea

@@ -82,6 +82,28 @@ def targets_2d(rng, B, H, W, offsets):
     return t, w, m
 
 
+def case_targets(name, seed, B, H, W, shifts, nb):
+    """label image -> what the data provider feeds the loss (scripts_cvppp/data/data_provider.py:204-225):
+    gen_affs_ours(ignore=False) run by the reference itself for padding=True and padding=False, plus the
+    per-channel class-balance weights (weight_binary_ratio, restated above: its module needs skimage)."""
+    rng = np.random.default_rng(seed)
+    offsets = refaff.multi_offset(shifts, neighbor=nb)
+    labels = np.stack([blocky_labels(rng, H, W, cell=6, n=9) for _ in range(B)])
+    labels[-1, : H // 3] = 0  # a large background area and, below, one uniform channel (weights all 1)
+    out = {}
+    for padding in (True, False):
+        t = np.zeros((B, len(offsets), H, W), np.float32)
+        m = np.zeros((B, len(offsets), H, W), np.uint8)
+        w = np.zeros((B, len(offsets), H, W), np.float32)
+        for b in range(B):
+            t[b], m[b] = refaff.gen_affs_ours(labels[b], offsets, ignore=False, padding=padding)
+            for i in range(len(offsets)):
+                w[b, i] = weight_binary_ratio(t[b, i])
+        tag = "pad" if padding else "nopad"
+        out["target_" + tag], out["mask_" + tag], out["weight_" + tag] = t, m, w
+    save(name, labels=labels.astype(np.int32), offsets=np.asarray(offsets, np.int32), **out)
+
+
 def T(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
@@ -189,6 +211,10 @@ def synth_full(B, D, H, W, K, seed):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "targets":  # only the label -> target / mask / weight fixtures
+        case_targets("gtgt_2d_nb4", 41, B=2, H=45, W=52, shifts=[1, 3, 5, 9, 27], nb=4)
+        case_targets("gtgt_2d_nb8", 42, B=1, H=31, W=40, shifts=[1, 3, 9], nb=8)
+        sys.exit(0)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     # 2D, shipped CVPPP stencil (shifts 1,3,5,9,27 x neighbor 4 -> K=10), ragged sizes
@@ -212,5 +238,7 @@ if __name__ == "__main__":
     case_3d("g3d_norm5_w", 24, B=2, D=16, Z=5, Y=29, X=28, which="norm5", affs0_weight=2)
     case_3d("g3d_norm1_ema", 25, B=1, D=16, Z=6, Y=20, X=24, which="norm1", ema=True)
     case_3d("g3d_norm5_ema", 26, B=1, D=16, Z=6, Y=30, X=31, which="norm5", affs0_weight=2, ema=True)
+    case_targets("gtgt_2d_nb4", 41, B=2, H=45, W=52, shifts=[1, 3, 5, 9, 27], nb=4)
+    case_targets("gtgt_2d_nb8", 42, B=1, H=31, W=40, shifts=[1, 3, 9], nb=8)
     # full CVPPP size, summary only
     case_full_summary("g2d_full544_summary", 555, B=2, D=16, H=544, W=544)

@@ -601,3 +601,38 @@ def test_loss_section_graph_replay(pkg, dev, synth):
     assert torch.equal(g_pred, e_pred)
     for a, b in zip(g_grads, e_grads):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["gtgt_2d_nb4", "gtgt_2d_nb8"])
+def test_gpu_target_generation_matches_reference_golden(pkg, dev, name):
+    """pea_gen_targets against the reference's gen_affs_ours outputs (and the restated weight_binary_ratio): bit-exact"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    lab = torch.from_numpy(g["labels"]).to(dev)
+    offs = [list(o) for o in g["offsets"]]
+    for padding, tag in ((True, "pad"), (False, "nopad")):
+        t, m, w = pkg.gen_targets(lab, offs, padding=padding)
+        assert np.array_equal(t.cpu().numpy(), g["target_" + tag])
+        assert np.array_equal(m.cpu().numpy(), g["mask_" + tag])
+        assert np.array_equal(w.cpu().numpy(), g["weight_" + tag])
+    t2, m2 = pkg.gen_affs_ours(lab, offs, padding=True)
+    assert np.array_equal(t2.cpu().numpy(), g["target_pad"]) and np.array_equal(m2.cpu().numpy(), g["mask_pad"])
+
+
+def test_gpu_target_generation_3d_and_full_size(pkg, dev, orc, synth):
+    """3D both-foreground targets (seg_to_aff semantics) against the oracle on a small volume, and the CVPPP bench
+    size against the host generator bench.py feeds the loss with (synth.affinity_targets / class_balance_weights)"""
+    offs3 = orc.norm_offsets([1, 1, 1, 2, 3, 3, 3, 9, 9, 4])
+    lab = synth.synth_labels(2, (7, 21, 26), 77, cell=5)
+    o_t, o_m = orc.np_gen_targets(lab, offs3, padding=False, both_foreground=True)
+    t, m, w = pkg.gen_targets(torch.from_numpy(lab).to(dev), offs3, padding=False, both_foreground=True)
+    assert np.array_equal(t.cpu().numpy(), o_t) and np.array_equal(m.cpu().numpy(), o_m)
+    assert np.array_equal(w.cpu().numpy(), orc.np_weight_binary_ratio(o_t.reshape(2, len(offs3), -1)).reshape(o_t.shape))
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    B, H, W = 4, 544, 544
+    labf = synth.synth_labels(B, (1, H, W), 555)
+    ht, hm = synth.affinity_targets(labf, [[0] + list(o) for o in offsets], padding=True)
+    hw = synth.class_balance_weights(ht)
+    t, m, w = pkg.gen_targets(torch.from_numpy(labf[:, 0]).to(dev), offsets, padding=True)
+    assert np.array_equal(t.cpu().numpy(), ht[:, :, 0]) and np.array_equal(m.cpu().numpy(), hm[:, :, 0])
+    assert np.array_equal(w.cpu().numpy(), hw[:, :, 0])

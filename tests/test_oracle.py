@@ -1,4 +1,6 @@
 """CPU: pin the oracle (C, numpy and torch restatements) against the reference's golden vectors."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -126,3 +128,18 @@ def test_full_size_summary_fixture_against_oracle(orc, pkg):
     assert abs(affs.astype(np.float64).sum() - float(g["affs_sum"])) < 1e-6 * affs.size ** 0.5 * 10
     de, _ = orc.c_bwd(d, e, None, t, w, m)
     assert np.abs(de.reshape(-1)[g["grad_idx"]] - g["grad_val"]).max() <= 2e-5 * np.abs(g["grad_val"]).max()
+
+
+@pytest.mark.parametrize("name", ["gtgt_2d_nb4", "gtgt_2d_nb8"])
+def test_target_generation_restatement_matches_reference(name):
+    """oracle np_gen_targets / np_weight_binary_ratio against what the reference's gen_affs_ours produced
+    (tests/golden/make_golden.py::case_targets): bit-exact (integer / byte work)"""
+    import oracle.pea_oracle as orc
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    lab = g["labels"][:, None]
+    offs = [list(o) for o in g["offsets"]]
+    for padding, tag in ((True, "pad"), (False, "nopad")):
+        t, m = orc.np_gen_targets(lab, offs, padding=padding)
+        assert np.array_equal(t[:, :, 0], g["target_" + tag])
+        assert np.array_equal(m[:, :, 0], g["mask_" + tag])
+        assert np.array_equal(orc.np_weight_binary_ratio(t[:, :, 0]), g["weight_" + tag])
