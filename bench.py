@@ -159,8 +159,10 @@ def main():
         fwd = lambda: L.pea_affinity_fwd(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(affs), P(G), P(lossv), P(work), wsb, st)
         bwd = lambda: L.pea_affinity_bwd(ctypes.byref(desc), P(Ed), None, P(G), P(one), P(dE), None, st)
         inf = lambda: L.pea_affinity_infer(ctypes.byref(desc), P(Ed), None, P(affs), st)
+        # the opt-in one-launch step (PEA_FUSED=1), timed beside the default two launches for the record
+        fused = lambda: L.pea_affinity_fwd_bwd(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(affs), P(lossv), None, P(dE), P(work), wsb, st)
         kt = {}
-        for name, fn in (("fwd", fwd), ("bwd", bwd), ("infer", inf)):
+        for name, fn in (("fwd", fwd), ("bwd", bwd), ("infer", inf), ("fused_fwd_bwd", fused)):
             event_time_ms(fn, 10)
             kt[name] = event_time_ms(fn, max(20, min(args.steps, 200)))
         ab = algorithmic_bytes_per_px(D, K)
