@@ -169,6 +169,7 @@ bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, TParams* Q) {
     q.dr = NT / q.RW;
     q.dc = NT % q.RW;
     q.inv_rw = 1.0f / (float)q.RW;
+    q.inv_sw = 1.0f / (float)std::max(1, q.hx0 + q.hx1);
     q.inv_eps = 1.0f / P.eps;
     q.tiles_y = (P.Y + c.TH - 1) / c.TH;
     q.tiles_x = (P.X + c.TW - 1) / c.TW;

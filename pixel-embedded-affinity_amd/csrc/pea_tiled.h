@@ -48,6 +48,7 @@ struct TParams {
   int RH, RW, R;           // staged region (rows, columns, pixels)
   int dr, dc;              // NT / RW, NT % RW: (row, col) advance of one staging step
   float inv_rw;            // 1 / RW
+  float inv_sw;            // 1 / (hx0 + hx1): halo strip width of the tile's rows (stage_region_own)
   float inv_eps;           // 1 / eps
   int tiles_y, tiles_x, tiles_per_plane;
   int ntiles, tiles_per_xcd;
@@ -188,6 +189,51 @@ __device__ __forceinline__ void stage_region(const KParams& P, const TParams& Q,
     r += Q.dr;
     c += Q.dc;
     if (c >= Q.RW) { c -= Q.RW; r += 1; }
+  }
+}
+
+// stage_region for the self-loss backward: every lane first stages ITS OWN tile pixel (keeping the raw channels and
+// 1 / norm in registers: the 16 separate own-pixel loads disappear), then the lanes share the halo pixels.
+// Halo enumeration: rows above the tile, rows below it, then the left / right strips of the tile's rows.
+template <typename T, int D_T, int PLQ, int TH, int TW, bool CROP>
+__device__ __forceinline__ void stage_region_own(const KParams& P, const TParams& Q, rsrc_t eb, unsigned zo, unsigned cs,
+                                                 int y0, int x0, char* __restrict__ lds, int ly, int lx, float* own,
+                                                 float& own_inv, float& own_ss) {
+  typedef Lds<D_T, PLQ> L;
+  constexpr int NT = TH * TW;
+  const int top = Q.hy0 * Q.RW, bot = Q.hy1 * Q.RW, sw = Q.hx0 + Q.hx1;
+  const int nhalo = top + bot + TH * sw;
+  for (int j = -NT + (int)threadIdx.x; j < nhalo; j += NT) {  // first trip (j < 0): the own pixel
+    int r, c;
+    if (j < 0) { r = ly + Q.hy0; c = lx + Q.hx0; }
+    else if (j < top) { r = (int)(((float)j + 0.5f) * Q.inv_rw); c = j - r * Q.RW; }
+    else if (j < top + bot) { const int k = j - top; const int rr = (int)(((float)k + 0.5f) * Q.inv_rw); r = Q.hy0 + TH + rr; c = k - rr * Q.RW; }
+    else { const int k = j - top - bot; const int rr = (int)(((float)k + 0.5f) * Q.inv_sw); const int cc = k - rr * sw; r = Q.hy0 + rr; c = cc < Q.hx0 ? cc : cc + TW; }
+    bool oky, okx;
+    const int gy = wrap1<CROP>(y0 - Q.hy0 + r, P.Y, oky);
+    const int gx = wrap1<CROP>(x0 - Q.hx0 + c, P.X, okx);
+    const unsigned vo = (oky && okx) ? (unsigned)(gy * P.X + gx) * (unsigned)sizeof(T) : kOOB;  // outside => zeros
+    float v[D_T];
+    float ss = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < D_T; ++ch) {
+      v[ch] = bl_emb<T>(eb, vo, zo + ch * cs);
+      ss = fmaf(v[ch], v[ch], ss);
+    }
+    const float inv = rnorm(ss, Q.inv_eps);
+    if (j < 0) {
+      own_inv = inv;
+      own_ss = ss;
+#pragma unroll
+      for (int ch = 0; ch < D_T; ++ch) own[ch] = v[ch] * inv;
+    }
+    char* dst = lds + (r * Q.RW + c) * 16;
+#pragma unroll
+    for (int q = 0; q < L::S; ++q) {
+      f4 t;
+      t.x = v[4 * q] * inv; t.y = v[4 * q + 1] * inv; t.z = v[4 * q + 2] * inv; t.w = v[4 * q + 3] * inv;
+      *(f4*)(dst + q * L::kPlaneB) = t;
+    }
   }
 }
 
@@ -676,14 +722,20 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_bwd_tiled(const 
   }
 
   // (1) own raw pixel and the g values of the first near chunk: in flight during staging
+  // self loss (both roles, x == nb): the lane stages its own pixel itself, so x needs no loads of its own
+  constexpr bool OWN_STAGED = ROLE_A && ROLE_B;
   float xh[D_T];
+  if (!OWN_STAGED) {
 #pragma unroll
-  for (int c = 0; c < D_T; ++c) xh[c] = bl_emb<T>(xB, pe, ezo + c * ecs);
+    for (int c = 0; c < D_T; ++c) xh[c] = bl_emb<T>(xB, pe, ezo + c * ecs);
+  }
   float gn[KN][NR];
   if (Q.n_near > 0) PEA_BWD_LOAD_GN(0)
 
   // (2) stage
-  stage_region<T, D_T, PLQ, NT, CROP>(P, Q, nB, ezo, ecs, y0, x0, lds);
+  float own_inv = 0.f, own_ss = 0.f;
+  if (OWN_STAGED) stage_region_own<T, D_T, PLQ, TH, TW, CROP>(P, Q, nB, ezo, ecs, y0, x0, lds, ly, lx, xh, own_inv, own_ss);
+  else stage_region<T, D_T, PLQ, NT, CROP>(P, Q, nB, ezo, ecs, y0, x0, lds);
 
   // (3) far (offset, role) pairs, two at a time: pair j = (far offset j / NR, role j % NR).  Vectors and g of
   //     the first two pairs are in flight across the barrier and the near-pair work.
@@ -721,10 +773,13 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_bwd_tiled(const 
     ss = fmaf(xh[c], xh[c], ss);
     G[c] = 0.f;
   }
+  if (OWN_STAGED) ss = own_ss;  // xh is already normalised
   const bool tiny = ss < P.eps * P.eps;
-  const float invp = rnorm(ss, Q.inv_eps);
+  const float invp = OWN_STAGED ? own_inv : rnorm(ss, Q.inv_eps);
+  if (!OWN_STAGED) {
 #pragma unroll
-  for (int c = 0; c < D_T; ++c) xh[c] *= invp;
+    for (int c = 0; c < D_T; ++c) xh[c] *= invp;
+  }
   lds_barrier();
 
   // Far pairs 0 and 1 were requested before the barrier: consume them first, then request pairs 2 and 3 so that
