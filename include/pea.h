@@ -168,6 +168,15 @@ size_t pea_targets_workspace_bytes(const PeaDesc *desc);
 int pea_gen_targets(const PeaDesc *desc, const int32_t *labels, unsigned flags, float *target, uint8_t *mask,
                     float *weight, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- the step after the path: 3D inference stitcher ----
+ * Provider_valid.add_vol / get_results of scripts_ac3ac4/data/provider_valid.py:320-349 on the device, so a predicted
+ * window never leaves HBM: out_affs [C,Z,Y,X] and weight_map [Z,Y,X] accumulate affs_vol [C,oz,oy,ox] * weight_vol
+ * [oz,oy,ox] (the Gaussian blend weights of get_weight, :305-318) at (z0,y0,x0); finalize divides in place.  Separate
+ * f32 multiply / add / divide (no FMA): bit-identical to the numpy statements for the same add order. */
+int pea_stitch_add(float *out_affs, float *weight_map, const float *affs_vol, const float *weight_vol, int C, int Z, int Y,
+                   int X, int oz, int oy, int ox, int z0, int y0, int x0, void *stream);
+int pea_stitch_finalize(float *out_affs, const float *weight_map, int C, size_t voxels, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ from .loss.loss_embedding_mse_3d import (ema_embedding_loss_norm1, ema_embedding
 from .utils.affinity_ours import gen_offsets, multi_offset
 from .utils.postproc import fill_border_relu_, relu_
 from .utils.targets import gen_affs_ours, gen_targets
+from .harness.stitch import VolumeStitcher
 from .harness.loss_section import (ac3ac4_loss_section, cvppp_loss_section, deep_weight_factor, finish_pred_2d_,
                                    finish_pred_3d_)
 
@@ -27,5 +28,5 @@ __all__ = [
     "embedding_loss", "ema_embedding_loss", "embedding2affs", "embedding_loss_norm1", "embedding_loss_norm5",
     "ema_embedding_loss_norm1", "ema_embedding_loss_norm5", "inf_embedding_loss_norm1", "inf_embedding_loss_norm5",
     "gen_offsets", "multi_offset", "fill_border_relu_", "relu_", "cvppp_loss_section", "ac3ac4_loss_section",
-    "deep_weight_factor", "finish_pred_2d_", "finish_pred_3d_", "gen_targets", "gen_affs_ours",
+    "deep_weight_factor", "finish_pred_2d_", "finish_pred_3d_", "gen_targets", "gen_affs_ours", "VolumeStitcher",
 ]

@@ -25,7 +25,7 @@ TGT_PADDING, TGT_BOTH_FOREGROUND = 1, 2
 
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",
            "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_bwd", "pea_scale_inplace", "pea_fill_border_relu",
-           "pea_targets_workspace_bytes", "pea_gen_targets")
+           "pea_targets_workspace_bytes", "pea_gen_targets", "pea_stitch_add", "pea_stitch_finalize")
 
 
 class PeaLibraryError(RuntimeError):
@@ -105,6 +105,10 @@ def lib():
     L.pea_targets_workspace_bytes.argtypes = [dp]
     L.pea_gen_targets.restype = ctypes.c_int
     L.pea_gen_targets.argtypes = [dp, vp, ctypes.c_uint, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.pea_stitch_add.restype = ctypes.c_int
+    L.pea_stitch_add.argtypes = [vp, vp, vp, vp] + [ctypes.c_int] * 10 + [vp]
+    L.pea_stitch_finalize.restype = ctypes.c_int
+    L.pea_stitch_finalize.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t, vp]
     L.pea_fill_border_relu.restype = ctypes.c_int
     L.pea_fill_border_relu.argtypes = [vp] + [ctypes.c_int] * 7 + [vp]
     if L.pea_version() != PEA_ABI_VERSION:

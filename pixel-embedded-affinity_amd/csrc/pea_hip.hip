@@ -492,6 +492,32 @@ __global__ __launch_bounds__(256) void k_fill_border_relu(float* __restrict__ af
   if (src != i || relu) affs[i] = v;
 }
 
+// 3D inference stitcher (scripts_ac3ac4/data/provider_valid.py:320-349): out[:, window] += vol * w ; wmap[window] += w,
+// then out /= wmap.  Product and sum are rounded separately (no FMA) so the result is bit-identical to numpy's.
+__global__ __launch_bounds__(256) void k_stitch_add(float* __restrict__ out, float* __restrict__ wmap, const float* __restrict__ vol,
+                                                    const float* __restrict__ wv, int C, int Z, int Y, int X, int oz, int oy, int ox,
+                                                    int z0, int y0, int x0) {
+  const size_t n = (size_t)oz * oy * ox;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int z = (int)(i / ((size_t)oy * ox)), y = (int)((i / ox) % oy), x = (int)(i % ox);
+  const size_t o = ((size_t)(z0 + z) * Y + (y0 + y)) * X + (x0 + x), S = (size_t)Z * Y * X;
+  const float w = wv[i];
+  for (int c = 0; c < C; ++c) {
+    float prod = vol[c * n + i] * w;
+    asm volatile("" : "+v"(prod));  // keep the product a rounded f32: hipcc would contract a * b + c into one FMA
+    out[c * S + o] = out[c * S + o] + prod;
+  }
+  wmap[o] = wmap[o] + w;
+}
+
+__global__ __launch_bounds__(256) void k_stitch_finalize(float* __restrict__ out, const float* __restrict__ wmap, int C, size_t S) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= S) return;
+  const float w = wmap[i];
+  for (int c = 0; c < C; ++c) out[c * S + i] = __fdiv_rn(out[c * S + i], w);
+}
+
 }  // namespace
 
 extern "C" {
@@ -671,6 +697,28 @@ int pea_gen_targets(const PeaDesc* desc, const int32_t* labels, unsigned flags, 
   hipLaunchKernelGGL(k_gen_targets, dim3(chunks, (unsigned)G.B), dim3(256), 0, s, G, labels, target, mask, (unsigned*)workspace);
   if (weight)
     hipLaunchKernelGGL(k_gen_weights, dim3(chunks, (unsigned)(G.B * G.K)), dim3(256), 0, s, G, target, (const unsigned*)workspace, weight);
+  return hip_rc();
+}
+
+int pea_stitch_add(float* out_affs, float* weight_map, const float* affs_vol, const float* weight_vol, int C, int Z, int Y,
+                   int X, int oz, int oy, int ox, int z0, int y0, int x0, void* stream) {
+  if (!out_affs || !weight_map || !affs_vol || !weight_vol) return PEA_E_NULL;
+  if (C < 1 || oz < 1 || oy < 1 || ox < 1 || z0 < 0 || y0 < 0 || x0 < 0 || z0 + oz > Z || y0 + oy > Y || x0 + ox > X) return PEA_E_DESC;
+  if (misaligned(out_affs, 4) || misaligned(weight_map, 4) || misaligned(affs_vol, 4) || misaligned(weight_vol, 4)) return PEA_E_ALIGN;
+  const size_t n = (size_t)oz * oy * ox, blocks = (n + 255) / 256;
+  if (blocks > 0x7fffffffULL) return PEA_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_stitch_add, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out_affs, weight_map, affs_vol,
+                     weight_vol, C, Z, Y, X, oz, oy, ox, z0, y0, x0);
+  return hip_rc();
+}
+
+int pea_stitch_finalize(float* out_affs, const float* weight_map, int C, size_t voxels, void* stream) {
+  if (!out_affs || !weight_map) return PEA_E_NULL;
+  if (C < 1) return PEA_E_DESC;
+  if (misaligned(out_affs, 4) || misaligned(weight_map, 4)) return PEA_E_ALIGN;
+  const size_t blocks = (voxels + 255) / 256;
+  if (blocks > 0x7fffffffULL) return PEA_E_UNSUPPORTED;
+  if (voxels) hipLaunchKernelGGL(k_stitch_finalize, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out_affs, weight_map, C, voxels);
   return hip_rc();
 }
 

@@ -636,3 +636,26 @@ def test_gpu_target_generation_3d_and_full_size(pkg, dev, orc, synth):
     t, m, w = pkg.gen_targets(torch.from_numpy(labf[:, 0]).to(dev), offsets, padding=True)
     assert np.array_equal(t.cpu().numpy(), ht[:, :, 0]) and np.array_equal(m.cpu().numpy(), hm[:, :, 0])
     assert np.array_equal(w.cpu().numpy(), hw[:, :, 0])
+
+
+def test_volume_stitcher_matches_reference_statements(pkg, dev):
+    """overlapping windows blended with the reference's Gaussian weights: numpy statements of
+    scripts_ac3ac4/data/provider_valid.py:320-349 against pea_stitch_add / pea_stitch_finalize, bit for bit"""
+    stitch = __import__("importlib").import_module(ge.PKG_NAME + ".harness.stitch")
+    C, shape, out_size, stride, vp = 3, (26, 56, 56), (18, 40, 40), (8, 16, 16), (4, 8, 8)
+    rng = np.random.default_rng(5)
+    w = stitch.get_weight(out_size)
+    out_np = np.zeros((C,) + shape, np.float32)
+    wm_np = np.zeros((1,) + shape, np.float32)
+    st = pkg.VolumeStitcher(C, shape, out_size, dev)
+    for fz in range(0, shape[0] - out_size[0] + 1, stride[0]):
+        for fy in range(0, shape[1] - out_size[1] + 1, stride[1]):
+            for fx in range(0, shape[2] - out_size[2] + 1, stride[2]):
+                vol = rng.standard_normal((C,) + out_size).astype(np.float32)
+                out_np[:, fz:fz + out_size[0], fy:fy + out_size[1], fx:fx + out_size[2]] += vol * w
+                wm_np[:, fz:fz + out_size[0], fy:fy + out_size[1], fx:fx + out_size[2]] += w
+                st.add_vol(torch.from_numpy(vol).to(dev), (fz, fy, fx))
+    res_np = (out_np / wm_np)[:, vp[0]:-vp[0], vp[1]:-vp[1], vp[2]:-vp[2]]
+    res = st.get_results(vp)
+    assert np.array_equal(st.weight_map.cpu().numpy(), wm_np)
+    assert np.array_equal(res.cpu().numpy(), res_np)
