@@ -164,9 +164,24 @@ int pea_fill_border_relu(float *affs, int B, int K, int Z, int Y, int X, int shi
  * workspace: pea_targets_workspace_bytes(desc) bytes (integer counts; zeroed by the call). */
 #define PEA_TGT_PADDING 1u
 #define PEA_TGT_BOTH_FOREGROUND 2u
+#define PEA_TGT_MASK_INSIDE 4u /* labels-in training step only: mask = [neighbour inside] (2D path); without it mask == 1 (3D path) */
 size_t pea_targets_workspace_bytes(const PeaDesc *desc);
 int pea_gen_targets(const PeaDesc *desc, const int32_t *labels, unsigned flags, float *target, uint8_t *mask,
                     float *weight, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- the training step from labels: no target / weight / mask tensors at all (SURVEY.md section 8f, f2 fused) ----
+ * pea_label_weights: wtab [B,K,2] f32 = { weight of target-1 pixels, weight of target-0 pixels } per (image, channel), i.e.
+ * weight_binary_ratio(lb_affs[i]) (scripts_cvppp/data/data_segmentation.py:205-228) as two scalars; integer counts in
+ * `workspace` (pea_targets_workspace_bytes).  pea_affinity_fwd_bwd_labels: pea_affinity_fwd_bwd with
+ *   target_i(q) = [label(q) == label(q + o_i)] (flags as pea_gen_targets), mask_i(q) = [q + o_i inside] with
+ *   PEA_TGT_MASK_INSIDE else 1, weight_i(q) = target ? wtab[b][i][0] : wtab[b][i][1]
+ * evaluated inside the kernel: results equal (to rounding) to pea_gen_targets + pea_affinity_fwd + pea_affinity_bwd.
+ * Returns PEA_E_UNSUPPORTED when no fused kernel covers the descriptor (then use those three). */
+int pea_label_weights(const PeaDesc *desc, const int32_t *labels, unsigned flags, float *wtab, void *workspace,
+                      size_t workspace_bytes, void *stream);
+int pea_affinity_fwd_bwd_labels(const PeaDesc *desc, const void *e, const void *e_other, const int32_t *labels,
+                                const float *wtab, unsigned flags, float *affs, float *loss_out, const float *dloss, void *de,
+                                void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- the step after the path: 3D inference stitcher ----
  * Provider_valid.add_vol / get_results of scripts_ac3ac4/data/provider_valid.py:320-349 on the device, so a predicted

@@ -11,9 +11,10 @@ Import name: the directory is not a valid Python identifier, so load it through
 """
 from . import _lib
 from ._lib import PeaLibraryError, build
-from .affinity_op import AffinityMap, AffinitySpec, FusedAffinityMSE, affinity_infer
+from .affinity_op import AffinityMap, AffinitySpec, FusedAffinityMSE, LabelsAffinityMSE, affinity_infer
 from .loss.loss import WeightedMSE
-from .loss.loss_embedding_mse import ema_embedding_loss, embedding2affs, embedding_loss
+from .loss.loss_embedding_mse import (ema_embedding_loss, ema_embedding_loss_from_labels, embedding2affs, embedding_loss,
+                                      embedding_loss_from_labels)
 from .loss.loss_embedding_mse_3d import (ema_embedding_loss_norm1, ema_embedding_loss_norm5, embedding_loss_norm1,
                                          embedding_loss_norm5, inf_embedding_loss_norm1, inf_embedding_loss_norm5)
 from .utils.affinity_ours import gen_offsets, multi_offset
@@ -28,5 +29,6 @@ __all__ = [
     "embedding_loss", "ema_embedding_loss", "embedding2affs", "embedding_loss_norm1", "embedding_loss_norm5",
     "ema_embedding_loss_norm1", "ema_embedding_loss_norm5", "inf_embedding_loss_norm1", "inf_embedding_loss_norm5",
     "gen_offsets", "multi_offset", "fill_border_relu_", "relu_", "cvppp_loss_section", "ac3ac4_loss_section",
-    "deep_weight_factor", "finish_pred_2d_", "finish_pred_3d_", "gen_targets", "gen_affs_ours", "VolumeStitcher",
+    "deep_weight_factor", "finish_pred_2d_", "finish_pred_3d_", "gen_targets", "gen_affs_ours", "VolumeStitcher", "embedding_loss_from_labels",
+    "ema_embedding_loss_from_labels", "LabelsAffinityMSE",
 ]

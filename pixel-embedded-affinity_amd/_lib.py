@@ -21,11 +21,12 @@ BORDER_CIRCULAR, BORDER_CROP_ZERO = 0, 1
 F32, F16 = 0, 1
 NORM_BX, NORM_CROPPED, NORM_FULL = 0, 1, 2
 FLAG_RELU_AFFS = 1
-TGT_PADDING, TGT_BOTH_FOREGROUND = 1, 2
+TGT_PADDING, TGT_BOTH_FOREGROUND, TGT_MASK_INSIDE = 1, 2, 4
 
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",
            "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_bwd", "pea_scale_inplace", "pea_fill_border_relu",
-           "pea_targets_workspace_bytes", "pea_gen_targets", "pea_stitch_add", "pea_stitch_finalize")
+           "pea_targets_workspace_bytes", "pea_gen_targets", "pea_stitch_add", "pea_stitch_finalize",
+           "pea_label_weights", "pea_affinity_fwd_bwd_labels")
 
 
 class PeaLibraryError(RuntimeError):
@@ -105,6 +106,10 @@ def lib():
     L.pea_targets_workspace_bytes.argtypes = [dp]
     L.pea_gen_targets.restype = ctypes.c_int
     L.pea_gen_targets.argtypes = [dp, vp, ctypes.c_uint, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.pea_label_weights.restype = ctypes.c_int
+    L.pea_label_weights.argtypes = [dp, vp, ctypes.c_uint, vp, vp, ctypes.c_size_t, vp]
+    L.pea_affinity_fwd_bwd_labels.restype = ctypes.c_int
+    L.pea_affinity_fwd_bwd_labels.argtypes = [dp, vp, vp, vp, vp, ctypes.c_uint, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.pea_stitch_add.restype = ctypes.c_int
     L.pea_stitch_add.argtypes = [vp, vp, vp, vp] + [ctypes.c_int] * 10 + [vp]
     L.pea_stitch_finalize.restype = ctypes.c_int

@@ -279,3 +279,59 @@ class LossList(list):
     def __repr__(self):
         self._fill()
         return super(LossList, self).__repr__()
+
+
+class LabelsAffinityMSE(torch.autograd.Function):
+    """loss, affs, per_offset_losses = f(e, e_other, labels): the training step straight from the label image
+    (pea_label_weights + pea_affinity_fwd_bwd_labels): target / mask / weight are evaluated inside the kernel and
+    d loss / d e comes out of the same launch (for grad_output = 1; backward() rescales it in place).
+    flags: _lib.TGT_* (2D reference path: PADDING | MASK_INSIDE; 3D: BOTH_FOREGROUND)."""
+
+    @staticmethod
+    def forward(ctx, e, e_other, labels, spec, flags):
+        e_c = _embedding_arg(e, "embedding")
+        o_c = None
+        if e_other is not None:
+            o_c = _embedding_arg(e_other, "ema_embedding").to(e_c.dtype)
+            if o_c.shape != e_c.shape:
+                raise ValueError("ema_embedding shape %s != embedding shape %s" % (tuple(o_c.shape), tuple(e_c.shape)))
+        _require_gpu(labels, "labels")
+        if labels.dtype.is_floating_point or tuple(labels.shape) != (e_c.shape[0],) + tuple(e_c.shape[2:]):
+            raise ValueError("labels must be an integer tensor of shape %s" % ((e_c.shape[0],) + tuple(e_c.shape[2:]),))
+        lab = labels.to(torch.int32).contiguous()
+        kshape = _affs_shape(e_c, spec.K)
+        with torch.cuda.device(e_c.device):
+            d = make_desc(spec, e_c)
+            L = _lib.lib()
+            affs = torch.empty(kshape, dtype=torch.float32, device=e_c.device)
+            loss_vec = torch.empty(1 + spec.K, dtype=torch.float32, device=e_c.device)
+            wtab = torch.empty(e_c.shape[0] * spec.K * 2, dtype=torch.float32, device=e_c.device)
+            cb = L.pea_targets_workspace_bytes(ctypes.byref(d))
+            counts = torch.empty(max(cb, 4) // 4, dtype=torch.int32, device=e_c.device)
+            _lib.check(L.pea_label_weights(ctypes.byref(d), _ptr(lab), flags, _ptr(wtab), _ptr(counts), cb, _stream()), "pea_label_weights")
+            wsb = L.pea_workspace_bytes(ctypes.byref(d))
+            work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=e_c.device)
+            de_unit = torch.empty_like(e_c)
+            rc = L.pea_affinity_fwd_bwd_labels(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(lab), _ptr(wtab), flags, _ptr(affs),
+                                               _ptr(loss_vec), None, _ptr(de_unit), _ptr(work), wsb, _stream())
+            if rc == _lib.E_UNSUPPORTED:
+                raise NotImplementedError("no labels-in kernel for this descriptor (D != 16 or stencil too wide): "
+                                          "use gen_targets + embedding_loss")
+            _lib.check(rc, "pea_affinity_fwd_bwd_labels")
+        ctx.de_unit, ctx.desc = de_unit, d
+        loss, per_offset = loss_vec[0], loss_vec[1:]
+        ctx.mark_non_differentiable(affs, per_offset)
+        return loss, affs, per_offset
+
+    @staticmethod
+    def backward(ctx, dloss, _daffs, _dvec):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        if ctx.de_unit is None:
+            raise RuntimeError("the labels-in step hands its gradient buffer to the first backward; for a second backward "
+                               "over a retained graph use gen_targets + embedding_loss")
+        de, ctx.de_unit = ctx.de_unit, None
+        with torch.cuda.device(de.device):
+            dl = dloss.to(device=de.device, dtype=torch.float32).contiguous()
+            _lib.check(_lib.lib().pea_scale_inplace(_ptr(de), ctx.desc.dtype, de.numel(), _ptr(dl), _stream()), "pea_scale_inplace")
+        return de, None, None, None, None

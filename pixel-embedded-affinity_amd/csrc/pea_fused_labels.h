@@ -1,0 +1,276 @@
+// pea_fused_labels.h -- the training step from LABELS: affinities, class-balanced MSE loss and d loss / d e in one
+// launch, with target / mask / weight never materialised ("removes target / weight /
+// mask reads from the op entirely if fused").
+//
+// k_fused_tiled (pea_fused.h) has to sample target, weight and mask at p and at p - o: 60 one-dword loads per pixel and
+// 300 MB of HBM over-fetch at the bench shape, which is why it only ties the two-launch path.  From an int32 label
+// image the same quantities are
+//     t_i(q) = [label(q) == label(q + o_i)]          (and both > 0 with PEA_TGT_BOTH_FOREGROUND; neighbour outside the
+//     m_i(q) = [q + o_i inside the image]             image: t = PEA_TGT_PADDING ? 1 : 0, exactly pea_gen_targets)
+//     w_i(q) = t_i(q) ? wpos[b][i] : wneg[b][i]      (class balance: two scalars per (image, channel), pea_label_weights)
+// and for BOTH roles of offset o_i the pixel needs one label besides its own: label(p + o_i) for role A, label(p - o_i)
+// for role B (t_i(p - o_i) compares label(p - o_i) with label(p)).  21 four-byte loads per pixel from a 9.5 MB tensor
+// that lives in L2, instead of 60 from 308 MB.  HBM traffic per pixel: 4D (e) + 4 (labels) + 4K (affs) + 4D (de).
+// Self loss: every lane stages its own pixel itself (stage_region_own), so x needs no loads of its own either.
+// Same tile / LDS structure, same arithmetic and the same results (to rounding) as pea_affinity_fwd / _bwd fed with
+// pea_gen_targets' outputs (tests/test_gpu_parity.py::test_labels_step_*).
+#pragma once
+#include "pea_targets.h"
+#include "pea_tiled.h"
+
+namespace pea {
+
+constexpr unsigned kLabMask = PEA_TGT_MASK_INSIDE;  // mask = [neighbour inside] (the 2D path); else mask == 1 (the 3D path)
+
+template <typename T, int D_T, int TH, int TW, int PLQ, bool CROP, bool ROLE_B>
+__global__ __launch_bounds__(TH* TW, 4) void k_fused_labels(const KParams P, const TParams Q, const T* __restrict__ xt,
+                                                            const T* __restrict__ nbt, const int32_t* __restrict__ labels,
+                                                            const float* __restrict__ wtab, unsigned lflags,
+                                                            float* __restrict__ affs, float* __restrict__ partials,
+                                                            const float* __restrict__ dloss, T* __restrict__ dx) {
+  typedef Lds<D_T, PLQ> L;
+  constexpr int NT = TH * TW, NW = NT / 64;
+  constexpr int NR = ROLE_B ? 2 : 1;
+  constexpr int KN = 8;  // near offsets per chunk (x NR roles: one neighbour label each)
+  extern __shared__ f4 lds4[];
+  char* lds = (char*)lds4;
+  float* s_part = (float*)(lds + L::kBytes);  // [NW][K] loss partials per wave
+  const int tile = tile_id(Q);
+  if (tile >= Q.ntiles) return;
+  const int plane = tile / Q.tiles_per_plane;
+  const int rem = tile - plane * Q.tiles_per_plane;
+  const int ty = rem / Q.tiles_x;
+  const int y0 = ty * TH, x0 = (rem - ty * Q.tiles_x) * TW;
+  const int b = plane / P.Z, z = plane - b * P.Z;
+  const size_t S = (size_t)P.S;
+  const unsigned YX = (unsigned)(P.Y * P.X);
+  const rsrc_t xB = mkbuf(xt + (size_t)b * D_T * S), nB = mkbuf(nbt + (size_t)b * D_T * S);
+  const rsrc_t dB = mkbuf(dx + (size_t)b * D_T * S);
+  const rsrc_t lB = mkbuf(labels + (size_t)b * S);
+  const rsrc_t aB = mkbuf(affs ? affs + (size_t)b * P.K * S : nullptr);
+  const bool has_a = affs != nullptr;
+  const bool relu = P.flags & PEA_FLAG_RELU_AFFS;
+  const bool pad = lflags & PEA_TGT_PADDING, fg = lflags & PEA_TGT_BOTH_FOREGROUND, msk = lflags & kLabMask;
+  const unsigned ecs = (unsigned)P.S * (unsigned)sizeof(T);
+  const unsigned ezo = (unsigned)z * YX * (unsigned)sizeof(T);
+  const unsigned kcs = (unsigned)P.S * 4u, kzo = (unsigned)z * YX * 4u;
+  const float dl = dloss ? dloss[0] : 1.f;
+  const float* wt_b = wtab + 2 * (size_t)b * P.K;  // {wpos, wneg} per channel of this image
+
+  int ly, lx;
+  lane_pixel<TW>(ly, lx);
+  const int py = y0 + ly, px = x0 + lx;
+  const bool live = py < P.Y && px < P.X;
+  const unsigned po = (unsigned)(py * P.X + px);
+  const unsigned pe = live ? po * (unsigned)sizeof(T) : kOOB;
+  const unsigned pb = live ? po * 4u : kOOB;
+  const int pr = (ly + Q.hy0) * Q.RW + lx + Q.hx0;
+  const int wave = threadIdx.x >> 6;
+
+  // neighbour label of (near entry, role): role A at p + o, role B at p - o, UNWRAPPED (a neighbour outside the image
+  // has no label: inside = false, the load reads out of range)
+  int ln[KN][NR];
+  bool lin[KN][NR];
+#define PEA_LAB_LOAD1(u, k)                                                                                  \
+  {                                                                                                          \
+    _Pragma("unroll") for (int r = 0; r < NR; ++r) {                                                         \
+      const OffEnt en_ = Q.near[min((k), Q.n_near - 1)];                                                     \
+      const int sg_ = r == 0 ? 1 : -1;                                                                       \
+      const int uy_ = py + sg_ * ent_oy(en_), ux_ = px + sg_ * ent_ox(en_);                                  \
+      const bool in_ = live && (unsigned)uy_ < (unsigned)P.Y && (unsigned)ux_ < (unsigned)P.X && ((k) < Q.n_near); \
+      lin[u][r] = in_;                                                                                       \
+      ln[u][r] = __builtin_amdgcn_raw_buffer_load_b32(lB, in_ ? (unsigned)(uy_ * P.X + ux_) * 4u : kOOB, kzo, 0); \
+    }                                                                                                        \
+  }
+
+  // (1) own label, the neighbour labels of the first near chunk (and, EMA cross loss, the own raw pixel): in flight
+  //     during staging
+  const int lown = __builtin_amdgcn_raw_buffer_load_b32(lB, pb, kzo, 0);
+  float xh[D_T];
+  if (!ROLE_B) {
+#pragma unroll
+    for (int c = 0; c < D_T; ++c) xh[c] = bl_emb<T>(xB, pe, ezo + c * ecs);
+  }
+#pragma unroll
+  for (int u = 0; u < KN; ++u) PEA_LAB_LOAD1(u, u)
+
+  // (2) stage the neighbour tensor's region, normalised
+  float own_inv = 0.f, own_ss = 0.f;
+  if (ROLE_B) stage_region_own<T, D_T, PLQ, TH, TW, CROP>(P, Q, nB, ezo, ecs, y0, x0, lds, ly, lx, xh, own_inv, own_ss);
+  else stage_region<T, D_T, PLQ, NT, CROP>(P, Q, nB, ezo, ecs, y0, x0, lds);
+
+  // (3) far (offset, role) pairs, one at a time ahead: pair j = (far offset j / NR, role j % NR)
+  const int n_farp = Q.n_far * NR;
+  float fv[D_T];
+  int fl = 0;
+  bool fok = false, fin = false;
+#define PEA_LAB_LOAD_FAR(j)                                                                                   \
+  {                                                                                                           \
+    const OffEnt fe_ = Q.far[(j) / NR];                                                                       \
+    const int sg_ = ((j) % NR) == 0 ? 1 : -1;                                                                 \
+    const int uz_ = z + sg_ * fe_.d, uy_ = py + sg_ * ent_oy(fe_), ux_ = px + sg_ * ent_ox(fe_);              \
+    fin = live && (unsigned)uz_ < (unsigned)P.Z && (unsigned)uy_ < (unsigned)P.Y && (unsigned)ux_ < (unsigned)P.X; \
+    bool okz_, oky_, okx_;                                                                                    \
+    const int zz_ = wrap1<CROP>(uz_, P.Z, okz_);                                                              \
+    const int yy_ = wrap1<CROP>(uy_, P.Y, oky_);                                                              \
+    const int xx_ = wrap1<CROP>(ux_, P.X, okx_);                                                              \
+    fok = live && okz_ && oky_ && okx_;                                                                       \
+    const unsigned zc_ = (unsigned)(CROP ? min(max(zz_, 0), P.Z - 1) : zz_);                                  \
+    const unsigned vo_ = fok ? (unsigned)(yy_ * P.X + xx_) * (unsigned)sizeof(T) : kOOB;                      \
+    _Pragma("unroll") for (int c = 0; c < D_T; ++c) fv[c] = bl_emb<T>(nB, vo_, zc_ * YX * (unsigned)sizeof(T) + c * ecs); \
+    fl = __builtin_amdgcn_raw_buffer_load_b32(lB, fin ? (unsigned)(uy_ * P.X + ux_) * 4u : kOOB,              \
+                                              (unsigned)(fin ? uz_ : 0) * YX * 4u, 0);                        \
+  }
+  if (n_farp > 0) PEA_LAB_LOAD_FAR(0)
+
+  float G[D_T];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < D_T; ++c) {
+    ss = fmaf(xh[c], xh[c], ss);
+    G[c] = 0.f;
+  }
+  if (ROLE_B) ss = own_ss;  // xh is already normalised
+  const bool tiny = ss < P.eps * P.eps;
+  const float invp = ROLE_B ? own_inv : rnorm(ss, Q.inv_eps);
+  if (!ROLE_B) {
+#pragma unroll
+    for (int c = 0; c < D_T; ++c) xh[c] *= invp;
+  }
+  lds_barrier();
+
+  // one pair: a = <own, nbhat>; t, m, w from the two labels; role A also writes affs and the loss partial; returns the
+  // coefficient of nbhat in G.  exists: the pair is part of the loss at all (CROP_ZERO drops pairs that leave the volume).
+#define PEA_LAB_PAIR(ROLE, ent, a_in, exists, lnb, inside, coef)                                              \
+  {                                                                                                           \
+    const bool eq_ = lown == (lnb) && (!fg || (lown > 0 && (lnb) > 0));                                       \
+    const float t_ = ((inside) ? eq_ : pad) ? 1.f : 0.f;                                                      \
+    const float m_ = (msk && !(inside)) ? 0.f : 1.f;                                                          \
+    const float w_ = t_ != 0.f ? wt_b[2 * (ent).i] : wt_b[2 * (ent).i + 1];                                  \
+    float a_ = (exists) ? (a_in) : 0.f;                                                                       \
+    const float rr_ = a_ * m_ - t_ * m_;                                                                      \
+    const float wr_ = (exists) ? w_ * rr_ : 0.f;                                                              \
+    if ((ROLE) == 0) {                                                                                        \
+      if (has_a) bs32<true>(aB, relu ? fmaxf(a_, 0.f) : a_, pb, kzo + (unsigned)(ent).i * kcs);              \
+      const float red_ = wave_sum63(wr_ * rr_);                                                               \
+      if ((threadIdx.x & 63) == 63) s_part[wave * P.K + (ent).i] = red_;                                      \
+    }                                                                                                         \
+    coef = (ent).gscale * wr_ * m_;                                                                           \
+  }
+#define PEA_LAB_FAR(j)                                                                                        \
+  {                                                                                                           \
+    const OffEnt fe_ = Q.far[(j) / NR];                                                                       \
+    float sq_ = 0.f, dot_ = 0.f;                                                                              \
+    _Pragma("unroll") for (int c = 0; c < D_T; ++c) {                                                         \
+      sq_ = fmaf(fv[c], fv[c], sq_);                                                                          \
+      dot_ = fmaf(xh[c], fv[c], dot_);                                                                        \
+    }                                                                                                         \
+    const float rn_ = rnorm(sq_, Q.inv_eps);                                                                  \
+    float cf_;                                                                                                \
+    PEA_LAB_PAIR((j) % NR, fe_, dot_ * rn_, fok, fl, fin, cf_)                                                \
+    cf_ *= rn_;                                                                                               \
+    _Pragma("unroll") for (int c = 0; c < D_T; ++c) G[c] = fmaf(cf_, fv[c], G[c]);                            \
+  }
+
+  // ---- near pairs: neighbour vectors from LDS ---------------------------------------------------------
+  int jf = 0;  // next far pair to consume (its loads were issued one step earlier)
+  for (int k0 = 0; k0 < Q.n_near; k0 += KN) {
+#pragma unroll
+    for (int u = 0; u < KN; ++u) {
+      if (k0 + u < Q.n_near) {  // uniform
+        const OffEnt en = Q.near[k0 + u];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          float v[D_T];
+          lds_pixel<D_T, PLQ>(lds, pr + (r == 0 ? en.d : -en.d), v);
+          float a = 0.f;
+#pragma unroll
+          for (int c = 0; c < D_T; ++c) a = fmaf(xh[c], v[c], a);
+          const bool exists = live && (!CROP || lin[u][r]);
+          float cf;
+          PEA_LAB_PAIR(r, en, a, exists, ln[u][r], lin[u][r], cf)
+#pragma unroll
+          for (int c = 0; c < D_T; ++c) G[c] = fmaf(cf, v[c], G[c]);
+          asm volatile("" ::: "memory");  // one neighbour vector live at a time (see k_bwd_tiled)
+        }
+        if (k0 + KN + u < Q.n_near) PEA_LAB_LOAD1(u, k0 + KN + u)  // rolling prefetch into the freed slot
+        if ((u & 1) == 1 && jf < n_farp) {  // a far pair every two near entries: its round trip hides under LDS work
+          PEA_LAB_FAR(jf)
+          ++jf;
+          if (jf < n_farp) PEA_LAB_LOAD_FAR(jf)
+        }
+      }
+    }
+  }
+  while (jf < n_farp) {
+    PEA_LAB_FAR(jf)
+    ++jf;
+    if (jf < n_farp) PEA_LAB_LOAD_FAR(jf)
+  }
+#undef PEA_LAB_LOAD1
+#undef PEA_LAB_LOAD_FAR
+#undef PEA_LAB_PAIR
+#undef PEA_LAB_FAR
+
+  float proj = 0.f;
+#pragma unroll
+  for (int c = 0; c < D_T; ++c) proj = fmaf(xh[c], G[c], proj);
+  if (tiny) proj = 0.f;  // clamp_min branch of F.normalize: d ehat / d e = I / eps
+  const float sc = dl * invp;
+#pragma unroll
+  for (int c = 0; c < D_T; ++c) bs_emb<T>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
+
+  lds_barrier();
+  if (threadIdx.x < P.K) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += s_part[w * P.K + threadIdx.x];
+    partials[(size_t)threadIdx.x * Q.ntiles + tile] = v;
+  }
+}
+
+// counts of positive targets per (image, channel) straight from the labels (no target tensor), then the weight table
+__global__ __launch_bounds__(256) void k_label_counts(const GParams G, const int32_t* __restrict__ labels,
+                                                      unsigned* __restrict__ counts) {
+  __shared__ unsigned s_cnt[PEA_MAX_K];
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x < PEA_MAX_K) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const bool live = p < G.S;
+  const int yx = G.Y * G.X;
+  const int z = live ? p / yx : 0, r = live ? p - z * yx : 0, y = r / G.X, x = r - y * G.X;
+  const int32_t* lb = labels + (size_t)b * G.S;
+  const int a = live ? lb[p] : 0;
+  const bool pad = G.flags & PEA_TGT_PADDING, fg = G.flags & PEA_TGT_BOTH_FOREGROUND;
+  for (int i = 0; i < G.K; ++i) {
+    const int zz = z + G.off[i][0], yy = y + G.off[i][1], xx = x + G.off[i][2];
+    const bool inside = live && (unsigned)zz < (unsigned)G.Z && (unsigned)yy < (unsigned)G.Y && (unsigned)xx < (unsigned)G.X;
+    bool t = pad;
+    if (inside) {
+      const int nb = lb[(zz * G.Y + yy) * G.X + xx];
+      t = a == nb && (!fg || (a > 0 && nb > 0));
+    }
+    const unsigned long long bal = __ballot(live && t);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt[i], (unsigned)__popcll(bal));
+  }
+  __syncthreads();
+  if (threadIdx.x < G.K && s_cnt[threadIdx.x]) atomicAdd(&counts[b * G.K + threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_weight_table(int n, int S, const unsigned* __restrict__ counts, float* __restrict__ wtab) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned c = counts[i];
+  float wpos = 1.f, wneg = 1.f;
+  if (c != 0 && c != (unsigned)S) {
+    double f = (double)c / (double)S;
+    f = fmin(fmax(f, 5e-2), 0.99);
+    if (f > 0.5) wneg = (float)(f / (1.0 - f));
+    else wpos = (float)((1.0 - f) / f);
+  }
+  wtab[2 * i] = wpos;
+  wtab[2 * i + 1] = wneg;
+}
+
+}  // namespace pea

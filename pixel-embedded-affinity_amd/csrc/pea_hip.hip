@@ -26,6 +26,7 @@
 #include "pea_phased.h"
 #include "pea_fused.h"
 #include "pea_targets.h"
+#include "pea_fused_labels.h"
 #include "pea_plan.h"
 
 using namespace pea;
@@ -454,6 +455,28 @@ bool try_fused(const KParams& P, const T* x, const T* nb, const float* t, const 
   return true;
 }
 
+template <typename T, int D_T, bool RB>
+bool try_fused_labels(const KParams& P, const T* x, const T* nb, const int32_t* labels, const float* wtab, unsigned lflags,
+                      float* affs, float* partials, const float* dl, T* dx, hipStream_t s, int* nparts) {
+  constexpr TileCfg c = kBwdCfg[0];
+  TParams Q;
+  if (!plan_tiles(P, c, RB, &Q)) return false;
+  const size_t lds = Lds<D_T, c.PLQ>::kBytes + (size_t)(c.TH * c.TW / 64) * P.K * sizeof(float);
+  if (lds > (size_t)kLdsMax) return false;
+  const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(c.TH * c.TW);
+  if (P.border == PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_fused_labels<T, D_T, c.TH, c.TW, c.PLQ, false, RB>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, x, nb, labels, wtab, lflags, affs, partials, dl, dx);
+  } else {
+    constexpr auto kern = k_fused_labels<T, D_T, c.TH, c.TW, c.PLQ, true, RB>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, x, nb, labels, wtab, lflags, affs, partials, dl, dx);
+  }
+  *nparts = Q.ntiles;
+  return true;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_scale_inplace(T* __restrict__ buf, size_t n4, size_t n, const float* __restrict__ scale) {
   const float sc = scale[0];
@@ -681,7 +704,7 @@ int pea_gen_targets(const PeaDesc* desc, const int32_t* labels, unsigned flags, 
   if (rc) return rc;
   if (!labels || !target) return PEA_E_NULL;
   if (misaligned(labels, 4) || misaligned(target, 4) || misaligned(weight, 4) || misaligned(workspace, 4)) return PEA_E_ALIGN;
-  if (flags & ~(PEA_TGT_PADDING | PEA_TGT_BOTH_FOREGROUND)) return PEA_E_DESC;
+  if (flags & ~(PEA_TGT_PADDING | PEA_TGT_BOTH_FOREGROUND | PEA_TGT_MASK_INSIDE)) return PEA_E_DESC;
   const size_t need = (size_t)desc->B * desc->K * sizeof(unsigned);
   if (!workspace || workspace_bytes < need) return PEA_E_WORKSPACE;
   GParams G;
@@ -719,6 +742,64 @@ int pea_stitch_finalize(float* out_affs, const float* weight_map, int C, size_t 
   const size_t blocks = (voxels + 255) / 256;
   if (blocks > 0x7fffffffULL) return PEA_E_UNSUPPORTED;
   if (voxels) hipLaunchKernelGGL(k_stitch_finalize, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out_affs, weight_map, C, voxels);
+  return hip_rc();
+}
+
+int pea_label_weights(const PeaDesc* desc, const int32_t* labels, unsigned flags, float* wtab, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  const int rc = validate(desc);
+  if (rc) return rc;
+  if (!labels || !wtab) return PEA_E_NULL;
+  if (misaligned(labels, 4) || misaligned(wtab, 4) || misaligned(workspace, 4)) return PEA_E_ALIGN;
+  if (flags & ~(PEA_TGT_PADDING | PEA_TGT_BOTH_FOREGROUND | PEA_TGT_MASK_INSIDE)) return PEA_E_DESC;
+  const size_t need = (size_t)desc->B * desc->K * sizeof(unsigned);
+  if (!workspace || workspace_bytes < need) return PEA_E_WORKSPACE;
+  if (desc->B > 65535) return PEA_E_UNSUPPORTED;
+  GParams G;
+  G.B = desc->B; G.Z = desc->dims[0]; G.Y = desc->dims[1]; G.X = desc->dims[2]; G.K = desc->K;
+  G.S = G.Z * G.Y * G.X;
+  G.flags = flags;
+  for (int i = 0; i < PEA_MAX_K; ++i)
+    for (int a = 0; a < 3; ++a) G.off[i][a] = i < desc->K ? desc->offsets[i][a] : 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, need, s) != hipSuccess) return hip_rc();
+  hipLaunchKernelGGL(k_label_counts, dim3((unsigned)((G.S + 255) / 256), (unsigned)G.B), dim3(256), 0, s, G, labels, (unsigned*)workspace);
+  const int n = G.B * G.K;
+  hipLaunchKernelGGL(k_weight_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, G.S, (const unsigned*)workspace, wtab);
+  return hip_rc();
+}
+
+int pea_affinity_fwd_bwd_labels(const PeaDesc* desc, const void* e, const void* e_other, const int32_t* labels,
+                                const float* wtab, unsigned flags, float* affs, float* loss_out, const float* dloss, void* de,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = validate(desc);
+  if (rc) return rc;
+  if (!e || !labels || !wtab || !loss_out || !de) return PEA_E_NULL;
+  const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
+  if (misaligned(e, es) || misaligned(e_other, es) || misaligned(de, es) || misaligned(affs, 4) || misaligned(labels, 4) ||
+      misaligned(wtab, 4) || misaligned(loss_out, 4) || misaligned(dloss, 4) || misaligned(workspace, 4))
+    return PEA_E_ALIGN;
+  if (flags & ~(PEA_TGT_PADDING | PEA_TGT_BOTH_FOREGROUND | PEA_TGT_MASK_INSIDE)) return PEA_E_DESC;
+  const KParams P = make_params(desc);
+  if (!workspace || workspace_bytes < fwd_partials(P) * P.K * sizeof(float)) return PEA_E_WORKSPACE;
+  if (P.D != 16 || env_int("PEA_FORCE_DIRECT", 0) != 0) return PEA_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  float* partials = (float*)workspace;
+  int nparts = 0;
+  bool done;
+  if (desc->dtype == PEA_F16) {
+    const __half *x = (const __half*)e, *nb = (const __half*)e_other;
+    done = nb ? try_fused_labels<__half, 16, false>(P, x, nb, labels, wtab, flags, affs, partials, dloss, (__half*)de, s, &nparts)
+              : try_fused_labels<__half, 16, true>(P, x, x, labels, wtab, flags, affs, partials, dloss, (__half*)de, s, &nparts);
+  } else {
+    const float *x = (const float*)e, *nb = (const float*)e_other;
+    done = nb ? try_fused_labels<float, 16, false>(P, x, nb, labels, wtab, flags, affs, partials, dloss, (float*)de, s, &nparts)
+              : try_fused_labels<float, 16, true>(P, x, x, labels, wtab, flags, affs, partials, dloss, (float*)de, s, &nparts);
+  }
+  if (!done) return PEA_E_UNSUPPORTED;
+  rc = hip_rc();
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P, partials, nparts, loss_out);
   return hip_rc();
 }
 

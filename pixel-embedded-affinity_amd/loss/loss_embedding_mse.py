@@ -17,7 +17,7 @@ Semantics kept from the reference (file:line there):
 import torch
 
 from .. import _lib
-from ..affinity_op import AffinityMap, AffinitySpec, FusedAffinityMSE, LossList, affinity_infer
+from ..affinity_op import AffinityMap, AffinitySpec, FusedAffinityMSE, LabelsAffinityMSE, LossList, affinity_infer
 
 
 def _eps(mode):
@@ -68,4 +68,30 @@ def ema_embedding_loss(embedding, ema_embedding, target, weightmap, mask, criter
         loss, affs, _ = FusedAffinityMSE.apply(embedding, ema_embedding, target, weightmap, mask, _spec(offsets, lam, mode))
     else:
         loss, affs, _ = _foreign_criterion(embedding, ema_embedding, target, weightmap, mask, criterion, offsets, lam, mode)
+    return loss, affs
+
+
+# ---- the same losses straight from the label image (no target / weightmap / mask tensors) ----
+_FLAGS_2D = _lib.TGT_PADDING | _lib.TGT_MASK_INSIDE  # gen_affs_ours(ignore=False, padding=True) + its mask, the shipped provider
+
+
+def _from_labels(embedding, ema_embedding, labels, criterion, offsets, lam, mode):
+    if not _fused(criterion):
+        raise NotImplementedError("the labels-in step fuses WeightedMSE; for another criterion use gen_targets + embedding_loss")
+    return LabelsAffinityMSE.apply(embedding, ema_embedding, labels, _spec(offsets, lam, mode), _FLAGS_2D)
+
+
+def embedding_loss_from_labels(embedding, labels, criterion, offsets, affs0_weight=1, mode='ours'):
+    """embedding_loss(embedding, *gen_targets(labels, offsets, padding=True), criterion, offsets) without the three
+    [B,K,H,W] tensors: -> (loss, affs, all_loss).  labels: int tensor [B,H,W] on the GPU."""
+    loss, affs, parts = _from_labels(embedding, None, labels, criterion, offsets, [1.0] * len(offsets), mode)
+    return loss, affs, LossList(parts)
+
+
+def ema_embedding_loss_from_labels(embedding, ema_embedding, labels, criterion, offsets, affs0_weight=1, mode='ours'):
+    """ema_embedding_loss from the label image (the EMA operand must be detached, as the shipped configs have it)"""
+    if ema_embedding.requires_grad:
+        raise NotImplementedError("a second operand that needs its own gradient takes gen_targets + ema_embedding_loss")
+    lam = [float(affs0_weight) if i < 2 else 1.0 for i in range(len(offsets))]
+    loss, affs, _ = _from_labels(embedding, ema_embedding, labels, criterion, offsets, lam, mode)
     return loss, affs

@@ -659,3 +659,43 @@ def test_volume_stitcher_matches_reference_statements(pkg, dev):
     res = st.get_results(vp)
     assert np.array_equal(st.weight_map.cpu().numpy(), wm_np)
     assert np.array_equal(res.cpu().numpy(), res_np)
+
+
+@pytest.mark.parametrize("case", ["self_nb4", "self_nb8", "ema", "f16"])
+def test_labels_step_matches_targets_path(pkg, dev, synth, case):
+    """the labels-in training step (pea_label_weights + pea_affinity_fwd_bwd_labels) against pea_gen_targets +
+    embedding_loss / ema_embedding_loss on the same label images: loss, per-offset losses, affs, gradient"""
+    nb = 8 if case == "self_nb8" else 4
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27] if nb == 4 else [1, 3, 9], nb)
+    B, D, H, W = 3, 16, 80, 136
+    lab = synth.synth_labels(B, (1, H, W), 91, cell=11)[:, 0]
+    lab_t = torch.from_numpy(lab).to(dev)
+    e = synth.synth_embedding((B, D, H, W), 92)
+    if case == "f16":
+        e = e.astype(np.float16)
+    ema = torch.from_numpy(synth.synth_embedding((B, D, H, W), 93).astype(e.dtype)).to(dev) if case == "ema" else None
+    crit = pkg.WeightedMSE()
+    t, m, w = pkg.gen_targets(lab_t, offsets, padding=True)
+
+    def run(labels_in):
+        et = torch.from_numpy(e).to(dev).requires_grad_(True)
+        if case == "ema":
+            if labels_in:
+                loss, affs = pkg.ema_embedding_loss_from_labels(et, ema, lab_t, crit, offsets, affs0_weight=2)
+            else:
+                loss, affs = pkg.ema_embedding_loss(et, ema, t, w, m, crit, offsets, affs0_weight=2)
+            parts = None
+        elif labels_in:
+            loss, affs, parts = pkg.embedding_loss_from_labels(et, lab_t, crit, offsets)
+        else:
+            loss, affs, parts = pkg.embedding_loss(et, t, w, m, crit, offsets)
+        (loss * 0.5).backward()
+        return loss.item(), affs.cpu().numpy(), et.grad.float().cpu().numpy(), (None if parts is None else list(parts))
+
+    l0, a0, g0, p0 = run(False)
+    l1, a1, g1, p1 = run(True)
+    assert abs(l1 - l0) <= 2e-6 * abs(l0)
+    assert np.abs(a1 - a0).max() < 2e-6
+    assert relmax(g1, g0) < (2e-3 if case == "f16" else 1e-5)
+    if p0 is not None:
+        np.testing.assert_allclose(p1, p0, rtol=2e-6)
