@@ -161,8 +161,16 @@ def main():
         inf = lambda: L.pea_affinity_infer(ctypes.byref(desc), P(Ed), None, P(affs), st)
         # the opt-in one-launch step (PEA_FUSED=1), timed beside the default two launches for the record
         fused = lambda: L.pea_affinity_fwd_bwd(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(affs), P(lossv), None, P(dE), P(work), wsb, st)
+        # the labels-in training step (embedding_loss_from_labels): same outputs from the int32 label image, no t / w / m
+        lab = torch.from_numpy(synth.synth_labels(B, (1, H, W), 555 + rank)[:, 0].copy()).to(dev)
+        wtab = torch.empty(B * K * 2, device=dev)
+        cnt = torch.empty(B * K, dtype=torch.int32, device=dev)
+        lflags = pkg._lib.TGT_PADDING | pkg._lib.TGT_MASK_INSIDE
+        labels_step = lambda: (L.pea_label_weights(ctypes.byref(desc), P(lab), lflags, P(wtab), P(cnt), B * K * 4, st),
+                               L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(Ed), None, P(lab), P(wtab), lflags, P(affs),
+                                                             P(lossv), None, P(dE), P(work), wsb, st))
         kt = {}
-        for name, fn in (("fwd", fwd), ("bwd", bwd), ("infer", inf), ("fused_fwd_bwd", fused)):
+        for name, fn in (("fwd", fwd), ("bwd", bwd), ("infer", inf), ("fused_fwd_bwd", fused), ("labels_step", labels_step)):
             event_time_ms(fn, 10)
             kt[name] = event_time_ms(fn, max(20, min(args.steps, 200)))
         ab = algorithmic_bytes_per_px(D, K)
@@ -186,6 +194,7 @@ def main():
             "kernel_ms": {k: round(v, 5) for k, v in kt.items()},
             "kernel_sum_mpx_s": round(B * H * W / ((kt["fwd"] + kt["bwd"]) * 1e-3) / 1e6, 1),
             "infer_mpx_s": round(B * H * W / (kt["infer"] * 1e-3) / 1e6, 1),
+            "labels_step_mpx_s": round(B * H * W / (kt["labels_step"] * 1e-3) / 1e6, 1),
             "roofline": {"bound": "hbm", "kernel": "pea_affinity_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_px": ab[dom], "px_per_launch": B * H * W,

@@ -232,27 +232,55 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fused_labels(const KParams P, con
 // counts of positive targets per (image, channel) straight from the labels (no target tensor), then the weight table
 __global__ __launch_bounds__(256) void k_label_counts(const GParams G, const int32_t* __restrict__ labels,
                                                       unsigned* __restrict__ counts) {
+  // NIT pixels per lane, decoded once; per channel NIT independent neighbour loads in flight; counts go wave ballot ->
+  // LDS -> K global atomics per workgroup (one atomic per 256 pixels and channel onto B*K addresses cost 90 us)
   __shared__ unsigned s_cnt[PEA_MAX_K];
+  constexpr int NIT = kTgtNit;
   const int b = blockIdx.y;
-  const int p = blockIdx.x * 256 + threadIdx.x;
   if (threadIdx.x < PEA_MAX_K) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  const bool live = p < G.S;
   const int yx = G.Y * G.X;
-  const int z = live ? p / yx : 0, r = live ? p - z * yx : 0, y = r / G.X, x = r - y * G.X;
   const int32_t* lb = labels + (size_t)b * G.S;
-  const int a = live ? lb[p] : 0;
   const bool pad = G.flags & PEA_TGT_PADDING, fg = G.flags & PEA_TGT_BOTH_FOREGROUND;
-  for (int i = 0; i < G.K; ++i) {
-    const int zz = z + G.off[i][0], yy = y + G.off[i][1], xx = x + G.off[i][2];
-    const bool inside = live && (unsigned)zz < (unsigned)G.Z && (unsigned)yy < (unsigned)G.Y && (unsigned)xx < (unsigned)G.X;
-    bool t = pad;
-    if (inside) {
-      const int nb = lb[(zz * G.Y + yy) * G.X + xx];
-      t = a == nb && (!fg || (a > 0 && nb > 0));
+  int pp[NIT], pz[NIT], py[NIT], px[NIT], pa[NIT];
+#pragma unroll
+  for (int j = 0; j < NIT; ++j) {
+    const int p = (blockIdx.x * NIT + j) * 256 + (int)threadIdx.x;
+    const bool live = p < G.S;
+    pp[j] = live ? p : -1;
+    pz[j] = live ? p / yx : 0;
+    const int r = live ? p - pz[j] * yx : 0;
+    py[j] = r / G.X;
+    px[j] = r - py[j] * G.X;
+    pa[j] = live ? lb[p] : 0;
+  }
+  constexpr int CH = 4;  // channels per step: CH * NIT independent neighbour loads in flight per lane
+  for (int i0 = 0; i0 < G.K; i0 += CH) {
+    int nb[CH][NIT];
+    bool in[CH][NIT];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int i = min(i0 + u, G.K - 1);
+      const int oz = G.off[i][0], oy = G.off[i][1], ox = G.off[i][2];
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const int zz = pz[j] + oz, yy = py[j] + oy, xx = px[j] + ox;
+        in[u][j] = pp[j] >= 0 && (unsigned)zz < (unsigned)G.Z && (unsigned)yy < (unsigned)G.Y && (unsigned)xx < (unsigned)G.X;
+        nb[u][j] = lb[in[u][j] ? (zz * G.Y + yy) * G.X + xx : 0];
+      }
     }
-    const unsigned long long bal = __ballot(live && t);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt[i], (unsigned)__popcll(bal));
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int i = i0 + u;
+      const bool on = i < G.K;  // uniform
+      unsigned c = 0;
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const bool t = in[u][j] ? (pa[j] == nb[u][j] && (!fg || (pa[j] > 0 && nb[u][j] > 0))) : pad;
+        c += (unsigned)__popcll(__ballot(pp[j] >= 0 && t));
+      }
+      if (on && (threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt[i], c);
+    }
   }
   __syncthreads();
   if (threadIdx.x < G.K && s_cnt[threadIdx.x]) atomicAdd(&counts[b * G.K + threadIdx.x], s_cnt[threadIdx.x]);

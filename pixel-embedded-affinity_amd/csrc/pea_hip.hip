@@ -717,7 +717,8 @@ int pea_gen_targets(const PeaDesc* desc, const int32_t* labels, unsigned flags, 
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(workspace, 0, need, s) != hipSuccess) return hip_rc();
   const unsigned chunks = (unsigned)((G.S + 255) / 256);
-  hipLaunchKernelGGL(k_gen_targets, dim3(chunks, (unsigned)G.B), dim3(256), 0, s, G, labels, target, mask, (unsigned*)workspace);
+  const unsigned gx = (chunks + kTgtNit - 1) / kTgtNit;  // kTgtNit * 256 pixels per workgroup
+  hipLaunchKernelGGL(k_gen_targets, dim3(gx, (unsigned)G.B), dim3(256), 0, s, G, labels, target, mask, (unsigned*)workspace);
   if (weight)
     hipLaunchKernelGGL(k_gen_weights, dim3(chunks, (unsigned)(G.B * G.K)), dim3(256), 0, s, G, target, (const unsigned*)workspace, weight);
   return hip_rc();
@@ -763,7 +764,9 @@ int pea_label_weights(const PeaDesc* desc, const int32_t* labels, unsigned flags
     for (int a = 0; a < 3; ++a) G.off[i][a] = i < desc->K ? desc->offsets[i][a] : 0;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(workspace, 0, need, s) != hipSuccess) return hip_rc();
-  hipLaunchKernelGGL(k_label_counts, dim3((unsigned)((G.S + 255) / 256), (unsigned)G.B), dim3(256), 0, s, G, labels, (unsigned*)workspace);
+  const unsigned chunks = (unsigned)((G.S + 255) / 256);
+  const unsigned gx = (chunks + kTgtNit - 1) / kTgtNit;
+  hipLaunchKernelGGL(k_label_counts, dim3(gx, (unsigned)G.B), dim3(256), 0, s, G, labels, (unsigned*)workspace);
   const int n = G.B * G.K;
   hipLaunchKernelGGL(k_weight_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, G.S, (const unsigned*)workspace, wtab);
   return hip_rc();

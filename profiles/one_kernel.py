@@ -38,6 +38,8 @@ WTAB = torch.empty(B * K * 2, device=dev)
 CNT = torch.empty(B * K, dtype=torch.int32, device=dev)
 assert L.pea_label_weights(ctypes.byref(desc), P(LAB), 5, P(WTAB), P(CNT), B * K * 4, st) == 0
 fns = {
+    "gentgt": lambda: L.pea_gen_targets(ctypes.byref(desc), P(LAB), 1, P(T), P(M), P(Wt), P(CNT), B * K * 4, st),
+    "labw": lambda: L.pea_label_weights(ctypes.byref(desc), P(LAB), 5, P(WTAB), P(CNT), B * K * 4, st),
     "labels": lambda: L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(E), None, P(LAB), P(WTAB), 5, P(affs), P(lossv), None, P(dE), P(work), wsb, st),
     "fused": lambda: L.pea_affinity_fwd_bwd(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), P(lossv), None, P(dE), P(work), wsb, st),
     "fwd": lambda: L.pea_affinity_fwd(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), P(G), P(lossv), P(work), wsb, st),
