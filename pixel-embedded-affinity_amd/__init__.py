@@ -15,14 +15,15 @@ from .affinity_op import AffinityMap, AffinitySpec, FusedAffinityMSE, LabelsAffi
 from .loss.loss import WeightedMSE
 from .loss.loss_embedding_mse import (ema_embedding_loss, ema_embedding_loss_from_labels, embedding2affs, embedding_loss,
                                       embedding_loss_from_labels)
-from .loss.loss_embedding_mse_3d import (ema_embedding_loss_norm1, ema_embedding_loss_norm5, embedding_loss_norm1,
-                                         embedding_loss_norm5, inf_embedding_loss_norm1, inf_embedding_loss_norm5)
+from .loss.loss_embedding_mse_3d import (ema_embedding_loss_norm1, ema_embedding_loss_norm5, ema_embedding_loss_norm5_from_labels,
+                                         embedding_loss_norm1, embedding_loss_norm1_from_labels, embedding_loss_norm5,
+                                         embedding_loss_norm5_from_labels, inf_embedding_loss_norm1, inf_embedding_loss_norm5)
 from .utils.affinity_ours import gen_offsets, multi_offset
 from .utils.postproc import fill_border_relu_, relu_
 from .utils.targets import gen_affs_ours, gen_targets
 from .harness.stitch import VolumeStitcher
-from .harness.loss_section import (ac3ac4_loss_section, cvppp_loss_section, deep_weight_factor, finish_pred_2d_,
-                                   finish_pred_3d_)
+from .harness.loss_section import (ac3ac4_loss_section, cvppp_loss_section, cvppp_loss_section_from_labels, deep_weight_factor,
+                                   finish_pred_2d_, finish_pred_3d_)
 
 __all__ = [
     "PeaLibraryError", "build", "AffinityMap", "AffinitySpec", "FusedAffinityMSE", "affinity_infer", "WeightedMSE",
@@ -30,5 +31,6 @@ __all__ = [
     "ema_embedding_loss_norm1", "ema_embedding_loss_norm5", "inf_embedding_loss_norm1", "inf_embedding_loss_norm5",
     "gen_offsets", "multi_offset", "fill_border_relu_", "relu_", "cvppp_loss_section", "ac3ac4_loss_section",
     "deep_weight_factor", "finish_pred_2d_", "finish_pred_3d_", "gen_targets", "gen_affs_ours", "VolumeStitcher", "embedding_loss_from_labels",
-    "ema_embedding_loss_from_labels", "LabelsAffinityMSE",
+    "ema_embedding_loss_from_labels", "LabelsAffinityMSE", "cvppp_loss_section_from_labels",
+    "embedding_loss_norm1_from_labels", "embedding_loss_norm5_from_labels", "ema_embedding_loss_norm5_from_labels",
 ]

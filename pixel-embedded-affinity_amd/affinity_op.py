@@ -281,6 +281,11 @@ class LossList(list):
         return super(LossList, self).__repr__()
 
 
+class LabelsStepUnsupported(NotImplementedError):
+    """pea_affinity_fwd_bwd_labels has no kernel for the descriptor; the *_from_labels wrappers then generate the
+    target / mask / weight tensors on the GPU (pea_gen_targets) and take the tensor path -- same results."""
+
+
 class LabelsAffinityMSE(torch.autograd.Function):
     """loss, affs, per_offset_losses = f(e, e_other, labels): the training step straight from the label image
     (pea_label_weights + pea_affinity_fwd_bwd_labels): target / mask / weight are evaluated inside the kernel and
@@ -315,8 +320,8 @@ class LabelsAffinityMSE(torch.autograd.Function):
             rc = L.pea_affinity_fwd_bwd_labels(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(lab), _ptr(wtab), flags, _ptr(affs),
                                                _ptr(loss_vec), None, _ptr(de_unit), _ptr(work), wsb, _stream())
             if rc == _lib.E_UNSUPPORTED:
-                raise NotImplementedError("no labels-in kernel for this descriptor (D != 16 or stencil too wide): "
-                                          "use gen_targets + embedding_loss")
+                raise LabelsStepUnsupported("no labels-in kernel for this descriptor (D != 16, image smaller than a tile, "
+                                            "stencil too wide): use gen_targets + the tensor API")
             _lib.check(rc, "pea_affinity_fwd_bwd_labels")
         ctx.de_unit, ctx.desc = de_unit, d
         loss, per_offset = loss_vec[0], loss_vec[1:]

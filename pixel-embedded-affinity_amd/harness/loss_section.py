@@ -6,7 +6,8 @@ can replace scripts_cvppp/main.py:282-312 / scripts_ac3ac4/main.py:216-238 by on
 happens inside (the reference's K `.item()` calls per loss are gone), so the section can be captured in a HIP graph
 (tests/test_gpu_parity.py::test_loss_section_graph_replay).
 """
-from ..loss.loss_embedding_mse import ema_embedding_loss, embedding_loss
+from ..loss.loss_embedding_mse import (ema_embedding_loss, ema_embedding_loss_from_labels, embedding_loss,
+                                       embedding_loss_from_labels)
 from ..loss.loss_embedding_mse_3d import (ema_embedding_loss_norm1, ema_embedding_loss_norm5, embedding_loss_norm1,
                                           embedding_loss_norm5)
 from ..utils.postproc import fill_border_relu_, relu_
@@ -82,3 +83,25 @@ def finish_pred_3d_(pred, shift=1):
 def finish_pred_2d_(pred):
     """scripts_cvppp/main.py:312"""
     return relu_(pred)
+
+
+def cvppp_loss_section_from_labels(embedding, emds, ema_embedding, labels, label_downs, criterion, offsets, nb_half,
+                                   affs0_weight=1, dis_mode='ours', deep_weight=1, self_emb=1.0, cross_emb=1.0):
+    """cvppp_loss_section without any target / weight / mask tensor: `labels` [B,H,W] and `label_downs` = the four
+    nearest-downsampled label images (scripts_cvppp/data/data_provider.py:199-208) replace target, weightmap, affs_mask
+    and down1..down4; every loss is one labels-in launch (gen_affs_ours(padding=True) + weight_binary_ratio evaluated
+    inside the kernel)."""
+    dwf = deep_weight_factor(deep_weight)
+    losses = []
+    for j, (emd, lab) in enumerate(zip(emds, label_downs)):
+        k = nb_half * (4 - j)
+        l, _, _ = embedding_loss_from_labels(emd, lab, criterion, offsets[:k], affs0_weight=affs0_weight, mode=dis_mode)
+        losses.append(l)
+    loss_embedding, pred, _ = embedding_loss_from_labels(embedding, labels, criterion, offsets, affs0_weight=affs0_weight, mode=dis_mode)
+    loss_embedding_cross, _ = ema_embedding_loss_from_labels(embedding, ema_embedding, labels, criterion, offsets,
+                                                             affs0_weight=affs0_weight, mode=dis_mode)
+    loss_embedding = loss_embedding * dwf[0]
+    loss_emd = [losses[j] * dwf[j + 1] for j in range(4)]
+    loss_embedding_cross = loss_embedding_cross * dwf[0]
+    loss = (loss_emd[0] + loss_emd[1] + loss_emd[2] + loss_emd[3] + loss_embedding) * self_emb + loss_embedding_cross * cross_emb
+    return loss, pred, {"loss_embedding": loss_embedding, "loss_emd": loss_emd, "loss_embedding_cross": loss_embedding_cross}

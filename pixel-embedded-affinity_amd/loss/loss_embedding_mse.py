@@ -17,7 +17,8 @@ Semantics kept from the reference (file:line there):
 import torch
 
 from .. import _lib
-from ..affinity_op import AffinityMap, AffinitySpec, FusedAffinityMSE, LabelsAffinityMSE, LossList, affinity_infer
+from ..affinity_op import (AffinityMap, AffinitySpec, FusedAffinityMSE, LabelsAffinityMSE, LabelsStepUnsupported, LossList,
+                           affinity_infer)
 
 
 def _eps(mode):
@@ -78,7 +79,12 @@ _FLAGS_2D = _lib.TGT_PADDING | _lib.TGT_MASK_INSIDE  # gen_affs_ours(ignore=Fals
 def _from_labels(embedding, ema_embedding, labels, criterion, offsets, lam, mode):
     if not _fused(criterion):
         raise NotImplementedError("the labels-in step fuses WeightedMSE; for another criterion use gen_targets + embedding_loss")
-    return LabelsAffinityMSE.apply(embedding, ema_embedding, labels, _spec(offsets, lam, mode), _FLAGS_2D)
+    try:
+        return LabelsAffinityMSE.apply(embedding, ema_embedding, labels, _spec(offsets, lam, mode), _FLAGS_2D)
+    except LabelsStepUnsupported:  # e.g. the coarsest deep-supervision scales: targets on the GPU, then the tensor path
+        from ..utils.targets import gen_targets
+        t, m, w = gen_targets(labels, offsets, padding=True)
+        return FusedAffinityMSE.apply(embedding, ema_embedding, t, w, m, _spec(offsets, lam, mode))
 
 
 def embedding_loss_from_labels(embedding, labels, criterion, offsets, affs0_weight=1, mode='ours'):

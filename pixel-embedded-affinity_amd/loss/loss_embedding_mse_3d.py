@@ -13,7 +13,7 @@ Semantics kept from the reference (file:line there):
 import torch
 
 from .. import _lib
-from ..affinity_op import AffinityMap, AffinitySpec, FusedAffinityMSE, affinity_infer
+from ..affinity_op import AffinityMap, AffinitySpec, FusedAffinityMSE, LabelsAffinityMSE, LabelsStepUnsupported, affinity_infer
 from ..utils.affinity_ours import NORM5_SHIFTS, axis_offsets_3d
 
 
@@ -70,3 +70,37 @@ def ema_embedding_loss_norm5(embedding, ema_embedding, target, weightmap, criter
 def inf_embedding_loss_norm5(embedding):
     """-> affs [B,12,Z,Y,X] -- reference :212-234"""
     return affinity_infer(embedding, None, _spec(NORM5_SHIFTS, 1, 3))
+
+
+# ---- the same losses straight from the segmentation (no target / weightmap tensors; SURVEY.md section 8f, f2) ----
+# targets as the 12-channel provider builds them: seg_to_aff(lb, nhood, pad='') (scripts_ac3ac4/data/data_affinity.py:53-102,
+# data_provider_labeled_deep.py:253-256): 1 iff both voxels carry the same label > 0, 0 in the border slices; weights =
+# weight_binary_ratio per channel over the whole volume.  The cropped-away border pairs carry no loss either way.
+_FLAGS_3D = _lib.TGT_BOTH_FOREGROUND
+
+
+def _run_labels(embedding, ema_embedding, labels, criterion, shifts, affs0_weight, first):
+    if not getattr(criterion, 'pea_fused', False):
+        raise NotImplementedError("the labels-in step fuses WeightedMSE; for another criterion use gen_targets + the tensor API")
+    if ema_embedding is not None and ema_embedding.requires_grad:
+        raise NotImplementedError("a second operand that needs its own gradient takes the tensor API")
+    spec = _spec(shifts, affs0_weight, first)
+    try:
+        loss, affs, _ = LabelsAffinityMSE.apply(embedding, ema_embedding, labels, spec, _FLAGS_3D)
+    except LabelsStepUnsupported:
+        from ..utils.targets import gen_targets
+        t, _, w = gen_targets(labels, axis_offsets_3d(shifts), padding=False, both_foreground=True, want_mask=False)
+        loss, affs, _ = FusedAffinityMSE.apply(embedding, ema_embedding, t, w, None, spec)
+    return loss, affs
+
+
+def embedding_loss_norm1_from_labels(embedding, labels, criterion, affs0_weight=1, shift=1):
+    return _run_labels(embedding, None, labels, criterion, [shift] * 3, affs0_weight, 1)
+
+
+def embedding_loss_norm5_from_labels(embedding, labels, criterion, affs0_weight=1):
+    return _run_labels(embedding, None, labels, criterion, NORM5_SHIFTS, affs0_weight, 3)
+
+
+def ema_embedding_loss_norm5_from_labels(embedding, ema_embedding, labels, criterion, affs0_weight=1):
+    return _run_labels(embedding, ema_embedding, labels, criterion, NORM5_SHIFTS, affs0_weight, 3)

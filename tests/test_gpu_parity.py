@@ -699,3 +699,62 @@ def test_labels_step_matches_targets_path(pkg, dev, synth, case):
     assert relmax(g1, g0) < (2e-3 if case == "f16" else 1e-5)
     if p0 is not None:
         np.testing.assert_allclose(p1, p0, rtol=2e-6)
+
+
+def test_labels_step_3d_and_section(pkg, dev, orc, synth):
+    """3D labels-in losses (seg_to_aff(pad='') targets, both-foreground, no mask, cropped border) against gen_targets +
+    the tensor API; and the multi-scale 2D loss section from label images against the tensor section"""
+    crit = pkg.WeightedMSE()
+    B, D, Z, Y, X = 2, 16, 6, 72, 76
+    shifts = [1, 1, 1, 2, 3, 3, 3, 9, 9, 4, 27, 27]
+    offs = orc.norm_offsets(shifts)
+    lab = synth.synth_labels(B, (Z, Y, X), 101, cell=9)
+    lab_t = torch.from_numpy(lab).to(dev)
+    e = synth.synth_embedding((B, D, Z, Y, X), 102)
+    ema = cu(synth.synth_embedding((B, D, Z, Y, X), 103), dev)
+    t, _, w = pkg.gen_targets(lab_t, offs, padding=False, both_foreground=True, want_mask=False)
+    for use_ema in (False, True):
+        res = []
+        for labels_in in (False, True):
+            et = cu(e, dev).requires_grad_(True)
+            if labels_in:
+                loss, affs = (pkg.ema_embedding_loss_norm5_from_labels(et, ema, lab_t, crit, affs0_weight=2) if use_ema
+                              else pkg.embedding_loss_norm5_from_labels(et, lab_t, crit, affs0_weight=2))
+            else:
+                loss, affs = (pkg.ema_embedding_loss_norm5(et, ema, t, w, crit, affs0_weight=2) if use_ema
+                              else pkg.embedding_loss_norm5(et, t, w, crit, affs0_weight=2))
+            (loss * 0.5).backward()
+            res.append((loss.item(), affs.cpu().numpy(), et.grad.cpu().numpy()))
+        (l0, a0, g0), (l1, a1, g1) = res
+        assert abs(l1 - l0) <= 2e-6 * abs(l0)
+        assert np.abs(a1 - a0).max() < 2e-6
+        assert relmax(g1, g0) < 1e-5
+    # multi-scale section
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    nb_half, B, D, H, W = 2, 2, 16, 96, 96
+    labf = synth.synth_labels(B, (1, H, W), 105, cell=12)[:, 0]
+    lab_downs = [np.ascontiguousarray(labf[:, ::2 ** (j + 1), ::2 ** (j + 1)]) for j in range(4)]
+    e0 = synth.synth_embedding((B, D, H, W), 106)
+    emds = [synth.synth_embedding((B, D, H >> (j + 1), W >> (j + 1)), 107 + j) for j in range(4)]
+    ema2 = cu(synth.synth_embedding((B, D, H, W), 111), dev)
+    labf_t, lab_downs_t = torch.from_numpy(labf).to(dev), [torch.from_numpy(x).to(dev) for x in lab_downs]
+    out = []
+    for labels_in in (False, True):
+        et = cu(e0, dev).requires_grad_(True)
+        emd_t = [cu(x, dev).requires_grad_(True) for x in emds]
+        if labels_in:
+            loss, pred, _ = pkg.cvppp_loss_section_from_labels(et, emd_t, ema2, labf_t, lab_downs_t, crit, offsets, nb_half, deep_weight=2)
+        else:
+            tt, mm, ww = pkg.gen_targets(labf_t, offsets, padding=True)
+            downs = []
+            for j in range(4):
+                k = nb_half * (4 - j)
+                tj, mj, wj = pkg.gen_targets(lab_downs_t[j], offsets[:k], padding=True)
+                downs.append(torch.cat([tj, wj, mj.float()], dim=1))
+            loss, pred, _ = pkg.cvppp_loss_section(et, emd_t, ema2, tt, ww, mm, downs, crit, offsets, nb_half, deep_weight=2)
+        loss.backward()
+        out.append((loss.item(), pred.cpu().numpy(), [et.grad.cpu().numpy()] + [x.grad.cpu().numpy() for x in emd_t]))
+    assert abs(out[1][0] - out[0][0]) <= 2e-6 * abs(out[0][0])
+    assert np.abs(out[1][1] - out[0][1]).max() < 2e-6
+    for a, b in zip(out[1][2], out[0][2]):
+        assert relmax(a, b) < 1e-5
