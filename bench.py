@@ -164,9 +164,10 @@ def main():
         # the labels-in training step (embedding_loss_from_labels): same outputs from the int32 label image, no t / w / m
         lab = torch.from_numpy(synth.synth_labels(B, (1, H, W), 555 + rank)[:, 0].copy()).to(dev)
         wtab = torch.empty(B * K * 2, device=dev)
-        cnt = torch.empty(B * K, dtype=torch.int32, device=dev)
+        cnt_bytes = L.pea_targets_workspace_bytes(ctypes.byref(desc))
+        cnt = torch.empty(cnt_bytes // 4, dtype=torch.int32, device=dev)
         lflags = pkg._lib.TGT_PADDING | pkg._lib.TGT_MASK_INSIDE
-        labels_step = lambda: (L.pea_label_weights(ctypes.byref(desc), P(lab), lflags, P(wtab), P(cnt), B * K * 4, st),
+        labels_step = lambda: (L.pea_label_weights(ctypes.byref(desc), P(lab), lflags, P(wtab), P(cnt), cnt_bytes, st),
                                L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(Ed), None, P(lab), P(wtab), lflags, P(affs),
                                                              P(lossv), None, P(dE), P(work), wsb, st))
         kt = {}

@@ -230,75 +230,81 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fused_labels(const KParams P, con
 }
 
 // counts of positive targets per (image, channel) straight from the labels (no target tensor), then the weight table
+// 2D mapping (no index divisions): a workgroup is 4 waves = 4 rows x 64 columns, every lane walks kCntRows rows spaced 4
+// apart; grid = (ceil(X / 64), ceil(Y / (4 * kCntRows)), B * Z).  Counts go wave ballot -> LDS -> one partial per
+// (workgroup, channel) in the workspace, summed in a fixed order by k_weight_table: no global atomics, no memset (one
+// atomic per 256 pixels and channel onto B*K addresses cost 90 us at the bench shape).
+constexpr int kCntRows = 8;
 __global__ __launch_bounds__(256) void k_label_counts(const GParams G, const int32_t* __restrict__ labels,
                                                       unsigned* __restrict__ counts) {
-  // NIT pixels per lane, decoded once; per channel NIT independent neighbour loads in flight; counts go wave ballot ->
-  // LDS -> K global atomics per workgroup (one atomic per 256 pixels and channel onto B*K addresses cost 90 us)
   __shared__ unsigned s_cnt[PEA_MAX_K];
-  constexpr int NIT = kTgtNit;
-  const int b = blockIdx.y;
+  constexpr int NIT = kCntRows, CH = 4;  // CH * NIT independent neighbour loads in flight per lane
+  const int b = blockIdx.z / G.Z, z = blockIdx.z - b * G.Z;
   if (threadIdx.x < PEA_MAX_K) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  const int yx = G.Y * G.X;
   const int32_t* lb = labels + (size_t)b * G.S;
   const bool pad = G.flags & PEA_TGT_PADDING, fg = G.flags & PEA_TGT_BOTH_FOREGROUND;
-  int pp[NIT], pz[NIT], py[NIT], px[NIT], pa[NIT];
+  const int x = blockIdx.x * 64 + (int)(threadIdx.x & 63);
+  const int ybase = blockIdx.y * (4 * NIT) + (int)(threadIdx.x >> 6);
+  const bool xin = x < G.X;
+  int pa[NIT];
 #pragma unroll
   for (int j = 0; j < NIT; ++j) {
-    const int p = (blockIdx.x * NIT + j) * 256 + (int)threadIdx.x;
-    const bool live = p < G.S;
-    pp[j] = live ? p : -1;
-    pz[j] = live ? p / yx : 0;
-    const int r = live ? p - pz[j] * yx : 0;
-    py[j] = r / G.X;
-    px[j] = r - py[j] * G.X;
-    pa[j] = live ? lb[p] : 0;
+    const int y = ybase + 4 * j;
+    pa[j] = (xin && y < G.Y) ? lb[(z * G.Y + y) * G.X + x] : 0;
   }
-  constexpr int CH = 4;  // channels per step: CH * NIT independent neighbour loads in flight per lane
   for (int i0 = 0; i0 < G.K; i0 += CH) {
     int nb[CH][NIT];
     bool in[CH][NIT];
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
       const int i = min(i0 + u, G.K - 1);
-      const int oz = G.off[i][0], oy = G.off[i][1], ox = G.off[i][2];
+      const int zz = z + G.off[i][0], oy = G.off[i][1], xx = x + G.off[i][2];
+      const bool zx = xin && (unsigned)zz < (unsigned)G.Z && (unsigned)xx < (unsigned)G.X;
+      const int base = (zx ? zz * G.Y : 0) * G.X + (zx ? xx : 0);
 #pragma unroll
       for (int j = 0; j < NIT; ++j) {
-        const int zz = pz[j] + oz, yy = py[j] + oy, xx = px[j] + ox;
-        in[u][j] = pp[j] >= 0 && (unsigned)zz < (unsigned)G.Z && (unsigned)yy < (unsigned)G.Y && (unsigned)xx < (unsigned)G.X;
-        nb[u][j] = lb[in[u][j] ? (zz * G.Y + yy) * G.X + xx : 0];
+        const int yy = ybase + 4 * j + oy;
+        in[u][j] = zx && ybase + 4 * j < G.Y && (unsigned)yy < (unsigned)G.Y;
+        nb[u][j] = lb[in[u][j] ? base + yy * G.X : 0];
       }
     }
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
-      const int i = i0 + u;
-      const bool on = i < G.K;  // uniform
       unsigned c = 0;
 #pragma unroll
       for (int j = 0; j < NIT; ++j) {
+        const bool live = xin && ybase + 4 * j < G.Y;
         const bool t = in[u][j] ? (pa[j] == nb[u][j] && (!fg || (pa[j] > 0 && nb[u][j] > 0))) : pad;
-        c += (unsigned)__popcll(__ballot(pp[j] >= 0 && t));
+        c += (unsigned)__popcll(__ballot(live && t));
       }
-      if (on && (threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt[i], c);
+      if (i0 + u < G.K && (threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt[i0 + u], c);
     }
   }
   __syncthreads();
-  if (threadIdx.x < G.K && s_cnt[threadIdx.x]) atomicAdd(&counts[b * G.K + threadIdx.x], s_cnt[threadIdx.x]);
+  // partials [b][k][workgroup of this image]
+  const int per_img = (int)(gridDim.x * gridDim.y) * G.Z, wg = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * G.Z + z;
+  if (threadIdx.x < G.K) counts[((size_t)b * G.K + threadIdx.x) * per_img + wg] = s_cnt[threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void k_weight_table(int n, int S, const unsigned* __restrict__ counts, float* __restrict__ wtab) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const unsigned c = counts[i];
-  float wpos = 1.f, wneg = 1.f;
-  if (c != 0 && c != (unsigned)S) {
-    double f = (double)c / (double)S;
-    f = fmin(fmax(f, 5e-2), 0.99);
-    if (f > 0.5) wneg = (float)(f / (1.0 - f));
-    else wpos = (float)((1.0 - f) / f);
+// one wave per (image, channel): fixed-order integer sum of the workgroup partials, then the two weights
+__global__ __launch_bounds__(64) void k_weight_table(int S, int per_img, const unsigned* __restrict__ parts, float* __restrict__ wtab) {
+  const int i = blockIdx.x;
+  unsigned c = 0;
+  for (int k = threadIdx.x; k < per_img; k += 64) c += parts[(size_t)i * per_img + k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if (threadIdx.x == 0) {
+    float wpos = 1.f, wneg = 1.f;
+    if (c != 0 && c != (unsigned)S) {
+      double f = (double)c / (double)S;
+      f = fmin(fmax(f, 5e-2), 0.99);
+      if (f > 0.5) wneg = (float)(f / (1.0 - f));
+      else wpos = (float)((1.0 - f) / f);
+    }
+    wtab[2 * i] = wpos;
+    wtab[2 * i + 1] = wneg;
   }
-  wtab[2 * i] = wpos;
-  wtab[2 * i + 1] = wneg;
 }
 
 }  // namespace pea

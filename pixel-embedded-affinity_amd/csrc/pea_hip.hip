@@ -695,7 +695,9 @@ int pea_fill_border_relu(float* affs, int B, int K, int Z, int Y, int X, int shi
 
 size_t pea_targets_workspace_bytes(const PeaDesc* desc) {
   if (validate(desc)) return 0;
-  return (size_t)desc->B * desc->K * sizeof(unsigned);
+  // pea_gen_targets: one count per (image, channel); pea_label_weights: one partial per (image, channel, workgroup)
+  const size_t wgs = (size_t)((desc->dims[2] + 63) / 64) * ((desc->dims[1] + 4 * kCntRows - 1) / (4 * kCntRows)) * desc->dims[0];
+  return (size_t)desc->B * desc->K * sizeof(unsigned) * std::max<size_t>(1, wgs);
 }
 
 int pea_gen_targets(const PeaDesc* desc, const int32_t* labels, unsigned flags, float* target, uint8_t* mask, float* weight,
@@ -753,9 +755,8 @@ int pea_label_weights(const PeaDesc* desc, const int32_t* labels, unsigned flags
   if (!labels || !wtab) return PEA_E_NULL;
   if (misaligned(labels, 4) || misaligned(wtab, 4) || misaligned(workspace, 4)) return PEA_E_ALIGN;
   if (flags & ~(PEA_TGT_PADDING | PEA_TGT_BOTH_FOREGROUND | PEA_TGT_MASK_INSIDE)) return PEA_E_DESC;
-  const size_t need = (size_t)desc->B * desc->K * sizeof(unsigned);
+  const size_t need = pea_targets_workspace_bytes(desc);
   if (!workspace || workspace_bytes < need) return PEA_E_WORKSPACE;
-  if (desc->B > 65535) return PEA_E_UNSUPPORTED;
   GParams G;
   G.B = desc->B; G.Z = desc->dims[0]; G.Y = desc->dims[1]; G.X = desc->dims[2]; G.K = desc->K;
   G.S = G.Z * G.Y * G.X;
@@ -763,12 +764,12 @@ int pea_label_weights(const PeaDesc* desc, const int32_t* labels, unsigned flags
   for (int i = 0; i < PEA_MAX_K; ++i)
     for (int a = 0; a < 3; ++a) G.off[i][a] = i < desc->K ? desc->offsets[i][a] : 0;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(workspace, 0, need, s) != hipSuccess) return hip_rc();
-  const unsigned chunks = (unsigned)((G.S + 255) / 256);
-  const unsigned gx = (chunks + kTgtNit - 1) / kTgtNit;
-  hipLaunchKernelGGL(k_label_counts, dim3(gx, (unsigned)G.B), dim3(256), 0, s, G, labels, (unsigned*)workspace);
+  if ((long long)G.B * G.Z > 65535 || (G.Y + 4 * kCntRows - 1) / (4 * kCntRows) > 65535) return PEA_E_UNSUPPORTED;
+  const dim3 cgrid((unsigned)((G.X + 63) / 64), (unsigned)((G.Y + 4 * kCntRows - 1) / (4 * kCntRows)), (unsigned)(G.B * G.Z));
+  hipLaunchKernelGGL(k_label_counts, cgrid, dim3(256), 0, s, G, labels, (unsigned*)workspace);
+  const int per_img = (int)(cgrid.x * cgrid.y) * G.Z;
   const int n = G.B * G.K;
-  hipLaunchKernelGGL(k_weight_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, G.S, (const unsigned*)workspace, wtab);
+  hipLaunchKernelGGL(k_weight_table, dim3((unsigned)n), dim3(64), 0, s, G.S, per_img, (const unsigned*)workspace, wtab);
   return hip_rc();
 }
 

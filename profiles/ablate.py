@@ -39,8 +39,8 @@ for shifts in ([1, 3, 5, 9, 27], [1, 3, 5, 9], [27], [1], [1, 3, 5, 9, 11, 13], 
     bwd = lambda: L.pea_affinity_bwd(ctypes.byref(desc), P(E), None, P(G), P(one), P(dE), None, st)
     inf = lambda: L.pea_affinity_infer(ctypes.byref(desc), P(E), None, P(affs), st)
     LAB = torch.from_numpy(synth.synth_labels(B, (1, H, W), 555)[:, 0].copy()).to(dev)
-    WTAB = torch.empty(B * K * 2, device=dev); CNT = torch.empty(B * K, dtype=torch.int32, device=dev)
-    assert L.pea_label_weights(ctypes.byref(desc), P(LAB), 5, P(WTAB), P(CNT), B * K * 4, st) == 0
+    WTAB = torch.empty(B * K * 2, device=dev); CNTB = L.pea_targets_workspace_bytes(ctypes.byref(desc)); CNT = torch.empty(CNTB // 4, dtype=torch.int32, device=dev)
+    assert L.pea_label_weights(ctypes.byref(desc), P(LAB), 5, P(WTAB), P(CNT), CNTB, st) == 0
     lab = lambda: L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(E), None, P(LAB), P(WTAB), 5, P(affs), P(lossv), None, P(dE), P(work), wsb, st)
     fwd()
     print("shifts %-22s K=%2d  fwd %6.1f  bwd %6.1f  inf %6.1f  labels-step %6.1f us" % (shifts, K, timed(fwd), timed(bwd), timed(inf), timed(lab)), flush=True)

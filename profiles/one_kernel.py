@@ -35,11 +35,12 @@ P = lambda x: ctypes.c_void_p(x.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 LAB = torch.from_numpy(synth.synth_labels(B, (1, H, W), 555)[:, 0].copy()).to(dev)
 WTAB = torch.empty(B * K * 2, device=dev)
-CNT = torch.empty(B * K, dtype=torch.int32, device=dev)
-assert L.pea_label_weights(ctypes.byref(desc), P(LAB), 5, P(WTAB), P(CNT), B * K * 4, st) == 0
+CNTB = L.pea_targets_workspace_bytes(ctypes.byref(desc))
+CNT = torch.empty(CNTB // 4, dtype=torch.int32, device=dev)
+assert L.pea_label_weights(ctypes.byref(desc), P(LAB), 5, P(WTAB), P(CNT), CNTB, st) == 0
 fns = {
-    "gentgt": lambda: L.pea_gen_targets(ctypes.byref(desc), P(LAB), 1, P(T), P(M), P(Wt), P(CNT), B * K * 4, st),
-    "labw": lambda: L.pea_label_weights(ctypes.byref(desc), P(LAB), 5, P(WTAB), P(CNT), B * K * 4, st),
+    "gentgt": lambda: L.pea_gen_targets(ctypes.byref(desc), P(LAB), 1, P(T), P(M), P(Wt), P(CNT), CNTB, st),
+    "labw": lambda: L.pea_label_weights(ctypes.byref(desc), P(LAB), 5, P(WTAB), P(CNT), CNTB, st),
     "labels": lambda: L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(E), None, P(LAB), P(WTAB), 5, P(affs), P(lossv), None, P(dE), P(work), wsb, st),
     "fused": lambda: L.pea_affinity_fwd_bwd(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), P(lossv), None, P(dE), P(work), wsb, st),
     "fwd": lambda: L.pea_affinity_fwd(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), P(G), P(lossv), P(work), wsb, st),
