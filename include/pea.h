@@ -32,6 +32,7 @@
  *   a_i(p)  = < ehat(p), ehat_other(p + o_i) >          (ehat_other = ehat when e_other == NULL)
  *   border CIRCULAR : p + o_i taken modulo (Y, X)   (torch.roll, 2D reference path)
  *   border CROP_ZERO: a_i(p) = 0 and no loss where p + o_i leaves the volume (3D reference path)
+ *   border REPLICATE: p + o_i clamped into the volume (embedding_loss_norm6; every pair exists)
  *   r_i(p)  = a_i(p) * m_i(p) - t_i(p) * m_i(p)
  *   L_i     = sum_{b,p} w_i(p) * r_i(p)^2 / N_i ,   loss = sum_i lambda_i * L_i
  *   N_i     = B * X                      (PEA_NORM_BX: the 2D WeightedMSE quirk, pred is [B,H,W])
@@ -54,6 +55,8 @@ extern "C" {
 /* border modes */
 #define PEA_BORDER_CIRCULAR 0
 #define PEA_BORDER_CROP_ZERO 1
+#define PEA_BORDER_REPLICATE 2 /* neighbour index clamped into the volume (nn.ReplicationPad3d + slice: shift_tensor,
+                                  scripts_ac3ac4/loss/loss_embedding_mse.py:294-344; embedding_loss_norm6 :346-354) */
 /* storage dtype of e / de (arithmetic is always f32) */
 #define PEA_F32 0
 #define PEA_F16 1

@@ -55,6 +55,10 @@ static inline long neighbour(const PeaDesc *d, const Geo *g, long z, long y, lon
     zz %= g->Z; if (zz < 0) zz += g->Z;
     yy %= g->Y; if (yy < 0) yy += g->Y;
     xx %= g->X; if (xx < 0) xx += g->X;
+  } else if (d->border == PEA_BORDER_REPLICATE) { /* shift_tensor: ReplicationPad3d then slice = clamp the index */
+    zz = zz < 0 ? 0 : (zz >= g->Z ? g->Z - 1 : zz);
+    yy = yy < 0 ? 0 : (yy >= g->Y ? g->Y - 1 : yy);
+    xx = xx < 0 ? 0 : (xx >= g->X ? g->X - 1 : xx);
   } else {
     if (zz < 0 || zz >= g->Z || yy < 0 || yy >= g->Y || xx < 0 || xx >= g->X) return -1;
   }
@@ -176,6 +180,54 @@ int pea_oracle_bwd(const PeaDesc *d, const float *e, const float *e_other, const
   float scale[PEA_MAX_K];
   for (int i = 0; i < d->K; ++i) scale[i] = (float)(2.0 * dloss * d->lambda[i] / norm_term(d, &g, i));
   const int self = (e_other == NULL);
+
+  if (d->border == PEA_BORDER_REPLICATE) {
+    /* A clamped index is not invertible (several p share one neighbour), so this border is restated in SCATTER form,
+     * sequentially: every pair (p, q = clamp(p + o_i)) adds g * ehat_other(q) to the first operand's G at p and
+     * g * ehat(p) to the second operand's G at q; then both go through F.normalize's Jacobian. */
+    const size_t n = (size_t)d->B * d->D * g.S;
+    float *G1 = (float *)calloc(n, sizeof(float));
+    float *G2 = (float *)calloc(n, sizeof(float));
+    if (!G1 || !G2) return PEA_E_WORKSPACE;
+    for (long b = 0; b < d->B; ++b)
+      for (int i = 0; i < d->K; ++i)
+        for (long z = 0; z < g.Z; ++z)
+          for (long y = 0; y < g.Y; ++y)
+            for (long x = 0; x < g.X; ++x) {
+              long p = (z * g.Y + y) * g.X + x;
+              long q = neighbour(d, &g, z, y, x, d->offsets[i], +1);
+              float gi = gval(d, &g, eh, oh, target, weight, mask, b, i, p, q, scale[i]);
+              for (long c = 0; c < d->D; ++c) {
+                G1[((size_t)b * d->D + c) * g.S + p] += gi * oh[((size_t)b * d->D + c) * g.S + q];
+                G2[((size_t)b * d->D + c) * g.S + q] += gi * eh[((size_t)b * d->D + c) * g.S + p];
+              }
+            }
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1 && (self || !de_other)) break;
+      const float *src = pass == 0 ? e : e_other;
+      const float *sh = pass == 0 ? eh : oh;
+      float *dst = pass == 0 ? de : de_other;
+      for (long b = 0; b < d->B; ++b)
+        for (long p = 0; p < g.S; ++p) {
+          float ss = 0.f, dot = 0.f, Gc[256];
+          for (long c = 0; c < d->D; ++c) {
+            size_t o = ((size_t)b * d->D + c) * g.S + p;
+            Gc[c] = pass == 0 ? (self ? G1[o] + G2[o] : G1[o]) : G2[o];
+            ss += src[o] * src[o];
+            dot += sh[o] * Gc[c];
+          }
+          float nn = sqrtf(ss);
+          for (long c = 0; c < d->D; ++c) {
+            size_t o = ((size_t)b * d->D + c) * g.S + p;
+            dst[o] = nn < d->eps ? Gc[c] / d->eps : (Gc[c] - sh[o] * dot) / nn;
+          }
+        }
+    }
+    free(G1); free(G2);
+    if (oh != eh) free(oh);
+    free(eh);
+    return PEA_OK;
+  }
 
   for (int pass = 0; pass < 2; ++pass) {
     /* pass 0: gradient w.r.t. e (first operand); pass 1: w.r.t. e_other */

@@ -25,7 +25,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 PEA_MAX_K = 32
 ABI = 1
-BORDER_CIRCULAR, BORDER_CROP_ZERO = 0, 1
+BORDER_CIRCULAR, BORDER_CROP_ZERO, BORDER_REPLICATE = 0, 1, 2
 NORM_BX, NORM_CROPPED, NORM_FULL = 0, 1, 2
 FLAG_RELU = 1
 NORM5_SHIFTS = [1, 1, 1, 2, 3, 3, 3, 9, 9, 4, 27, 27]  # ac34/loss/loss_embedding_mse.py:176
@@ -177,6 +177,13 @@ def desc_2d(e, offsets, lam=None, mode="ours", relu=False):
 def desc_3d(e, shifts, lam=None):
     B, D, Z, Y, X = e.shape
     return make_desc(B, D, [Z, Y, X], norm_offsets(shifts), lam, BORDER_CROP_ZERO, NORM_CROPPED, 1e-12, 0, ndim=3)
+
+
+def desc_3d_replicate(e, offsets):
+    """embedding_loss_norm6 (scripts_ac3ac4/loss/loss_embedding_mse.py:346-354): generic offsets, replicate border, one
+    WeightedMSE over the [B,K,Z,Y,X] map (normaliser B*Z*Y*X, loss.py:113-115), lambda = 1"""
+    B, D, Z, Y, X = e.shape
+    return make_desc(B, D, [Z, Y, X], [list(o) for o in offsets], None, BORDER_REPLICATE, NORM_FULL, 1e-12, 0, ndim=3)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@ from .loss.loss import WeightedMSE
 from .loss.loss_embedding_mse import (ema_embedding_loss, ema_embedding_loss_from_labels, embedding2affs, embedding_loss,
                                       embedding_loss_from_labels)
 from .loss.loss_embedding_mse_3d import (ema_embedding_loss_norm1, ema_embedding_loss_norm5, ema_embedding_loss_norm5_from_labels,
+                                         ema_embedding_loss_norm6, embedding_loss_norm6,
                                          embedding_loss_norm1, embedding_loss_norm1_from_labels, embedding_loss_norm5,
                                          embedding_loss_norm5_from_labels, inf_embedding_loss_norm1, inf_embedding_loss_norm5)
 from .utils.affinity_ours import gen_offsets, multi_offset
@@ -33,4 +34,5 @@ __all__ = [
     "deep_weight_factor", "finish_pred_2d_", "finish_pred_3d_", "gen_targets", "gen_affs_ours", "VolumeStitcher", "embedding_loss_from_labels",
     "ema_embedding_loss_from_labels", "LabelsAffinityMSE", "cvppp_loss_section_from_labels",
     "embedding_loss_norm1_from_labels", "embedding_loss_norm5_from_labels", "ema_embedding_loss_norm5_from_labels",
+    "embedding_loss_norm6", "ema_embedding_loss_norm6",
 ]

@@ -17,7 +17,7 @@ HEADER = os.path.join(HERE, "..", "include", "pea.h")
 PEA_ABI_VERSION = 1
 PEA_MAX_K = 32
 E_UNSUPPORTED = -3
-BORDER_CIRCULAR, BORDER_CROP_ZERO = 0, 1
+BORDER_CIRCULAR, BORDER_CROP_ZERO, BORDER_REPLICATE = 0, 1, 2
 F32, F16 = 0, 1
 NORM_BX, NORM_CROPPED, NORM_FULL = 0, 1, 2
 FLAG_RELU_AFFS = 1

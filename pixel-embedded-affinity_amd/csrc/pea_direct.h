@@ -48,6 +48,15 @@ __device__ __forceinline__ int logical_tile(const KParams& P) {
   return (bid % kXcd) * P.tiles_per_xcd + bid / kXcd;
 }
 
+// REPLICATE, role B: the coordinates c' along one axis (extent n) with clamp(c' + o) == c, as [lo, hi] (empty: lo > hi).
+// Interior c has the one pre-image c - o; a border coordinate collects every c' that the clamp folds onto it.
+__device__ __forceinline__ void clamp_preimage(int c, int o, int n, int& lo, int& hi) {
+  lo = hi = c - o;
+  if (o < 0 && c == 0) { lo = 0; hi = min(-o, n - 1); }
+  else if (o > 0 && c == n - 1) { lo = max(n - 1 - o, 0); hi = n - 1; }
+  else if (lo < 0 || lo > n - 1) { lo = 1; hi = 0; }
+}
+
 // neighbour of (z,y,x) displaced by o; returns flat index or -1 (CROP_ZERO, outside)
 __device__ __forceinline__ int neighbour(const KParams& P, int z, int y, int x, int oz, int oy, int ox) {
   int zz = z + oz, yy = y + oy, xx = x + ox;
@@ -55,6 +64,10 @@ __device__ __forceinline__ int neighbour(const KParams& P, int z, int y, int x, 
     zz += (zz < 0) ? P.Z : 0; zz -= (zz >= P.Z) ? P.Z : 0;
     yy += (yy < 0) ? P.Y : 0; yy -= (yy >= P.Y) ? P.Y : 0;
     xx += (xx < 0) ? P.X : 0; xx -= (xx >= P.X) ? P.X : 0;
+  } else if (P.border == PEA_BORDER_REPLICATE) {  // index clamped into the volume: every pair exists
+    zz = min(max(zz, 0), P.Z - 1);
+    yy = min(max(yy, 0), P.Y - 1);
+    xx = min(max(xx, 0), P.X - 1);
   } else if ((unsigned)zz >= (unsigned)P.Z || (unsigned)yy >= (unsigned)P.Y || (unsigned)xx >= (unsigned)P.X) {
     return -1;
   }
@@ -252,9 +265,31 @@ __global__ __launch_bounds__(kBlock) void k_bwd_direct(const KParams P, const T*
     for (int role = 0; role < 2; ++role) {
       if (role == 0 ? !ROLE_A : !ROLE_B) continue;
       const int sg = role == 0 ? 1 : -1;
+      const T* nb = (role == 0 ? nbA : nbB) + (size_t)b * D_T * S;
+      if (role == 1 && P.border == PEA_BORDER_REPLICATE) {
+        // the clamp is not invertible: gather from EVERY first-operand pixel p' whose clamped neighbour is this pixel
+        int z0, z1, y0, y1, x0, x1;
+        clamp_preimage(z, oz, P.Z, z0, z1);
+        clamp_preimage(y, oy, P.Y, y0, y1);
+        clamp_preimage(x, ox, P.X, x0, x1);
+        for (int zz = z0; zz <= z1; ++zz)
+          for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) {
+              const int q2 = (zz * P.Y + yy) * P.X + xx;
+              float v2[D_T], sq2 = 0.f;
+#pragma unroll
+              for (int c = 0; c < D_T; ++c) {
+                v2[c] = ld(nb, c * S + q2);
+                sq2 = fmaf(v2[c], v2[c], sq2);
+              }
+              const float g2 = gb[(size_t)i * S + q2] * inv_norm(sq2, P.eps);
+#pragma unroll
+              for (int c = 0; c < D_T; ++c) G[c] = fmaf(g2, v2[c], G[c]);
+            }
+        continue;
+      }
       const int q = neighbour(P, z, y, x, sg * oz, sg * oy, sg * ox);
       if (q < 0) continue;
-      const T* nb = (role == 0 ? nbA : nbB) + (size_t)b * D_T * S;
       float v[D_T], sq = 0.f;
 #pragma unroll
       for (int c = 0; c < D_T; ++c) {

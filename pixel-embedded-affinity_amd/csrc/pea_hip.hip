@@ -44,7 +44,7 @@ int validate(const PeaDesc* d) {
   for (int a = 0; a < 3; ++a)
     if (d->dims[a] < 1) return PEA_E_DESC;
   if (d->ndim == 2 && d->dims[0] != 1) return PEA_E_DESC;
-  if (d->border != PEA_BORDER_CIRCULAR && d->border != PEA_BORDER_CROP_ZERO) return PEA_E_DESC;
+  if (d->border != PEA_BORDER_CIRCULAR && d->border != PEA_BORDER_CROP_ZERO && d->border != PEA_BORDER_REPLICATE) return PEA_E_DESC;
   if (d->dtype != PEA_F32 && d->dtype != PEA_F16) return PEA_E_DESC;
   if (d->norm < PEA_NORM_BX || d->norm > PEA_NORM_FULL) return PEA_E_DESC;
   if (!(d->eps > 0.f)) return PEA_E_DESC;
@@ -139,6 +139,7 @@ constexpr int kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup ma
 // Choose the "near" offsets (served from LDS): the largest in-plane radius whose halo'd region still fits the
 // LDS planes of this tile shape.  both_sides: the backward needs p - o as well as p + o.
 bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, TParams* Q) {
+  if (P.border == PEA_BORDER_REPLICATE) return false;  // direct kernels only (row a-15: an unused variant of the reference)
   if ((long long)P.Y * P.X >= (1LL << 29)) return false;                     // plane byte offsets stay below 2^31 (kOOB)
   if ((long long)std::max(P.D, P.K) * P.S * 4 > 0xFFFFFFFFLL) return false;  // buffer soffset is 32-bit
   const int NT = c.TH * c.TW;

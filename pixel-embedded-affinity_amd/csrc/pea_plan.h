@@ -81,7 +81,7 @@ inline unsigned magic_div(int d) { return d == 1 ? 0u : (unsigned)(0x100000000UL
 
 // roles: bit 0 = A, bit 1 = B.  self: the neighbour tensor is x itself.  ncu: compute units of the device.
 inline bool plan_phased(const KParams& P, int roles, bool self, size_t esize, int ncu, MParams* out) {
-  if (P.D != 16 || P.X % 4) return false;
+  if (P.D != 16 || P.X % 4 || P.border == PEA_BORDER_REPLICATE) return false;
   if ((long long)P.D * P.S * (long long)esize >= 0x7fffffffLL) return false;  // per-lane byte offsets carry the channel
   if ((long long)P.K * P.S * 4 > 0xFFFFFFFFLL) return false;                   // scalar plane offsets are 32-bit
   std::vector<PlanPair> pr;

@@ -72,6 +72,32 @@ def inf_embedding_loss_norm5(embedding):
     return affinity_infer(embedding, None, _spec(NORM5_SHIFTS, 1, 3))
 
 
+# ---- norm6: generic offsets with a replicate border (reference :346-366; not selected by any shipped yaml) ----
+def _spec6(offsets):
+    return AffinitySpec(3, offsets, None, _lib.BORDER_REPLICATE, _lib.NORM_FULL, 1e-12)
+
+
+def _run6(embedding, ema_embedding, target, weightmap, criterion, offsets):
+    spec = _spec6(offsets)
+    if getattr(criterion, 'pea_fused', False):
+        # ONE criterion call over the [B,K,Z,Y,X] map: WeightedMSE's normaliser is B*Z*Y*X (loss.py:113-115)
+        loss, affs, _ = FusedAffinityMSE.apply(embedding, ema_embedding, target, weightmap, None, spec)
+        return loss, affs
+    affs = AffinityMap.apply(embedding, ema_embedding, spec)
+    return criterion(affs, target, weightmap), affs
+
+
+def embedding_loss_norm6(embedding, target, weightmap, criterion, affs0_weight=1, shift=1, fill=True):
+    """-> (loss, affs [B,K,Z,Y,X]); `shift` is the LIST of 3D offsets (the reference's naming, :348); a_i(p) =
+    <ehat(p), ehat(clamp(p + o_i))> (shift_tensor with replication padding, :294-344)"""
+    return _run6(embedding, None, target, weightmap, criterion, shift)
+
+
+def ema_embedding_loss_norm6(embedding, ema_embedding, target, weightmap, criterion, affs0_weight=1, shift=1, fill=True):
+    """reference :356-366: the EMA embedding is the shifted operand"""
+    return _run6(embedding, ema_embedding, target, weightmap, criterion, shift)
+
+
 # ---- the same losses straight from the segmentation (no target / weightmap tensors; SURVEY.md section 8f, f2) ----
 # targets as the 12-channel provider builds them: seg_to_aff(lb, nhood, pad='') (scripts_ac3ac4/data/data_affinity.py:53-102,
 # data_provider_labeled_deep.py:253-256): 1 iff both voxels carry the same label > 0, 0 in the border slices; weights =

@@ -180,6 +180,29 @@ def case_3d(name, seed, B, D, Z, Y, X, which, affs0_weight=1, shift=1, ema=False
          grad=et.grad.numpy(), **kw)
 
 
+def case_3d_norm6(name, seed, B, D, Z, Y, X, offsets, ema=False, both=False):
+    """embedding_loss_norm6 / ema_embedding_loss_norm6 (scripts_ac3ac4/loss/loss_embedding_mse.py:346-366): generic 3D
+    offsets, replicate-padded shifts (shift_tensor :294-344), ONE criterion call over all channels."""
+    rng = np.random.default_rng(seed)
+    K = len(offsets)
+    e = rng.standard_normal((B, D, Z, Y, X)).astype(np.float32)
+    t, w = targets_3d(rng, B, K, Z, Y, X)
+    et = T(e).requires_grad_(True)
+    kw = {}
+    if ema:
+        em = (e + 0.5 * rng.standard_normal(e.shape)).astype(np.float32)
+        mt = T(em).requires_grad_(both)
+        loss, affs = ref3d.ema_embedding_loss_norm6(et, mt, T(t), T(w), criterion, shift=[list(o) for o in offsets])
+        kw["ema"] = em
+    else:
+        loss, affs = ref3d.embedding_loss_norm6(et, T(t), T(w), criterion, shift=[list(o) for o in offsets])
+    loss.backward()
+    if ema and both:
+        kw["grad_ema"] = mt.grad.numpy()
+    save(name, kind="3d_norm6" + ("_ema" if ema else ""), e=e, target=t, weight=w, offsets=np.asarray(offsets, np.int32),
+         loss=np.float32(loss.item()), affs=affs.detach().numpy(), grad=et.grad.numpy(), **kw)
+
+
 def case_full_summary(name, seed, B, D, H, W):
     """One full-size CVPPP case (B x 16 x 544 x 544, K=10): too big to store, so inputs are a closed-form
     function of the index (no RNG) and only summary statistics + samples of the outputs are kept."""
@@ -215,6 +238,12 @@ if __name__ == "__main__":
         case_targets("gtgt_2d_nb4", 41, B=2, H=45, W=52, shifts=[1, 3, 5, 9, 27], nb=4)
         case_targets("gtgt_2d_nb8", 42, B=1, H=31, W=40, shifts=[1, 3, 9], nb=8)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "norm6":  # only the replicate-border fixtures
+        O6 = [[-1, 0, 0], [0, -1, 0], [0, 0, -1], [-2, 0, 0], [0, -3, 0], [0, 0, -3], [0, -3, 3], [1, 2, -2], [0, 9, 0]]
+        case_3d_norm6("g3r_norm6", 51, B=2, D=16, Z=5, Y=14, X=17, offsets=O6)
+        case_3d_norm6("g3r_norm6_ema", 52, B=1, D=16, Z=4, Y=12, X=13, offsets=O6, ema=True)
+        case_3d_norm6("g3r_norm6_ema_both", 53, B=1, D=8, Z=4, Y=11, X=12, offsets=O6[:6], ema=True, both=True)
+        sys.exit(0)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     # 2D, shipped CVPPP stencil (shifts 1,3,5,9,27 x neighbor 4 -> K=10), ragged sizes
@@ -240,5 +269,9 @@ if __name__ == "__main__":
     case_3d("g3d_norm5_ema", 26, B=1, D=16, Z=6, Y=30, X=31, which="norm5", affs0_weight=2, ema=True)
     case_targets("gtgt_2d_nb4", 41, B=2, H=45, W=52, shifts=[1, 3, 5, 9, 27], nb=4)
     case_targets("gtgt_2d_nb8", 42, B=1, H=31, W=40, shifts=[1, 3, 9], nb=8)
+    O6 = [[-1, 0, 0], [0, -1, 0], [0, 0, -1], [-2, 0, 0], [0, -3, 0], [0, 0, -3], [0, -3, 3], [1, 2, -2], [0, 9, 0]]
+    case_3d_norm6("g3r_norm6", 51, B=2, D=16, Z=5, Y=14, X=17, offsets=O6)
+    case_3d_norm6("g3r_norm6_ema", 52, B=1, D=16, Z=4, Y=12, X=13, offsets=O6, ema=True)
+    case_3d_norm6("g3r_norm6_ema_both", 53, B=1, D=8, Z=4, Y=11, X=12, offsets=O6[:6], ema=True, both=True)
     # full CVPPP size, summary only
     case_full_summary("g2d_full544_summary", 555, B=2, D=16, H=544, W=544)

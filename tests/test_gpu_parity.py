@@ -758,3 +758,24 @@ def test_labels_step_3d_and_section(pkg, dev, orc, synth):
     assert np.abs(out[1][1] - out[0][1]).max() < 2e-6
     for a, b in zip(out[1][2], out[0][2]):
         assert relmax(a, b) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["g3r_norm6", "g3r_norm6_ema", "g3r_norm6_ema_both"])
+def test_replicate_border_norm6_matches_reference_golden(pkg, dev, name):
+    """PEA_BORDER_REPLICATE (row a-15): embedding_loss_norm6 / ema_embedding_loss_norm6 against the reference's outputs,
+    including the border pixels whose clamped neighbour collects several pairs, and a non-detached EMA operand"""
+    g = load_golden(name)
+    offs = [list(map(int, o)) for o in g["offsets"]]
+    et = cu(g["e"], dev).requires_grad_(True)
+    crit = pkg.WeightedMSE()
+    if "ema" in g:
+        mt = cu(g["ema"], dev).requires_grad_("grad_ema" in g)
+        loss, affs = pkg.ema_embedding_loss_norm6(et, mt, cu(g["target"], dev), cu(g["weight"], dev), crit, shift=offs)
+    else:
+        loss, affs = pkg.embedding_loss_norm6(et, cu(g["target"], dev), cu(g["weight"], dev), crit, shift=offs)
+    loss.backward()
+    assert np.abs(affs.detach().cpu().numpy() - g["affs"]).max() < AFFS_ATOL
+    assert abs(loss.item() - float(g["loss"])) <= LOSS_RTOL * float(g["loss"])
+    assert relmax(et.grad.cpu().numpy(), g["grad"]) < GRAD_RTOL
+    if "grad_ema" in g:
+        assert relmax(mt.grad.cpu().numpy(), g["grad_ema"]) < GRAD_RTOL

@@ -143,3 +143,20 @@ def test_target_generation_restatement_matches_reference(name):
         assert np.array_equal(t[:, :, 0], g["target_" + tag])
         assert np.array_equal(m[:, :, 0], g["mask_" + tag])
         assert np.array_equal(orc.np_weight_binary_ratio(t[:, :, 0]), g["weight_" + tag])
+
+
+@pytest.mark.parametrize("name", ["g3r_norm6", "g3r_norm6_ema", "g3r_norm6_ema_both"])
+def test_replicate_border_restatement_matches_reference(name):
+    """embedding_loss_norm6 / ema_embedding_loss_norm6 (replicate-padded shifts, one criterion over all channels): the C
+    restatement (scatter-form backward) against the reference's loss, affinity map and autograd gradients"""
+    import oracle.pea_oracle as orc
+    g = load_golden(name)
+    e, ema = g["e"], g.get("ema")
+    d = orc.desc_3d_replicate(e, g["offsets"])
+    affs, loss = orc.c_fwd(d, e, ema, g["target"], g["weight"], None)
+    assert np.abs(affs - g["affs"]).max() < 2e-6
+    assert abs(loss[0] - float(g["loss"])) <= 3e-6 * float(g["loss"])
+    de, de_o = orc.c_bwd(d, e, ema, g["target"], g["weight"], None, want_other="grad_ema" in g)
+    assert np.abs(de - g["grad"]).max() <= 2e-5 * np.abs(g["grad"]).max()
+    if "grad_ema" in g:
+        assert np.abs(de_o - g["grad_ema"]).max() <= 2e-5 * np.abs(g["grad_ema"]).max()
