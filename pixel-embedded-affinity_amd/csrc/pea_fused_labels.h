@@ -23,7 +23,7 @@ namespace pea {
 constexpr unsigned kLabMask = PEA_TGT_MASK_INSIDE;  // mask = [neighbour inside] (the 2D path); else mask == 1 (the 3D path)
 
 template <typename T, int D_T, int TH, int TW, int PLQ, bool CROP, bool ROLE_B>
-__global__ __launch_bounds__(TH* TW, 4) void k_fused_labels(const KParams P, const TParams Q, const T* __restrict__ xt,
+__global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fused_labels(const KParams P, const TParams Q, const T* __restrict__ xt,
                                                             const T* __restrict__ nbt, const int32_t* __restrict__ labels,
                                                             const float* __restrict__ wtab, unsigned lflags,
                                                             float* __restrict__ affs, float* __restrict__ partials,

@@ -459,7 +459,7 @@ bool try_fused(const KParams& P, const T* x, const T* nb, const float* t, const 
 template <typename T, int D_T, bool RB>
 bool try_fused_labels(const KParams& P, const T* x, const T* nb, const int32_t* labels, const float* wtab, unsigned lflags,
                       float* affs, float* partials, const float* dl, T* dx, hipStream_t s, int* nparts) {
-  constexpr TileCfg c = kBwdCfg[0];
+  constexpr TileCfg c = bwd_cfg<D_T>(0);
   TParams Q;
   if (!plan_tiles(P, c, RB, &Q)) return false;
   const size_t lds = Lds<D_T, c.PLQ>::kBytes + (size_t)(c.TH * c.TW / 64) * P.K * sizeof(float);
@@ -787,20 +787,23 @@ int pea_affinity_fwd_bwd_labels(const PeaDesc* desc, const void* e, const void* 
   if (flags & ~(PEA_TGT_PADDING | PEA_TGT_BOTH_FOREGROUND | PEA_TGT_MASK_INSIDE)) return PEA_E_DESC;
   const KParams P = make_params(desc);
   if (!workspace || workspace_bytes < fwd_partials(P) * P.K * sizeof(float)) return PEA_E_WORKSPACE;
-  if (P.D != 16 || env_int("PEA_FORCE_DIRECT", 0) != 0) return PEA_E_UNSUPPORTED;
+  if ((P.D != 16 && P.D != 32) || env_int("PEA_FORCE_DIRECT", 0) != 0) return PEA_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* partials = (float*)workspace;
   int nparts = 0;
   bool done;
-  if (desc->dtype == PEA_F16) {
-    const __half *x = (const __half*)e, *nb = (const __half*)e_other;
-    done = nb ? try_fused_labels<__half, 16, false>(P, x, nb, labels, wtab, flags, affs, partials, dloss, (__half*)de, s, &nparts)
-              : try_fused_labels<__half, 16, true>(P, x, x, labels, wtab, flags, affs, partials, dloss, (__half*)de, s, &nparts);
-  } else {
-    const float *x = (const float*)e, *nb = (const float*)e_other;
-    done = nb ? try_fused_labels<float, 16, false>(P, x, nb, labels, wtab, flags, affs, partials, dloss, (float*)de, s, &nparts)
-              : try_fused_labels<float, 16, true>(P, x, x, labels, wtab, flags, affs, partials, dloss, (float*)de, s, &nparts);
+#define PEA_LAB_DISPATCH(TT, DD)                                                                                         \
+  {                                                                                                                      \
+    const TT *x = (const TT*)e, *nb = (const TT*)e_other;                                                                \
+    done = nb ? try_fused_labels<TT, DD, false>(P, x, nb, labels, wtab, flags, affs, partials, dloss, (TT*)de, s, &nparts) \
+              : try_fused_labels<TT, DD, true>(P, x, x, labels, wtab, flags, affs, partials, dloss, (TT*)de, s, &nparts);  \
   }
+  if (desc->dtype == PEA_F16) {
+    if (P.D == 16) PEA_LAB_DISPATCH(__half, 16) else PEA_LAB_DISPATCH(__half, 32)
+  } else {
+    if (P.D == 16) PEA_LAB_DISPATCH(float, 16) else PEA_LAB_DISPATCH(float, 32)
+  }
+#undef PEA_LAB_DISPATCH
   if (!done) return PEA_E_UNSUPPORTED;
   rc = hip_rc();
   if (rc) return rc;

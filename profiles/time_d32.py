@@ -22,6 +22,11 @@ dE = torch.empty_like(E); one = torch.ones((), device=dev)
 fns = {"fwd": lambda: L.pea_affinity_fwd(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), P(G), P(lossv), P(work), wsb, st),
        "bwd": lambda: L.pea_affinity_bwd(ctypes.byref(desc), P(E), None, P(G), P(one), P(dE), None, st),
        "inf": lambda: L.pea_affinity_infer(ctypes.byref(desc), P(E), None, P(affs), st)}
+LAB = torch.from_numpy(synth.synth_labels(B, (1, H, W), 555)[:, 0].copy()).to(dev)
+WTAB = torch.empty(B * K * 2, device=dev)
+CNTB = L.pea_targets_workspace_bytes(ctypes.byref(desc)); CNT = torch.empty(CNTB // 4, dtype=torch.int32, device=dev)
+assert L.pea_label_weights(ctypes.byref(desc), P(LAB), 5, P(WTAB), P(CNT), CNTB, st) == 0
+fns["labels_step"] = lambda: L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(E), None, P(LAB), P(WTAB), 5, P(affs), P(lossv), None, P(dE), P(work), wsb, st)
 fns["fwd"]()
 for name, fn in fns.items():
     for _ in range(5): fn()

@@ -661,25 +661,25 @@ def test_volume_stitcher_matches_reference_statements(pkg, dev):
     assert np.array_equal(res.cpu().numpy(), res_np)
 
 
-@pytest.mark.parametrize("case", ["self_nb4", "self_nb8", "ema", "f16"])
+@pytest.mark.parametrize("case", ["self_nb4", "self_nb8", "ema", "f16", "d32", "d32_ema"])
 def test_labels_step_matches_targets_path(pkg, dev, synth, case):
     """the labels-in training step (pea_label_weights + pea_affinity_fwd_bwd_labels) against pea_gen_targets +
     embedding_loss / ema_embedding_loss on the same label images: loss, per-offset losses, affs, gradient"""
     nb = 8 if case == "self_nb8" else 4
-    offsets = pkg.multi_offset([1, 3, 5, 9, 27] if nb == 4 else [1, 3, 9], nb)
-    B, D, H, W = 3, 16, 80, 136
+    offsets = pkg.multi_offset(([1, 3, 5, 9, 11] if case.startswith("d32") else [1, 3, 5, 9, 27]) if nb == 4 else [1, 3, 9], nb)
+    B, D, H, W = 3, (32 if case.startswith("d32") else 16), 80, 136
     lab = synth.synth_labels(B, (1, H, W), 91, cell=11)[:, 0]
     lab_t = torch.from_numpy(lab).to(dev)
     e = synth.synth_embedding((B, D, H, W), 92)
     if case == "f16":
         e = e.astype(np.float16)
-    ema = torch.from_numpy(synth.synth_embedding((B, D, H, W), 93).astype(e.dtype)).to(dev) if case == "ema" else None
+    ema = torch.from_numpy(synth.synth_embedding((B, D, H, W), 93).astype(e.dtype)).to(dev) if case.endswith("ema") else None
     crit = pkg.WeightedMSE()
     t, m, w = pkg.gen_targets(lab_t, offsets, padding=True)
 
     def run(labels_in):
         et = torch.from_numpy(e).to(dev).requires_grad_(True)
-        if case == "ema":
+        if ema is not None:
             if labels_in:
                 loss, affs = pkg.ema_embedding_loss_from_labels(et, ema, lab_t, crit, offsets, affs0_weight=2)
             else:
