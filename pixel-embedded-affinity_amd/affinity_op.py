@@ -293,7 +293,7 @@ class LabelsAffinityMSE(torch.autograd.Function):
     flags: _lib.TGT_* (2D reference path: PADDING | MASK_INSIDE; 3D: BOTH_FOREGROUND)."""
 
     @staticmethod
-    def forward(ctx, e, e_other, labels, spec, flags):
+    def forward(ctx, e, e_other, labels, spec, flags, need_affs=True):
         e_c = _embedding_arg(e, "embedding")
         o_c = None
         if e_other is not None:
@@ -308,7 +308,7 @@ class LabelsAffinityMSE(torch.autograd.Function):
         with torch.cuda.device(e_c.device):
             d = make_desc(spec, e_c)
             L = _lib.lib()
-            affs = torch.empty(kshape, dtype=torch.float32, device=e_c.device)
+            affs = torch.empty(kshape if need_affs else (0,), dtype=torch.float32, device=e_c.device)
             loss_vec = torch.empty(1 + spec.K, dtype=torch.float32, device=e_c.device)
             wtab = torch.empty(e_c.shape[0] * spec.K * 2, dtype=torch.float32, device=e_c.device)
             cb = L.pea_targets_workspace_bytes(ctypes.byref(d))
@@ -317,7 +317,7 @@ class LabelsAffinityMSE(torch.autograd.Function):
             wsb = L.pea_workspace_bytes(ctypes.byref(d))
             work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=e_c.device)
             de_unit = torch.empty_like(e_c)
-            rc = L.pea_affinity_fwd_bwd_labels(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(lab), _ptr(wtab), flags, _ptr(affs),
+            rc = L.pea_affinity_fwd_bwd_labels(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(lab), _ptr(wtab), flags, _ptr(affs) if need_affs else None,
                                                _ptr(loss_vec), None, _ptr(de_unit), _ptr(work), wsb, _stream())
             if rc == _lib.E_UNSUPPORTED:
                 raise LabelsStepUnsupported("no labels-in kernel for this descriptor (D != 16, image smaller than a tile, "
@@ -331,7 +331,7 @@ class LabelsAffinityMSE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss, _daffs, _dvec):
         if not ctx.needs_input_grad[0]:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         if ctx.de_unit is None:
             raise RuntimeError("the labels-in step hands its gradient buffer to the first backward; for a second backward "
                                "over a retained graph use gen_targets + embedding_loss")
@@ -339,4 +339,4 @@ class LabelsAffinityMSE(torch.autograd.Function):
         with torch.cuda.device(de.device):
             dl = dloss.to(device=de.device, dtype=torch.float32).contiguous()
             _lib.check(_lib.lib().pea_scale_inplace(_ptr(de), ctx.desc.dtype, de.numel(), _ptr(dl), _stream()), "pea_scale_inplace")
-        return de, None, None, None, None
+        return de, None, None, None, None, None

@@ -95,11 +95,12 @@ def cvppp_loss_section_from_labels(embedding, emds, ema_embedding, labels, label
     losses = []
     for j, (emd, lab) in enumerate(zip(emds, label_downs)):
         k = nb_half * (4 - j)
-        l, _, _ = embedding_loss_from_labels(emd, lab, criterion, offsets[:k], affs0_weight=affs0_weight, mode=dis_mode)
+        l, _, _ = embedding_loss_from_labels(emd, lab, criterion, offsets[:k], affs0_weight=affs0_weight, mode=dis_mode,
+                                             need_affs=False)  # the reference discards these maps (main.py:284-287)
         losses.append(l)
     loss_embedding, pred, _ = embedding_loss_from_labels(embedding, labels, criterion, offsets, affs0_weight=affs0_weight, mode=dis_mode)
     loss_embedding_cross, _ = ema_embedding_loss_from_labels(embedding, ema_embedding, labels, criterion, offsets,
-                                                             affs0_weight=affs0_weight, mode=dis_mode)
+                                                             affs0_weight=affs0_weight, mode=dis_mode, need_affs=False)
     loss_embedding = loss_embedding * dwf[0]
     loss_emd = [losses[j] * dwf[j + 1] for j in range(4)]
     loss_embedding_cross = loss_embedding_cross * dwf[0]

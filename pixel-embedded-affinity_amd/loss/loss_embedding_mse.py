@@ -76,28 +76,29 @@ def ema_embedding_loss(embedding, ema_embedding, target, weightmap, mask, criter
 _FLAGS_2D = _lib.TGT_PADDING | _lib.TGT_MASK_INSIDE  # gen_affs_ours(ignore=False, padding=True) + its mask, the shipped provider
 
 
-def _from_labels(embedding, ema_embedding, labels, criterion, offsets, lam, mode):
+def _from_labels(embedding, ema_embedding, labels, criterion, offsets, lam, mode, need_affs=True):
     if not _fused(criterion):
         raise NotImplementedError("the labels-in step fuses WeightedMSE; for another criterion use gen_targets + embedding_loss")
     try:
-        return LabelsAffinityMSE.apply(embedding, ema_embedding, labels, _spec(offsets, lam, mode), _FLAGS_2D)
+        return LabelsAffinityMSE.apply(embedding, ema_embedding, labels, _spec(offsets, lam, mode), _FLAGS_2D, need_affs)
     except LabelsStepUnsupported:  # e.g. the coarsest deep-supervision scales: targets on the GPU, then the tensor path
         from ..utils.targets import gen_targets
         t, m, w = gen_targets(labels, offsets, padding=True)
         return FusedAffinityMSE.apply(embedding, ema_embedding, t, w, m, _spec(offsets, lam, mode))
 
 
-def embedding_loss_from_labels(embedding, labels, criterion, offsets, affs0_weight=1, mode='ours'):
+def embedding_loss_from_labels(embedding, labels, criterion, offsets, affs0_weight=1, mode='ours', need_affs=True):
     """embedding_loss(embedding, *gen_targets(labels, offsets, padding=True), criterion, offsets) without the three
-    [B,K,H,W] tensors: -> (loss, affs, all_loss).  labels: int tensor [B,H,W] on the GPU."""
-    loss, affs, parts = _from_labels(embedding, None, labels, criterion, offsets, [1.0] * len(offsets), mode)
+    [B,K,H,W] tensors: -> (loss, affs, all_loss).  labels: int tensor [B,H,W] on the GPU.  need_affs=False skips the
+    affinity-map output (an empty tensor is returned) for the calls whose map the training loop throws away."""
+    loss, affs, parts = _from_labels(embedding, None, labels, criterion, offsets, [1.0] * len(offsets), mode, need_affs)
     return loss, affs, LossList(parts)
 
 
-def ema_embedding_loss_from_labels(embedding, ema_embedding, labels, criterion, offsets, affs0_weight=1, mode='ours'):
+def ema_embedding_loss_from_labels(embedding, ema_embedding, labels, criterion, offsets, affs0_weight=1, mode='ours', need_affs=True):
     """ema_embedding_loss from the label image (the EMA operand must be detached, as the shipped configs have it)"""
     if ema_embedding.requires_grad:
         raise NotImplementedError("a second operand that needs its own gradient takes gen_targets + ema_embedding_loss")
     lam = [float(affs0_weight) if i < 2 else 1.0 for i in range(len(offsets))]
-    loss, affs, _ = _from_labels(embedding, ema_embedding, labels, criterion, offsets, lam, mode)
+    loss, affs, _ = _from_labels(embedding, ema_embedding, labels, criterion, offsets, lam, mode, need_affs)
     return loss, affs

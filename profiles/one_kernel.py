@@ -39,6 +39,8 @@ CNTB = L.pea_targets_workspace_bytes(ctypes.byref(desc))
 CNT = torch.empty(CNTB // 4, dtype=torch.int32, device=dev)
 assert L.pea_label_weights(ctypes.byref(desc), P(LAB), 5, P(WTAB), P(CNT), CNTB, st) == 0
 fns = {
+    "labels_noaffs": lambda: L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(E), None, P(LAB), P(WTAB), 5, None, P(lossv), None, P(dE), P(work), wsb, st),
+    "fwd_nog": lambda: L.pea_affinity_fwd(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), None, P(lossv), P(work), wsb, st),
     "gentgt": lambda: L.pea_gen_targets(ctypes.byref(desc), P(LAB), 1, P(T), P(M), P(Wt), P(CNT), CNTB, st),
     "labw": lambda: L.pea_label_weights(ctypes.byref(desc), P(LAB), 5, P(WTAB), P(CNT), CNTB, st),
     "labels": lambda: L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(E), None, P(LAB), P(WTAB), 5, P(affs), P(lossv), None, P(dE), P(work), wsb, st),
