@@ -168,6 +168,7 @@ int pea_fill_border_relu(float *affs, int B, int K, int Z, int Y, int X, int shi
 #define PEA_TGT_PADDING 1u
 #define PEA_TGT_BOTH_FOREGROUND 2u
 #define PEA_TGT_MASK_INSIDE 4u /* labels-in training step only: mask = [neighbour inside] (2D path); without it mask == 1 (3D path) */
+#define PEA_TGT_ACCUMULATE 8u  /* labels-in training step only: de += result (e.g. the EMA cross loss on top of the self loss) */
 size_t pea_targets_workspace_bytes(const PeaDesc *desc);
 int pea_gen_targets(const PeaDesc *desc, const int32_t *labels, unsigned flags, float *target, uint8_t *mask,
                     float *weight, void *workspace, size_t workspace_bytes, void *stream);

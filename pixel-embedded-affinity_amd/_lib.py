@@ -21,7 +21,7 @@ BORDER_CIRCULAR, BORDER_CROP_ZERO, BORDER_REPLICATE = 0, 1, 2
 F32, F16 = 0, 1
 NORM_BX, NORM_CROPPED, NORM_FULL = 0, 1, 2
 FLAG_RELU_AFFS = 1
-TGT_PADDING, TGT_BOTH_FOREGROUND, TGT_MASK_INSIDE = 1, 2, 4
+TGT_PADDING, TGT_BOTH_FOREGROUND, TGT_MASK_INSIDE, TGT_ACCUMULATE = 1, 2, 4, 8
 
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",
            "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_bwd", "pea_scale_inplace", "pea_fill_border_relu",

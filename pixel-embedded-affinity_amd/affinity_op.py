@@ -136,6 +136,7 @@ class FusedAffinityMSE(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, e, e_other, target, weight, mask, spec):
+        ctx.set_materialize_grads(False)  # no 95 MB zero tensors for the gradients of the non-differentiable outputs
         e_c = _embedding_arg(e, "embedding")
         o_c = None
         if e_other is not None:
@@ -191,7 +192,7 @@ class FusedAffinityMSE(torch.autograd.Function):
         e_c, o_c, g, target, weight, mask = ctx.saved_tensors
         want_e = ctx.needs_input_grad[0]
         want_o = ctx.has_other and ctx.needs_input_grad[1]
-        if not (want_e or want_o):
+        if not (want_e or want_o) or dloss is None:
             return None, None, None, None, None, None
         if e_c.shape[1] not in SUPPORTED_TRAIN_D:
             raise NotImplementedError("backward needs D in %s (got %d); pad the embedding channels" % (SUPPORTED_TRAIN_D, e_c.shape[1]))
@@ -294,6 +295,7 @@ class LabelsAffinityMSE(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, e, e_other, labels, spec, flags, need_affs=True):
+        ctx.set_materialize_grads(False)
         e_c = _embedding_arg(e, "embedding")
         o_c = None
         if e_other is not None:
@@ -330,7 +332,7 @@ class LabelsAffinityMSE(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloss, _daffs, _dvec):
-        if not ctx.needs_input_grad[0]:
+        if not ctx.needs_input_grad[0] or dloss is None:
             return None, None, None, None, None, None
         if ctx.de_unit is None:
             raise RuntimeError("the labels-in step hands its gradient buffer to the first backward; for a second backward "

@@ -217,8 +217,16 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fused_labels(con
   for (int c = 0; c < D_T; ++c) proj = fmaf(xh[c], G[c], proj);
   if (tiny) proj = 0.f;  // clamp_min branch of F.normalize: d ehat / d e = I / eps
   const float sc = dl * invp;
+  if (lflags & PEA_TGT_ACCUMULATE) {  // uniform: de += (e.g. the EMA cross loss on top of the self loss' gradient)
+    float prev[D_T];
 #pragma unroll
-  for (int c = 0; c < D_T; ++c) bs_emb<T>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
+    for (int c = 0; c < D_T; ++c) prev[c] = bl_emb<T>(dB, pe, ezo + c * ecs);
+#pragma unroll
+    for (int c = 0; c < D_T; ++c) bs_emb<T>(dB, prev[c] + (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
+  } else {
+#pragma unroll
+    for (int c = 0; c < D_T; ++c) bs_emb<T>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
+  }
 
   lds_barrier();
   if (threadIdx.x < P.K) {

@@ -497,6 +497,17 @@ __global__ __launch_bounds__(256) void k_scale_inplace(T* __restrict__ buf, size
 
 // Caller epilogue of the 3D path (scripts_ac3ac4/main.py:233-237,296-300; inference.py:160-164): for c in {0,1,2} the
 // first `shift` slices of affs[:, c] along axis c (z, y, x) are overwritten with slices shift .. 2*shift-1, then relu.
+// shift == 0: plain F.relu in place, 4 floats per lane (the general kernel below spends its time on index divisions)
+__global__ __launch_bounds__(256) void k_relu_inplace(float* __restrict__ a, size_t n4, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) {
+    f4 v = ((f4*)a)[i];
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    ((f4*)a)[i] = v;
+  }
+  if (i < n - 4 * n4) a[4 * n4 + i] = fmaxf(a[4 * n4 + i], 0.f);
+}
+
 __global__ __launch_bounds__(256) void k_fill_border_relu(float* __restrict__ affs, int B, int K, int Z, int Y, int X, int shift,
                                                           int relu) {
   const size_t S = (size_t)Z * Y * X, n = (size_t)B * K * S;
@@ -689,6 +700,13 @@ int pea_fill_border_relu(float* affs, int B, int K, int Z, int Y, int X, int shi
   if (misaligned(affs, 4)) return PEA_E_ALIGN;
   const size_t n = (size_t)B * K * Z * Y * X, blocks = (n + 255) / 256;
   if (blocks > 0x7fffffffULL) return PEA_E_UNSUPPORTED;
+  if (shift == 0 && !misaligned(affs, 16)) {
+    if (relu) {
+      const size_t n4 = n / 4, b4 = (std::max(n4, n - 4 * n4) + 255) / 256;
+      hipLaunchKernelGGL(k_relu_inplace, dim3((unsigned)b4), dim3(256), 0, (hipStream_t)stream, affs, n4, n);
+    }
+    return hip_rc();
+  }
   // source slices [shift, 2*shift) are never themselves rewritten (relu is idempotent), so in place is race-free
   hipLaunchKernelGGL(k_fill_border_relu, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, affs, B, K, Z, Y, X, shift, relu);
   return hip_rc();
@@ -784,7 +802,7 @@ int pea_affinity_fwd_bwd_labels(const PeaDesc* desc, const void* e, const void* 
   if (misaligned(e, es) || misaligned(e_other, es) || misaligned(de, es) || misaligned(affs, 4) || misaligned(labels, 4) ||
       misaligned(wtab, 4) || misaligned(loss_out, 4) || misaligned(dloss, 4) || misaligned(workspace, 4))
     return PEA_E_ALIGN;
-  if (flags & ~(PEA_TGT_PADDING | PEA_TGT_BOTH_FOREGROUND | PEA_TGT_MASK_INSIDE)) return PEA_E_DESC;
+  if (flags & ~(PEA_TGT_PADDING | PEA_TGT_BOTH_FOREGROUND | PEA_TGT_MASK_INSIDE | PEA_TGT_ACCUMULATE)) return PEA_E_DESC;
   const KParams P = make_params(desc);
   if (!workspace || workspace_bytes < fwd_partials(P) * P.K * sizeof(float)) return PEA_E_WORKSPACE;
   if ((P.D != 16 && P.D != 32) || env_int("PEA_FORCE_DIRECT", 0) != 0) return PEA_E_UNSUPPORTED;

@@ -6,8 +6,13 @@ can replace scripts_cvppp/main.py:282-312 / scripts_ac3ac4/main.py:216-238 by on
 happens inside (the reference's K `.item()` calls per loss are gone), so the section can be captured in a HIP graph
 (tests/test_gpu_parity.py::test_loss_section_graph_replay).
 """
-from ..loss.loss_embedding_mse import (ema_embedding_loss, ema_embedding_loss_from_labels, embedding_loss,
-                                       embedding_loss_from_labels)
+import ctypes
+
+import torch
+
+from .. import _lib
+from .. import affinity_op as op
+from ..loss.loss_embedding_mse import ema_embedding_loss, embedding_loss
 from ..loss.loss_embedding_mse_3d import (ema_embedding_loss_norm1, ema_embedding_loss_norm5, embedding_loss_norm1,
                                           embedding_loss_norm5)
 from ..utils.postproc import fill_border_relu_, relu_
@@ -85,24 +90,137 @@ def finish_pred_2d_(pred):
     return relu_(pred)
 
 
+class _LabelsSection(torch.autograd.Function):
+    """The whole loss section as ONE autograd node: every loss is a labels-in launch that writes its gradient already
+    multiplied by its weight (deep_weight_factor x self_emb / cross_emb is known before the launch), the EMA cross loss
+    accumulates onto the self loss' gradient in the kernel's epilogue, and the weighted total is two tiny ops on a
+    [6]-vector of device scalars.  Nothing is left for autograd to do per loss: no scalar-multiply kernels, no gradient
+    accumulation pass over [B,D,H,W], no zero-filled gradients for the affinity maps (40 % of the section's GPU time
+    when it is composed from the per-loss functions, profiles/r1c_loss_section.txt)."""
+
+    @staticmethod
+    def forward(ctx, specs, weights, ema_embedding, labels_list, *embs):
+        ctx.set_materialize_grads(False)
+        dev = embs[0].device
+        L = _lib.lib()
+        flags2d = _lib.TGT_PADDING | _lib.TGT_MASK_INSIDE
+        ncall = len(specs)
+        kmax = max(sp.K for sp in specs)
+        with torch.cuda.device(dev):
+            wdev = _weights_on(dev, weights)
+            rows = torch.empty((ncall, 1 + kmax), dtype=torch.float32, device=dev)
+            grads, pred = [], None
+            wtab_full = None
+            for j in range(ncall):
+                cross = j == ncall - 1
+                e = embs[0] if cross else embs[j]
+                e_c = op._embedding_arg(e, "embedding")
+                o_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e_c.dtype) if cross else None
+                lab = labels_list[0] if cross else labels_list[j]
+                lab = lab.to(torch.int32).contiguous()
+                spec = specs[j]
+                d = op.make_desc(spec, e_c)
+                cb = L.pea_targets_workspace_bytes(ctypes.byref(d))
+                counts = torch.empty(max(cb, 4) // 4, dtype=torch.int32, device=dev)
+                if cross and wtab_full is not None:
+                    wtab = wtab_full  # same labels, same stencil as the full-resolution self loss
+                else:
+                    wtab = torch.empty(e_c.shape[0] * spec.K * 2, dtype=torch.float32, device=dev)
+                    _lib.check(L.pea_label_weights(ctypes.byref(d), op._ptr(lab), flags2d, op._ptr(wtab), op._ptr(counts), cb,
+                                                   op._stream()), "pea_label_weights")
+                    if j == 0:
+                        wtab_full = wtab
+                wsb = L.pea_workspace_bytes(ctypes.byref(d))
+                work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=dev)
+                want_pred = j == 0
+                affs = torch.empty(op._affs_shape(e_c, spec.K), dtype=torch.float32, device=dev) if want_pred else None
+                de = grads[0] if cross else torch.empty_like(e_c)
+                fl = flags2d | (_lib.TGT_ACCUMULATE if cross else 0)
+                row = rows[j]
+                rc = L.pea_affinity_fwd_bwd_labels(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(lab), op._ptr(wtab), fl,
+                                                   op._ptr(affs), op._ptr(row), op._ptr(wdev[j:j + 1]), op._ptr(de), op._ptr(work),
+                                                   wsb, op._stream())
+                if rc == _lib.E_UNSUPPORTED:
+                    # no labels kernel for this call (the coarsest scales are smaller than a tile): targets on the GPU,
+                    # then the two tensor launches with the same weight as dloss
+                    if cross:
+                        raise NotImplementedError("the cross loss needs the labels-in kernel (D = 16 or 32)")
+                    kshape = op._affs_shape(e_c, spec.K)
+                    t = torch.empty(kshape, dtype=torch.float32, device=dev)
+                    m = torch.empty(kshape, dtype=torch.uint8, device=dev)
+                    w = torch.empty(kshape, dtype=torch.float32, device=dev)
+                    _lib.check(L.pea_gen_targets(ctypes.byref(d), op._ptr(lab), _lib.TGT_PADDING, op._ptr(t), op._ptr(m), op._ptr(w),
+                                                 op._ptr(counts), cb, op._stream()), "pea_gen_targets")
+                    g = torch.empty(kshape, dtype=torch.float32, device=dev)
+                    _lib.check(L.pea_affinity_fwd(ctypes.byref(d), op._ptr(e_c), None, op._ptr(t), op._ptr(w), op._ptr(m), op._ptr(affs),
+                                                  op._ptr(g), op._ptr(row), op._ptr(work), wsb, op._stream()), "pea_affinity_fwd")
+                    _lib.check(L.pea_affinity_bwd(ctypes.byref(d), op._ptr(e_c), None, op._ptr(g), op._ptr(wdev[j:j + 1]), op._ptr(de),
+                                                  None, op._stream()), "pea_affinity_bwd")
+                else:
+                    _lib.check(rc, "pea_affinity_fwd_bwd_labels")
+                if not cross:
+                    grads.append(de)
+                if want_pred:
+                    pred = affs
+            losses = rows[:, 0]
+            total = (losses * wdev).sum()
+        ctx.grads, ctx.dtype_code = grads, None
+        ctx.mark_non_differentiable(pred, losses)
+        return total, pred, losses
+
+    @staticmethod
+    def backward(ctx, dtotal, _dpred, _dlosses):
+        if dtotal is None or ctx.grads is None:
+            return (None, None, None, None) + (None,) * (len(ctx.grads) if ctx.grads else 0)
+        grads, ctx.grads = ctx.grads, None
+        L = _lib.lib()
+        out = []
+        for k, de in enumerate(grads):
+            if not ctx.needs_input_grad[4 + k]:
+                out.append(None)
+                continue
+            with torch.cuda.device(de.device):
+                dl = dtotal.to(device=de.device, dtype=torch.float32).contiguous()
+                _lib.check(L.pea_scale_inplace(op._ptr(de), _lib.F16 if de.dtype == torch.float16 else _lib.F32, de.numel(), op._ptr(dl),
+                                               op._stream()), "pea_scale_inplace")
+            out.append(de)
+        return (None, None, None, None) + tuple(out)
+
+
+_WEIGHT_CACHE = {}
+
+
+def _weights_on(dev, weights):
+    """device copy of a tuple of Python floats, made once per distinct tuple (no H2D copy inside the step)"""
+    key = (str(dev), tuple(float(w) for w in weights))
+    t = _WEIGHT_CACHE.get(key)
+    if t is None:
+        t = torch.tensor(key[1], dtype=torch.float32, device=dev)
+        _WEIGHT_CACHE[key] = t
+    return t
+
+
 def cvppp_loss_section_from_labels(embedding, emds, ema_embedding, labels, label_downs, criterion, offsets, nb_half,
                                    affs0_weight=1, dis_mode='ours', deep_weight=1, self_emb=1.0, cross_emb=1.0):
     """cvppp_loss_section without any target / weight / mask tensor: `labels` [B,H,W] and `label_downs` = the four
     nearest-downsampled label images (scripts_cvppp/data/data_provider.py:199-208) replace target, weightmap, affs_mask
-    and down1..down4; every loss is one labels-in launch (gen_affs_ours(padding=True) + weight_binary_ratio evaluated
-    inside the kernel)."""
+    and down1..down4 (gen_affs_ours(padding=True) + weight_binary_ratio are evaluated inside the kernels).  The six
+    losses run as one autograd node (_LabelsSection).  Returns (loss, pred, parts) like cvppp_loss_section; the entries
+    of parts are the weighted per-loss values (device scalars, no gradient of their own)."""
+    if not getattr(criterion, 'pea_fused', False):
+        raise NotImplementedError("the labels-in section fuses WeightedMSE; use cvppp_loss_section for another criterion")
+    if ema_embedding.requires_grad:
+        raise NotImplementedError("the EMA operand must be detached (convert_consistency_flip)")
+    from ..loss.loss_embedding_mse import _spec
     dwf = deep_weight_factor(deep_weight)
-    losses = []
-    for j, (emd, lab) in enumerate(zip(emds, label_downs)):
+    specs = [_spec(offsets, [1.0] * len(offsets), dis_mode)]
+    for j in range(4):
         k = nb_half * (4 - j)
-        l, _, _ = embedding_loss_from_labels(emd, lab, criterion, offsets[:k], affs0_weight=affs0_weight, mode=dis_mode,
-                                             need_affs=False)  # the reference discards these maps (main.py:284-287)
-        losses.append(l)
-    loss_embedding, pred, _ = embedding_loss_from_labels(embedding, labels, criterion, offsets, affs0_weight=affs0_weight, mode=dis_mode)
-    loss_embedding_cross, _ = ema_embedding_loss_from_labels(embedding, ema_embedding, labels, criterion, offsets,
-                                                             affs0_weight=affs0_weight, mode=dis_mode, need_affs=False)
-    loss_embedding = loss_embedding * dwf[0]
-    loss_emd = [losses[j] * dwf[j + 1] for j in range(4)]
-    loss_embedding_cross = loss_embedding_cross * dwf[0]
-    loss = (loss_emd[0] + loss_emd[1] + loss_emd[2] + loss_emd[3] + loss_embedding) * self_emb + loss_embedding_cross * cross_emb
-    return loss, pred, {"loss_embedding": loss_embedding, "loss_emd": loss_emd, "loss_embedding_cross": loss_embedding_cross}
+        specs.append(_spec(offsets[:k], [1.0] * k, dis_mode))
+    specs.append(_spec(offsets, [float(affs0_weight) if i < 2 else 1.0 for i in range(len(offsets))], dis_mode))
+    weights = [dwf[0] * self_emb] + [dwf[j + 1] * self_emb for j in range(4)] + [dwf[0] * cross_emb]
+    loss, pred, losses = _LabelsSection.apply(specs, weights, ema_embedding, [labels] + list(label_downs), embedding, *emds)
+    wl = losses * _weights_on(losses.device, weights)
+    parts = {"loss_embedding": wl[0] / self_emb if self_emb else wl[0], "loss_emd": [wl[1 + j] / self_emb if self_emb else wl[1 + j] for j in range(4)],
+             "loss_embedding_cross": wl[5] / cross_emb if cross_emb else wl[5]}
+    return loss, pred, parts
