@@ -352,7 +352,8 @@ bool try_bwd_tiled(const KParams& P, const T* x, const T* nb, const float* g, co
   const int ci = env_int("PEA_BWD_CFG", kBwdDefault);
   if (ci < 0 || ci >= kNumBwdCfg) return false;
   TParams Q;
-  if (!plan_tiles(P, bwd_cfg<D_T>(ci), true, &Q)) return false;
+  // role A alone (a detached second operand's cross loss) reaches only p + o: a one-sided halo; role B needs p - o
+  if (!plan_tiles(P, bwd_cfg<D_T>(ci), !(RA && !RB), &Q)) return false;
 #define PEA_BWD_CASE(CI) \
   case CI: launch_bwd_cfg<T, D_T, RA, RB, CI>(P, Q, x, nb, g, dl, dx, s); break;
   switch (ci) { PEA_BWD_CASE(0) PEA_BWD_CASE(1) default: return false; }

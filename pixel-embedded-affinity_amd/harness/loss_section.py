@@ -27,6 +27,97 @@ def deep_weight_factor(deep_weight):
     return [deep_weight, 1.0, 1.0, 1.0, 1.0]
 
 
+class _TensorSection(torch.autograd.Function):
+    """cvppp_loss_section's six losses as ONE autograd node on the tensor path: per loss one forward launch (saving g)
+    and one backward launch whose dloss is the loss' weight; the EMA cross gradient is added to the self gradient with one
+    add.  Same reasons as _LabelsSection: nothing per loss is left to autograd."""
+
+    @staticmethod
+    def forward(ctx, specs, weights, ema_embedding, tensors, *embs):
+        ctx.set_materialize_grads(False)
+        dev = embs[0].device
+        L = _lib.lib()
+        ncall = len(specs)
+        kmax = max(sp.K for sp in specs)
+        with torch.cuda.device(dev):
+            wdev = _weights_on(dev, weights)
+            rows = torch.empty((ncall, 1 + kmax), dtype=torch.float32, device=dev)
+            grads, pred = [], None
+            for j in range(ncall):
+                cross = j == ncall - 1
+                e_c = op._embedding_arg(embs[0] if cross else embs[j], "embedding")
+                o_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e_c.dtype) if cross else None
+                spec = specs[j]
+                kshape = op._affs_shape(e_c, spec.K)
+                t, w, m = tensors[0] if cross else tensors[j]
+                t, ts = op._batch_strided(t, "target", torch.float32, kshape)
+                w, ws = op._batch_strided(w, "weightmap", torch.float32, kshape)
+                if m.dtype == torch.bool:
+                    m = m.view(torch.uint8)
+                m, ms = op._batch_strided(m, "mask", torch.uint8, kshape)
+                d = op.make_desc(spec, e_c, ts, ws, ms)
+                wsb = L.pea_workspace_bytes(ctypes.byref(d))
+                work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=dev)
+                affs = torch.empty(kshape, dtype=torch.float32, device=dev) if j == 0 else None
+                g = torch.empty(kshape, dtype=torch.float32, device=dev)
+                _lib.check(L.pea_affinity_fwd(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(t), op._ptr(w), op._ptr(m),
+                                              op._ptr(affs), op._ptr(g), op._ptr(rows[j]), op._ptr(work), wsb, op._stream()), "pea_affinity_fwd")
+                de = torch.empty_like(e_c)
+                _lib.check(L.pea_affinity_bwd(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(g), op._ptr(wdev[j:j + 1]),
+                                              op._ptr(de), None, op._stream()), "pea_affinity_bwd")
+                if cross:
+                    grads[0].add_(de)
+                else:
+                    grads.append(de)
+                if j == 0:
+                    pred = affs
+            losses = rows[:, 0]
+            total = (losses * wdev).sum()
+        ctx.grads = grads
+        ctx.mark_non_differentiable(pred, losses)
+        return total, pred, losses
+
+    backward = staticmethod(lambda ctx, dtotal, _dp, _dl: _section_backward(ctx, dtotal))
+
+
+def _section_backward(ctx, dtotal):
+    n = len(ctx.grads) if ctx.grads else 0
+    if dtotal is None or not ctx.grads:
+        return (None, None, None, None) + (None,) * n
+    grads, ctx.grads = ctx.grads, None
+    L = _lib.lib()
+    out = []
+    for k, de in enumerate(grads):
+        if not ctx.needs_input_grad[4 + k]:
+            out.append(None)
+            continue
+        with torch.cuda.device(de.device):
+            dl = dtotal.to(device=de.device, dtype=torch.float32).contiguous()
+            _lib.check(L.pea_scale_inplace(op._ptr(de), _lib.F16 if de.dtype == torch.float16 else _lib.F32, de.numel(), op._ptr(dl),
+                                           op._stream()), "pea_scale_inplace")
+        out.append(de)
+    return (None, None, None, None) + tuple(out)
+
+
+def _section_specs(offsets, nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb):
+    from ..loss.loss_embedding_mse import _spec
+    dwf = deep_weight_factor(deep_weight)
+    specs = [_spec(offsets, [1.0] * len(offsets), dis_mode)]
+    for j in range(4):
+        k = nb_half * (4 - j)
+        specs.append(_spec(offsets[:k], [1.0] * k, dis_mode))
+    specs.append(_spec(offsets, [float(affs0_weight) if i < 2 else 1.0 for i in range(len(offsets))], dis_mode))
+    weights = [dwf[0] * self_emb] + [dwf[j + 1] * self_emb for j in range(4)] + [dwf[0] * cross_emb]
+    return specs, weights
+
+
+def _section_parts(losses, weights, self_emb, cross_emb):
+    wl = losses * _weights_on(losses.device, weights)
+    return {"loss_embedding": wl[0] / self_emb if self_emb else wl[0],
+            "loss_emd": [wl[1 + j] / self_emb if self_emb else wl[1 + j] for j in range(4)],
+            "loss_embedding_cross": wl[5] / cross_emb if cross_emb else wl[5]}
+
+
 def cvppp_loss_section(embedding, emds, ema_embedding, target, weightmap, affs_mask, downs, criterion, offsets, nb_half,
                        affs0_weight=1, dis_mode='ours', deep_weight=1, self_emb=1.0, cross_emb=1.0):
     """scripts_cvppp/main.py:284-310 (and scripts_bbbc/main.py:279-305): five self losses over the deep-supervision
@@ -36,7 +127,26 @@ def cvppp_loss_section(embedding, emds, ema_embedding, target, weightmap, affs_m
     (target | weight | mask) thirds with k = nb_half * (4, 3, 2, 1) channels.  ema_embedding is the flipped-back,
     detached EMA output (convert_consistency_flip).  Returns (loss without the consistency term `loss_mask`, pred,
     parts) where pred is the full-resolution affinity map BEFORE relu (call relu_ after backward like the
-    reference does at :312) and parts the individual weighted losses (device scalars)."""
+    reference does at :312) and parts the individual weighted losses (device scalars).
+
+    With the fused criterion (WeightedMSE) and a detached EMA operand the six losses run as one autograd node
+    (_TensorSection); otherwise they are composed from embedding_loss / ema_embedding_loss call by call."""
+    if getattr(criterion, 'pea_fused', False) and not ema_embedding.requires_grad:
+        specs, weights = _section_specs(offsets, nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb)
+        tensors = [(target, weightmap, affs_mask)]
+        for j, down in enumerate(downs):
+            k = nb_half * (4 - j)
+            m = down[:, 2 * k:3 * k]
+            tensors.append((down[:, 0:k], down[:, k:2 * k], m if m.dtype in (torch.uint8, torch.bool) else m.to(torch.uint8)))
+        loss, pred, losses = _TensorSection.apply(specs, weights, ema_embedding, tensors, embedding, *emds)
+        return loss, pred, _section_parts(losses, weights, self_emb, cross_emb)
+    return cvppp_loss_section_composed(embedding, emds, ema_embedding, target, weightmap, affs_mask, downs, criterion, offsets,
+                                       nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb)
+
+
+def cvppp_loss_section_composed(embedding, emds, ema_embedding, target, weightmap, affs_mask, downs, criterion, offsets, nb_half,
+                                affs0_weight=1, dis_mode='ours', deep_weight=1, self_emb=1.0, cross_emb=1.0):
+    """the same section call by call, statement for statement as scripts_cvppp/main.py:284-310 (any criterion)"""
     dwf = deep_weight_factor(deep_weight)
     losses = []
     for j, (emd, down) in enumerate(zip(emds, downs)):
@@ -164,27 +274,11 @@ class _LabelsSection(torch.autograd.Function):
                     pred = affs
             losses = rows[:, 0]
             total = (losses * wdev).sum()
-        ctx.grads, ctx.dtype_code = grads, None
+        ctx.grads = grads
         ctx.mark_non_differentiable(pred, losses)
         return total, pred, losses
 
-    @staticmethod
-    def backward(ctx, dtotal, _dpred, _dlosses):
-        if dtotal is None or ctx.grads is None:
-            return (None, None, None, None) + (None,) * (len(ctx.grads) if ctx.grads else 0)
-        grads, ctx.grads = ctx.grads, None
-        L = _lib.lib()
-        out = []
-        for k, de in enumerate(grads):
-            if not ctx.needs_input_grad[4 + k]:
-                out.append(None)
-                continue
-            with torch.cuda.device(de.device):
-                dl = dtotal.to(device=de.device, dtype=torch.float32).contiguous()
-                _lib.check(L.pea_scale_inplace(op._ptr(de), _lib.F16 if de.dtype == torch.float16 else _lib.F32, de.numel(), op._ptr(dl),
-                                               op._stream()), "pea_scale_inplace")
-            out.append(de)
-        return (None, None, None, None) + tuple(out)
+    backward = staticmethod(lambda ctx, dtotal, _dp, _dl: _section_backward(ctx, dtotal))
 
 
 _WEIGHT_CACHE = {}
@@ -211,16 +305,6 @@ def cvppp_loss_section_from_labels(embedding, emds, ema_embedding, labels, label
         raise NotImplementedError("the labels-in section fuses WeightedMSE; use cvppp_loss_section for another criterion")
     if ema_embedding.requires_grad:
         raise NotImplementedError("the EMA operand must be detached (convert_consistency_flip)")
-    from ..loss.loss_embedding_mse import _spec
-    dwf = deep_weight_factor(deep_weight)
-    specs = [_spec(offsets, [1.0] * len(offsets), dis_mode)]
-    for j in range(4):
-        k = nb_half * (4 - j)
-        specs.append(_spec(offsets[:k], [1.0] * k, dis_mode))
-    specs.append(_spec(offsets, [float(affs0_weight) if i < 2 else 1.0 for i in range(len(offsets))], dis_mode))
-    weights = [dwf[0] * self_emb] + [dwf[j + 1] * self_emb for j in range(4)] + [dwf[0] * cross_emb]
+    specs, weights = _section_specs(offsets, nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb)
     loss, pred, losses = _LabelsSection.apply(specs, weights, ema_embedding, [labels] + list(label_downs), embedding, *emds)
-    wl = losses * _weights_on(losses.device, weights)
-    parts = {"loss_embedding": wl[0] / self_emb if self_emb else wl[0], "loss_emd": [wl[1 + j] / self_emb if self_emb else wl[1 + j] for j in range(4)],
-             "loss_embedding_cross": wl[5] / cross_emb if cross_emb else wl[5]}
-    return loss, pred, parts
+    return loss, pred, _section_parts(losses, weights, self_emb, cross_emb)

@@ -779,3 +779,27 @@ def test_replicate_border_norm6_matches_reference_golden(pkg, dev, name):
     assert relmax(et.grad.cpu().numpy(), g["grad"]) < GRAD_RTOL
     if "grad_ema" in g:
         assert relmax(mt.grad.cpu().numpy(), g["grad_ema"]) < GRAD_RTOL
+
+
+def test_loss_section_node_equals_composed(pkg, dev, synth):
+    """cvppp_loss_section as one autograd node (weights folded into the launches) against the statement-for-statement
+    composition from embedding_loss / ema_embedding_loss, with non-trivial weights and an outer factor on the loss"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    nb_half, B, D, H, W = 2, 2, 16, 96, 96
+    e, ema, t, w, m, emds, downs = _section_inputs(synth, offsets, nb_half, B, D, H, W, 131)
+    crit = pkg.WeightedMSE()
+    res = []
+    for fn in (pkg.cvppp_loss_section_composed, pkg.cvppp_loss_section):
+        et = cu(e, dev).requires_grad_(True)
+        emd_t = [cu(x, dev).requires_grad_(True) for x in emds]
+        loss, pred, parts = fn(et, emd_t, cu(ema, dev), cu(t, dev), cu(w, dev), cu(m, dev), [cu(x, dev) for x in downs], crit,
+                               offsets, nb_half, affs0_weight=2, deep_weight=2, self_emb=0.7, cross_emb=1.3)
+        (loss * 0.5).backward()
+        res.append((loss.item(), pred.cpu().numpy(), [et.grad.cpu().numpy()] + [x.grad.cpu().numpy() for x in emd_t],
+                    float(parts["loss_embedding_cross"].detach()), [float(v.detach()) for v in parts["loss_emd"]]))
+    assert abs(res[1][0] - res[0][0]) <= 2e-6 * abs(res[0][0])
+    assert np.abs(res[1][1] - res[0][1]).max() < 2e-6
+    for a, b in zip(res[1][2], res[0][2]):
+        assert relmax(a, b) < 1e-5
+    assert abs(res[1][3] - res[0][3]) <= 1e-5 * abs(res[0][3])
+    np.testing.assert_allclose(res[1][4], res[0][4], rtol=1e-5)
