@@ -174,6 +174,39 @@ def main():
         for name, fn in (("fwd", fwd), ("bwd", bwd), ("infer", inf), ("fused_fwd_bwd", fused), ("labels_step", labels_step)):
             event_time_ms(fn, 10)
             kt[name] = event_time_ms(fn, max(20, min(args.steps, 200)))
+        # ---- the training loop's loss section (five self losses over the scales + EMA cross loss + backward + relu,
+        #      scripts_cvppp/main.py:284-312): call-by-call composition, one autograd node, and the labels-in path
+        def section_us():
+            nb_half = NEIGHBOR // 2
+            labs = [torch.from_numpy(np.ascontiguousarray(synth.synth_labels(B, (1, H, W), 555 + rank)[:, 0][:, ::2 ** j, ::2 ** j])).to(dev)
+                    for j in range(5)]
+            embs = [torch.from_numpy(synth.synth_embedding((B, D, H >> j, W >> j), 600 + j)).to(dev) for j in range(5)]
+            ema = torch.from_numpy(synth.synth_embedding((B, D, H, W), 700)).to(dev)
+            tt, mm, ww = pkg.gen_targets(labs[0], offsets, padding=True)
+            downs = []
+            for j in range(1, 5):
+                k = nb_half * (5 - j)
+                tj, mj, wj = pkg.gen_targets(labs[j], offsets[:k], padding=True)
+                downs.append(torch.cat([tj, wj, mj.float()], dim=1))
+
+            def run(which):
+                x = [e.detach().requires_grad_(True) for e in embs]
+                if which == "labels":
+                    loss, pred, _ = pkg.cvppp_loss_section_from_labels(x[0], x[1:], ema, labs[0], labs[1:], crit, offsets, nb_half)
+                else:
+                    fn = pkg.cvppp_loss_section_composed if which == "composed" else pkg.cvppp_loss_section
+                    loss, pred, _ = fn(x[0], x[1:], ema, tt, ww, mm, downs, crit, offsets, nb_half)
+                loss.backward()
+                pkg.finish_pred_2d_(pred)
+
+            out = {}
+            for which in ("composed", "one_node", "labels"):
+                for _ in range(3):
+                    run(which)
+                out[which] = round(event_time_ms(lambda: run(which), 10) * 1e3, 1)
+            return out
+
+        section = section_us()
         ab = algorithmic_bytes_per_px(D, K)
         dom = "bwd" if kt["bwd"] >= kt["fwd"] else "fwd"
         launch_bytes = ab[dom] * B * H * W
@@ -196,6 +229,7 @@ def main():
             "kernel_sum_mpx_s": round(B * H * W / ((kt["fwd"] + kt["bwd"]) * 1e-3) / 1e6, 1),
             "infer_mpx_s": round(B * H * W / (kt["infer"] * 1e-3) / 1e6, 1),
             "labels_step_mpx_s": round(B * H * W / (kt["labels_step"] * 1e-3) / 1e6, 1),
+            "loss_section_us": section,
             "roofline": {"bound": "hbm", "kernel": "pea_affinity_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_px": ab[dom], "px_per_launch": B * H * W,
