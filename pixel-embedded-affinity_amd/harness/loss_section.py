@@ -52,9 +52,11 @@ class _TensorSection(torch.autograd.Function):
                 t, w, m = tensors[0] if cross else tensors[j]
                 t, ts = op._batch_strided(t, "target", torch.float32, kshape)
                 w, ws = op._batch_strided(w, "weightmap", torch.float32, kshape)
-                if m.dtype == torch.bool:
-                    m = m.view(torch.uint8)
-                m, ms = op._batch_strided(m, "mask", torch.uint8, kshape)
+                ms = 0
+                if m is not None:
+                    if m.dtype == torch.bool:
+                        m = m.view(torch.uint8)
+                    m, ms = op._batch_strided(m, "mask", torch.uint8, kshape)
                 d = op.make_desc(spec, e_c, ts, ws, ms)
                 wsb = L.pea_workspace_bytes(ctypes.byref(d))
                 work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=dev)
@@ -168,11 +170,48 @@ def cvppp_loss_section_composed(embedding, emds, ema_embedding, target, weightma
     return loss, pred, parts
 
 
+def _specs_3d(embedding_mode, affs0_weight):
+    from ..loss.loss_embedding_mse_3d import _spec as spec3
+    from ..utils.affinity_ours import NORM5_SHIFTS
+    if embedding_mode == 1:
+        full = ([1, 1, 1], 1)
+    elif embedding_mode == 5:
+        full = (NORM5_SHIFTS, 3)
+    else:
+        raise NotImplementedError
+    specs = [spec3(full[0], affs0_weight, full[1])] + [spec3([1, 1, 1], affs0_weight, 1) for _ in range(4)] + [spec3(full[0], affs0_weight, full[1])]
+    return specs, [1.0] * 6
+
+
 def ac3ac4_loss_section(embedding, emds, ema_embedding, target, weightmap, downs, criterion, embedding_mode=5, affs0_weight=1):
     """scripts_ac3ac4/main.py:219-231: full-resolution self + EMA cross loss (norm1 or norm5) and four norm1 losses on
     the deep-supervision heads; downs = (down1, .., down4) packed [B, 6, z, y, x] = (target[:3] | weight[3:]),
     paired emd1<->down4 .. emd4<->down1 as in the reference.  Returns (loss, pred before the border fill / relu);
-    call finish_pred_3d_(pred) after backward (:233-237)."""
+    call finish_pred_3d_(pred) after backward (:233-237).  One autograd node with the fused criterion and a detached
+    EMA operand, the call-by-call composition otherwise."""
+    if getattr(criterion, 'pea_fused', False) and not ema_embedding.requires_grad and embedding_mode in (1, 5):
+        specs, weights = _specs_3d(embedding_mode, affs0_weight)
+        tensors = [(target, weightmap, None)] + [(d[:, :3], d[:, 3:], None) for d in downs[::-1]]
+        loss, pred, _ = _TensorSection.apply(specs, weights, ema_embedding, tensors, embedding, *emds)
+        return loss, pred
+    return ac3ac4_loss_section_composed(embedding, emds, ema_embedding, target, weightmap, downs, criterion, embedding_mode, affs0_weight)
+
+
+def ac3ac4_loss_section_from_labels(embedding, emds, ema_embedding, labels, label_downs, criterion, embedding_mode=5, affs0_weight=1):
+    """ac3ac4_loss_section from the segmentation: labels [B,Z,Y,X] and label_downs = (seg of down1, .., seg of down4) replace
+    target / weightmap / down1..4 (seg_to_aff(pad='') + weight_binary_ratio are evaluated inside the kernels)."""
+    if not getattr(criterion, 'pea_fused', False):
+        raise NotImplementedError("the labels-in section fuses WeightedMSE")
+    if ema_embedding.requires_grad:
+        raise NotImplementedError("the EMA operand must be detached (convert_consistency_flip)")
+    specs, weights = _specs_3d(embedding_mode, affs0_weight)
+    specs[0].label_flags = (_lib.TGT_BOTH_FOREGROUND, _lib.TGT_BOTH_FOREGROUND, False)
+    loss, pred, _ = _LabelsSection.apply(specs, weights, ema_embedding, [labels] + list(label_downs[::-1]), embedding, *emds)
+    return loss, pred
+
+
+def ac3ac4_loss_section_composed(embedding, emds, ema_embedding, target, weightmap, downs, criterion, embedding_mode=5, affs0_weight=1):
+    """the same section call by call, statement for statement as scripts_ac3ac4/main.py:219-231 (any criterion)"""
     if embedding_mode == 1:
         loss_embedding, pred = embedding_loss_norm1(embedding, target, weightmap, criterion, affs0_weight=affs0_weight)
         loss_embedding_cross, _ = ema_embedding_loss_norm1(embedding, ema_embedding, target, weightmap, criterion,
@@ -213,7 +252,7 @@ class _LabelsSection(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         dev = embs[0].device
         L = _lib.lib()
-        flags2d = _lib.TGT_PADDING | _lib.TGT_MASK_INSIDE
+        flags2d, gen_flags, has_mask = specs[0].label_flags
         ncall = len(specs)
         kmax = max(sp.K for sp in specs)
         with torch.cuda.device(dev):
@@ -257,9 +296,9 @@ class _LabelsSection(torch.autograd.Function):
                         raise NotImplementedError("the cross loss needs the labels-in kernel (D = 16 or 32)")
                     kshape = op._affs_shape(e_c, spec.K)
                     t = torch.empty(kshape, dtype=torch.float32, device=dev)
-                    m = torch.empty(kshape, dtype=torch.uint8, device=dev)
+                    m = torch.empty(kshape, dtype=torch.uint8, device=dev) if has_mask else None
                     w = torch.empty(kshape, dtype=torch.float32, device=dev)
-                    _lib.check(L.pea_gen_targets(ctypes.byref(d), op._ptr(lab), _lib.TGT_PADDING, op._ptr(t), op._ptr(m), op._ptr(w),
+                    _lib.check(L.pea_gen_targets(ctypes.byref(d), op._ptr(lab), gen_flags, op._ptr(t), op._ptr(m), op._ptr(w),
                                                  op._ptr(counts), cb, op._stream()), "pea_gen_targets")
                     g = torch.empty(kshape, dtype=torch.float32, device=dev)
                     _lib.check(L.pea_affinity_fwd(ctypes.byref(d), op._ptr(e_c), None, op._ptr(t), op._ptr(w), op._ptr(m), op._ptr(affs),
@@ -306,5 +345,6 @@ def cvppp_loss_section_from_labels(embedding, emds, ema_embedding, labels, label
     if ema_embedding.requires_grad:
         raise NotImplementedError("the EMA operand must be detached (convert_consistency_flip)")
     specs, weights = _section_specs(offsets, nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb)
+    specs[0].label_flags = (_lib.TGT_PADDING | _lib.TGT_MASK_INSIDE, _lib.TGT_PADDING, True)  # gen_affs_ours(padding=True) + its mask
     loss, pred, losses = _LabelsSection.apply(specs, weights, ema_embedding, [labels] + list(label_downs), embedding, *emds)
     return loss, pred, _section_parts(losses, weights, self_emb, cross_emb)

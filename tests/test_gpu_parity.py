@@ -803,3 +803,38 @@ def test_loss_section_node_equals_composed(pkg, dev, synth):
         assert relmax(a, b) < 1e-5
     assert abs(res[1][3] - res[0][3]) <= 1e-5 * abs(res[0][3])
     np.testing.assert_allclose(res[1][4], res[0][4], rtol=1e-5)
+
+
+def test_3d_loss_section_variants_agree(pkg, dev, orc, synth):
+    """scripts_ac3ac4/main.py:219-231 (norm5 self + EMA cross + four norm1 heads): call-by-call composition, one autograd
+    node on the tensor path, and the labels-in section must agree"""
+    crit = pkg.WeightedMSE()
+    B, D = 1, 16
+    shapes = [(6, 72, 76), (6, 36, 38), (6, 36, 38), (3, 18, 20), (3, 18, 20)]  # full, emd1..emd4 (as the 3D U-Net's heads)
+    sh5 = orc.norm_offsets([1, 1, 1, 2, 3, 3, 3, 9, 9, 4, 27, 27])
+    sh1 = orc.norm_offsets([1, 1, 1])
+    labs = [synth.synth_labels(B, s, 140 + i, cell=7) for i, s in enumerate(shapes)]
+    lab_t = [torch.from_numpy(x).to(dev) for x in labs]
+    embs = [synth.synth_embedding((B, D) + s, 150 + i) for i, s in enumerate(shapes)]
+    ema = cu(synth.synth_embedding((B, D) + shapes[0], 160), dev)
+    t0, _, w0 = pkg.gen_targets(lab_t[0], sh5, padding=False, both_foreground=True, want_mask=False)
+    heads = [pkg.gen_targets(lab_t[1 + j], sh1, padding=False, both_foreground=True, want_mask=False) for j in range(4)]
+    # the reference pairs emd1 with down4, ..., emd4 with down1: downs[k] belongs to emd(4-k)
+    downs = [torch.cat([heads[3 - k][0], heads[3 - k][2]], dim=1) for k in range(4)]
+    label_downs = [lab_t[1 + (3 - k)] for k in range(4)]
+    res = []
+    for which in ("composed", "node", "labels"):
+        x = [cu(e, dev).requires_grad_(True) for e in embs]
+        if which == "labels":
+            loss, pred = pkg.ac3ac4_loss_section_from_labels(x[0], x[1:], ema, lab_t[0], label_downs, crit, embedding_mode=5, affs0_weight=2)
+        else:
+            fn = pkg.ac3ac4_loss_section_composed if which == "composed" else pkg.ac3ac4_loss_section
+            loss, pred = fn(x[0], x[1:], ema, t0, w0, downs, crit, embedding_mode=5, affs0_weight=2)
+        (loss * 0.5).backward()
+        pkg.finish_pred_3d_(pred)
+        res.append((loss.item(), pred.cpu().numpy(), [v.grad.cpu().numpy() for v in x]))
+    for k in (1, 2):
+        assert abs(res[k][0] - res[0][0]) <= 3e-6 * abs(res[0][0])
+        assert np.abs(res[k][1] - res[0][1]).max() < 2e-6
+        for a, b in zip(res[k][2], res[0][2]):
+            assert relmax(a, b) < 1e-5
