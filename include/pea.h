@@ -187,6 +187,17 @@ int pea_affinity_fwd_bwd_labels(const PeaDesc *desc, const void *e, const void *
                                 const float *wtab, unsigned flags, float *affs, float *loss_out, const float *dloss, void *de,
                                 void *workspace, size_t workspace_bytes, void *stream);
 
+/* The full-resolution pair of the training loop in ONE launch: the self loss (desc) and the detached-EMA cross loss
+ * (desc_cross: same geometry and stencil, its own lambda / normaliser) of the same embedding and labels
+ * (scripts_cvppp/main.py:288,293): de = dloss * d L_self / d e + dloss_cross * d L_cross / d e; affs (nullable) is the
+ * self loss' map; loss_out / loss_cross_out [1 + K] each.  workspace: 2 x pea_workspace_bytes(desc).  Returns
+ * PEA_E_UNSUPPORTED when the two launches of pea_affinity_fwd_bwd_labels (the second with PEA_TGT_ACCUMULATE) must be
+ * used instead. */
+int pea_affinity_fwd_bwd_labels_dual(const PeaDesc *desc, const PeaDesc *desc_cross, const void *e, const void *ema,
+                                     const int32_t *labels, const float *wtab, unsigned flags, float *affs, float *loss_out,
+                                     float *loss_cross_out, const float *dloss, const float *dloss_cross, void *de,
+                                     void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- the step after the path: 3D inference stitcher ----
  * Provider_valid.add_vol / get_results of scripts_ac3ac4/data/provider_valid.py:320-349 on the device, so a predicted
  * window never leaves HBM: out_affs [C,Z,Y,X] and weight_map [Z,Y,X] accumulate affs_vol [C,oz,oy,ox] * weight_vol

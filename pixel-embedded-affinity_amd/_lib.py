@@ -26,7 +26,7 @@ TGT_PADDING, TGT_BOTH_FOREGROUND, TGT_MASK_INSIDE, TGT_ACCUMULATE = 1, 2, 4, 8
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",
            "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_bwd", "pea_scale_inplace", "pea_fill_border_relu",
            "pea_targets_workspace_bytes", "pea_gen_targets", "pea_stitch_add", "pea_stitch_finalize",
-           "pea_label_weights", "pea_affinity_fwd_bwd_labels")
+           "pea_label_weights", "pea_affinity_fwd_bwd_labels", "pea_affinity_fwd_bwd_labels_dual")
 
 
 class PeaLibraryError(RuntimeError):
@@ -110,6 +110,8 @@ def lib():
     L.pea_label_weights.argtypes = [dp, vp, ctypes.c_uint, vp, vp, ctypes.c_size_t, vp]
     L.pea_affinity_fwd_bwd_labels.restype = ctypes.c_int
     L.pea_affinity_fwd_bwd_labels.argtypes = [dp, vp, vp, vp, vp, ctypes.c_uint, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.pea_affinity_fwd_bwd_labels_dual.restype = ctypes.c_int
+    L.pea_affinity_fwd_bwd_labels_dual.argtypes = [dp, dp, vp, vp, vp, vp, ctypes.c_uint, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.pea_stitch_add.restype = ctypes.c_int
     L.pea_stitch_add.argtypes = [vp, vp, vp, vp] + [ctypes.c_int] * 10 + [vp]
     L.pea_stitch_finalize.restype = ctypes.c_int

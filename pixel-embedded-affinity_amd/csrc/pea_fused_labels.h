@@ -238,6 +238,335 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fused_labels(con
 }
 
 // counts of positive targets per (image, channel) straight from the labels (no target tensor), then the weight table
+constexpr int kDualNear = 8;   // near entries of the self phase whose role-A labels the cross phase reuses
+
+constexpr int kDualNearMax = 8;
+struct CrossPar {  // the second (cross) loss of k_fused_labels_dual
+  float gscale[PEA_MAX_K];  // 2 * lambda_i / N_i of the cross loss
+  int d2[kDualNearMax];     // LDS displacement, in the cross phase's region, of the self plan's near entry k (host: both
+                            // plans have the same near / far split, entry for entry)
+};
+
+// Self loss AND detached-EMA cross loss of the same embedding / labels in one launch, two LDS phases: phase 1 is
+// k_fused_labels<ROLE_B = true> on x itself; then the EMA tensor's (one-sided) region is staged over the dead one and
+// the cross loss' role-A pairs add to the same G.  Saved against two launches: the cross kernel's own-pixel loads, its
+// read-modify-write of de, its label loads (role-A labels are kept), a launch.  dloss / dloss2 weight the two losses.
+template <typename T, int D_T, int TH, int TW, int PLQ, bool CROP>
+__global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fused_labels_dual(
+    const KParams P, const TParams Q, const TParams Q2, const CrossPar C2, const T* __restrict__ xt, const T* __restrict__ emat,
+    const int32_t* __restrict__ labels, const float* __restrict__ wtab, unsigned lflags, float* __restrict__ affs,
+    float* __restrict__ partials, float* __restrict__ partials2, const float* __restrict__ dloss,
+    const float* __restrict__ dloss2, T* __restrict__ dx) {
+  constexpr bool ROLE_B = true;
+  const T* nbt = xt;
+  typedef Lds<D_T, PLQ> L;
+  constexpr int NT = TH * TW, NW = NT / 64;
+  constexpr int NR = ROLE_B ? 2 : 1;
+  constexpr int KN = 8;  // near offsets per chunk (x NR roles: one neighbour label each)
+  extern __shared__ f4 lds4[];
+  char* lds = (char*)lds4;
+  float* s_part = (float*)(lds + L::kBytes);  // [NW][K] loss partials per wave (self), then [NW][K] (cross)
+  float* s_part2 = s_part + NW * P.K;
+  const int tile = tile_id(Q);
+  if (tile >= Q.ntiles) return;
+  const int plane = tile / Q.tiles_per_plane;
+  const int rem = tile - plane * Q.tiles_per_plane;
+  const int ty = rem / Q.tiles_x;
+  const int y0 = ty * TH, x0 = (rem - ty * Q.tiles_x) * TW;
+  const int b = plane / P.Z, z = plane - b * P.Z;
+  const size_t S = (size_t)P.S;
+  const unsigned YX = (unsigned)(P.Y * P.X);
+  const rsrc_t xB = mkbuf(xt + (size_t)b * D_T * S), nB = mkbuf(nbt + (size_t)b * D_T * S);
+  const rsrc_t dB = mkbuf(dx + (size_t)b * D_T * S);
+  const rsrc_t lB = mkbuf(labels + (size_t)b * S);
+  const rsrc_t aB = mkbuf(affs ? affs + (size_t)b * P.K * S : nullptr);
+  const bool has_a = affs != nullptr;
+  const bool relu = P.flags & PEA_FLAG_RELU_AFFS;
+  const bool pad = lflags & PEA_TGT_PADDING, fg = lflags & PEA_TGT_BOTH_FOREGROUND, msk = lflags & kLabMask;
+  const unsigned ecs = (unsigned)P.S * (unsigned)sizeof(T);
+  const unsigned ezo = (unsigned)z * YX * (unsigned)sizeof(T);
+  const unsigned kcs = (unsigned)P.S * 4u, kzo = (unsigned)z * YX * 4u;
+  const float dl = dloss ? dloss[0] : 1.f, dl2 = dloss2 ? dloss2[0] : 1.f;
+  const rsrc_t mB2 = mkbuf(emat + (size_t)b * D_T * S);
+  const float* wt_b = wtab + 2 * (size_t)b * P.K;  // {wpos, wneg} per channel of this image
+
+  int ly, lx;
+  lane_pixel<TW>(ly, lx);
+  const int py = y0 + ly, px = x0 + lx;
+  const bool live = py < P.Y && px < P.X;
+  const unsigned po = (unsigned)(py * P.X + px);
+  const unsigned pe = live ? po * (unsigned)sizeof(T) : kOOB;
+  const unsigned pb = live ? po * 4u : kOOB;
+  const int pr = (ly + Q.hy0) * Q.RW + lx + Q.hx0;
+  const int wave = threadIdx.x >> 6;
+
+  // neighbour label of (near entry, role): role A at p + o, role B at p - o, UNWRAPPED (a neighbour outside the image
+  // has no label: inside = false, the load reads out of range)
+  int ln[KN][NR];
+  bool lin[KN][NR];
+  int lnA[kDualNear];   // role-A labels of the near entries, kept for the cross phase
+  unsigned linA = 0;    // ... and their inside flags, one bit each
+#define PEA_LAB_LOAD1(u, k)                                                                                  \
+  {                                                                                                          \
+    _Pragma("unroll") for (int r = 0; r < NR; ++r) {                                                         \
+      const OffEnt en_ = Q.near[min((k), Q.n_near - 1)];                                                     \
+      const int sg_ = r == 0 ? 1 : -1;                                                                       \
+      const int uy_ = py + sg_ * ent_oy(en_), ux_ = px + sg_ * ent_ox(en_);                                  \
+      const bool in_ = live && (unsigned)uy_ < (unsigned)P.Y && (unsigned)ux_ < (unsigned)P.X && ((k) < Q.n_near); \
+      lin[u][r] = in_;                                                                                       \
+      ln[u][r] = __builtin_amdgcn_raw_buffer_load_b32(lB, in_ ? (unsigned)(uy_ * P.X + ux_) * 4u : kOOB, kzo, 0); \
+    }                                                                                                        \
+  }
+
+  // (1) own label, the neighbour labels of the first near chunk (and, EMA cross loss, the own raw pixel): in flight
+  //     during staging
+  const int lown = __builtin_amdgcn_raw_buffer_load_b32(lB, pb, kzo, 0);
+  float xh[D_T];
+  if (!ROLE_B) {
+#pragma unroll
+    for (int c = 0; c < D_T; ++c) xh[c] = bl_emb<T>(xB, pe, ezo + c * ecs);
+  }
+#pragma unroll
+  for (int u = 0; u < KN; ++u) PEA_LAB_LOAD1(u, u)
+
+  // (2) stage the neighbour tensor's region, normalised
+  float own_inv = 0.f, own_ss = 0.f;
+  if (ROLE_B) stage_region_own<T, D_T, PLQ, TH, TW, CROP>(P, Q, nB, ezo, ecs, y0, x0, lds, ly, lx, xh, own_inv, own_ss);
+  else stage_region<T, D_T, PLQ, NT, CROP>(P, Q, nB, ezo, ecs, y0, x0, lds);
+
+  // (3) far (offset, role) pairs, one at a time ahead: pair j = (far offset j / NR, role j % NR)
+  const int n_farp = Q.n_far * NR;
+  float fv[D_T];
+  int fl = 0;
+  bool fok = false, fin = false;
+#define PEA_LAB_LOAD_FAR(j)                                                                                   \
+  {                                                                                                           \
+    const OffEnt fe_ = Q.far[(j) / NR];                                                                       \
+    const int sg_ = ((j) % NR) == 0 ? 1 : -1;                                                                 \
+    const int uz_ = z + sg_ * fe_.d, uy_ = py + sg_ * ent_oy(fe_), ux_ = px + sg_ * ent_ox(fe_);              \
+    fin = live && (unsigned)uz_ < (unsigned)P.Z && (unsigned)uy_ < (unsigned)P.Y && (unsigned)ux_ < (unsigned)P.X; \
+    bool okz_, oky_, okx_;                                                                                    \
+    const int zz_ = wrap1<CROP>(uz_, P.Z, okz_);                                                              \
+    const int yy_ = wrap1<CROP>(uy_, P.Y, oky_);                                                              \
+    const int xx_ = wrap1<CROP>(ux_, P.X, okx_);                                                              \
+    fok = live && okz_ && oky_ && okx_;                                                                       \
+    const unsigned zc_ = (unsigned)(CROP ? min(max(zz_, 0), P.Z - 1) : zz_);                                  \
+    const unsigned vo_ = fok ? (unsigned)(yy_ * P.X + xx_) * (unsigned)sizeof(T) : kOOB;                      \
+    _Pragma("unroll") for (int c = 0; c < D_T; ++c) fv[c] = bl_emb<T>(nB, vo_, zc_ * YX * (unsigned)sizeof(T) + c * ecs); \
+    fl = __builtin_amdgcn_raw_buffer_load_b32(lB, fin ? (unsigned)(uy_ * P.X + ux_) * 4u : kOOB,              \
+                                              (unsigned)(fin ? uz_ : 0) * YX * 4u, 0);                        \
+  }
+  if (n_farp > 0) PEA_LAB_LOAD_FAR(0)
+
+  float G[D_T];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < D_T; ++c) {
+    ss = fmaf(xh[c], xh[c], ss);
+    G[c] = 0.f;
+  }
+  if (ROLE_B) ss = own_ss;  // xh is already normalised
+  const bool tiny = ss < P.eps * P.eps;
+  const float invp = ROLE_B ? own_inv : rnorm(ss, Q.inv_eps);
+  if (!ROLE_B) {
+#pragma unroll
+    for (int c = 0; c < D_T; ++c) xh[c] *= invp;
+  }
+  lds_barrier();
+
+  // one pair: a = <own, nbhat>; t, m, w from the two labels; role A also writes affs and the loss partial; returns the
+  // coefficient of nbhat in G.  exists: the pair is part of the loss at all (CROP_ZERO drops pairs that leave the volume).
+#define PEA_LAB_PAIR(ROLE, ent, a_in, exists, lnb, inside, coef)                                              \
+  {                                                                                                           \
+    const bool eq_ = lown == (lnb) && (!fg || (lown > 0 && (lnb) > 0));                                       \
+    const float t_ = ((inside) ? eq_ : pad) ? 1.f : 0.f;                                                      \
+    const float m_ = (msk && !(inside)) ? 0.f : 1.f;                                                          \
+    const float w_ = t_ != 0.f ? wt_b[2 * (ent).i] : wt_b[2 * (ent).i + 1];                                  \
+    float a_ = (exists) ? (a_in) : 0.f;                                                                       \
+    const float rr_ = a_ * m_ - t_ * m_;                                                                      \
+    const float wr_ = (exists) ? w_ * rr_ : 0.f;                                                              \
+    if ((ROLE) == 0) {                                                                                        \
+      if (has_a) bs32<true>(aB, relu ? fmaxf(a_, 0.f) : a_, pb, kzo + (unsigned)(ent).i * kcs);              \
+      const float red_ = wave_sum63(wr_ * rr_);                                                               \
+      if ((threadIdx.x & 63) == 63) s_part[wave * P.K + (ent).i] = red_;                                      \
+    }                                                                                                         \
+    coef = (ent).gscale * wr_ * m_ * dl;                                                                      \
+  }
+#define PEA_LAB_FAR(j)                                                                                        \
+  {                                                                                                           \
+    const OffEnt fe_ = Q.far[(j) / NR];                                                                       \
+    float sq_ = 0.f, dot_ = 0.f;                                                                              \
+    _Pragma("unroll") for (int c = 0; c < D_T; ++c) {                                                         \
+      sq_ = fmaf(fv[c], fv[c], sq_);                                                                          \
+      dot_ = fmaf(xh[c], fv[c], dot_);                                                                        \
+    }                                                                                                         \
+    const float rn_ = rnorm(sq_, Q.inv_eps);                                                                  \
+    float cf_;                                                                                                \
+    PEA_LAB_PAIR((j) % NR, fe_, dot_ * rn_, fok, fl, fin, cf_)                                                \
+    cf_ *= rn_;                                                                                               \
+    _Pragma("unroll") for (int c = 0; c < D_T; ++c) G[c] = fmaf(cf_, fv[c], G[c]);                            \
+  }
+
+  // ---- near pairs: neighbour vectors from LDS ---------------------------------------------------------
+  int jf = 0;  // next far pair to consume (its loads were issued one step earlier)
+  for (int k0 = 0; k0 < Q.n_near; k0 += KN) {
+#pragma unroll
+    for (int u = 0; u < KN; ++u) {
+      if (k0 + u < Q.n_near) {  // uniform
+        const OffEnt en = Q.near[k0 + u];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          float v[D_T];
+          lds_pixel<D_T, PLQ>(lds, pr + (r == 0 ? en.d : -en.d), v);
+          float a = 0.f;
+#pragma unroll
+          for (int c = 0; c < D_T; ++c) a = fmaf(xh[c], v[c], a);
+          const bool exists = live && (!CROP || lin[u][r]);
+          float cf;
+          PEA_LAB_PAIR(r, en, a, exists, ln[u][r], lin[u][r], cf)
+          if (r == 0 && k0 + u < kDualNear) { lnA[k0 + u] = ln[u][0]; linA |= lin[u][0] ? (1u << (k0 + u)) : 0u; }
+#pragma unroll
+          for (int c = 0; c < D_T; ++c) G[c] = fmaf(cf, v[c], G[c]);
+          asm volatile("" ::: "memory");  // one neighbour vector live at a time (see k_bwd_tiled)
+        }
+        if (k0 + KN + u < Q.n_near) PEA_LAB_LOAD1(u, k0 + KN + u)  // rolling prefetch into the freed slot
+        if ((u & 1) == 1 && jf < n_farp) {  // a far pair every two near entries: its round trip hides under LDS work
+          PEA_LAB_FAR(jf)
+          ++jf;
+          if (jf < n_farp) PEA_LAB_LOAD_FAR(jf)
+        }
+      }
+    }
+  }
+  while (jf < n_farp) {
+    PEA_LAB_FAR(jf)
+    ++jf;
+    if (jf < n_farp) PEA_LAB_LOAD_FAR(jf)
+  }
+#undef PEA_LAB_LOAD1
+#undef PEA_LAB_LOAD_FAR
+#undef PEA_LAB_PAIR
+#undef PEA_LAB_FAR
+
+  // ================= phase 2: the cross loss, a_i(p) = <xhat(p), emahat(p + o_i)>, role A only =================
+  lds_barrier();  // every lane is done with x's region
+  stage_region<T, D_T, PLQ, NT, CROP>(P, Q2, mB2, ezo, ecs, y0, x0, lds);
+  const int pr2 = (ly + Q2.hy0) * Q2.RW + lx + Q2.hx0;
+  float fv2[D_T];
+  int fl2 = 0;
+  bool fok2 = false, fin2 = false;
+#define PEA_LAB2_LOAD_FAR(j)                                                                                  \
+  {                                                                                                           \
+    const OffEnt fe_ = Q2.far[j];                                                                             \
+    const int uz_ = z + fe_.d, uy_ = py + ent_oy(fe_), ux_ = px + ent_ox(fe_);                                \
+    fin2 = live && (unsigned)uz_ < (unsigned)P.Z && (unsigned)uy_ < (unsigned)P.Y && (unsigned)ux_ < (unsigned)P.X; \
+    bool okz_, oky_, okx_;                                                                                    \
+    const int zz_ = wrap1<CROP>(uz_, P.Z, okz_);                                                              \
+    const int yy_ = wrap1<CROP>(uy_, P.Y, oky_);                                                              \
+    const int xx_ = wrap1<CROP>(ux_, P.X, okx_);                                                              \
+    fok2 = live && okz_ && oky_ && okx_;                                                                      \
+    const unsigned zc_ = (unsigned)(CROP ? min(max(zz_, 0), P.Z - 1) : zz_);                                  \
+    const unsigned vo_ = fok2 ? (unsigned)(yy_ * P.X + xx_) * (unsigned)sizeof(T) : kOOB;                     \
+    _Pragma("unroll") for (int c = 0; c < D_T; ++c) fv2[c] = bl_emb<T>(mB2, vo_, zc_ * YX * (unsigned)sizeof(T) + c * ecs); \
+    fl2 = __builtin_amdgcn_raw_buffer_load_b32(lB, fin2 ? (unsigned)(uy_ * P.X + ux_) * 4u : kOOB,            \
+                                               (unsigned)(fin2 ? uz_ : 0) * YX * 4u, 0);                      \
+  }
+  if (Q2.n_far > 0) PEA_LAB2_LOAD_FAR(0)
+  lds_barrier();
+#define PEA_LAB2_PAIR(ent, a_in, exists, lnb, inside, coef)                                                   \
+  {                                                                                                           \
+    const bool eq_ = lown == (lnb) && (!fg || (lown > 0 && (lnb) > 0));                                       \
+    const float t_ = ((inside) ? eq_ : pad) ? 1.f : 0.f;                                                      \
+    const float m_ = (msk && !(inside)) ? 0.f : 1.f;                                                          \
+    const float w_ = t_ != 0.f ? wt_b[2 * (ent).i] : wt_b[2 * (ent).i + 1];                                  \
+    const float a_ = (exists) ? (a_in) : 0.f;                                                                 \
+    const float rr_ = a_ * m_ - t_ * m_;                                                                      \
+    const float wr_ = (exists) ? w_ * rr_ : 0.f;                                                              \
+    const float red_ = wave_sum63(wr_ * rr_);                                                                 \
+    if ((threadIdx.x & 63) == 63) s_part2[wave * P.K + (ent).i] = red_;                                       \
+    coef = C2.gscale[(ent).i] * wr_ * m_ * dl2;                                                               \
+  }
+  int jf2 = 0;
+#pragma unroll
+  for (int k = 0; k < kDualNear; ++k) {
+    if (k < Q.n_near) {  // uniform; entry k of both plans is the same offset (host-checked)
+      const OffEnt en = Q.near[k];
+      float v[D_T];
+      lds_pixel<D_T, PLQ>(lds, pr2 + C2.d2[k], v);
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < D_T; ++c) a = fmaf(xh[c], v[c], a);
+      const bool ink = (linA >> k) & 1u;
+      const bool exists = live && (!CROP || ink);
+      float cf;
+      PEA_LAB2_PAIR(en, a, exists, lnA[k], ink, cf)
+#pragma unroll
+      for (int c = 0; c < D_T; ++c) G[c] = fmaf(cf, v[c], G[c]);
+      asm volatile("" ::: "memory");
+      if ((k & 3) == 3 && jf2 < Q2.n_far) {
+        const OffEnt fe = Q2.far[jf2];
+        float sq = 0.f, dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < D_T; ++c) { sq = fmaf(fv2[c], fv2[c], sq); dot = fmaf(xh[c], fv2[c], dot); }
+        const float rn = rnorm(sq, Q.inv_eps);
+        float cf2;
+        PEA_LAB2_PAIR(fe, dot * rn, fok2, fl2, fin2, cf2)
+        cf2 *= rn;
+#pragma unroll
+        for (int c = 0; c < D_T; ++c) G[c] = fmaf(cf2, fv2[c], G[c]);
+        ++jf2;
+        if (jf2 < Q2.n_far) PEA_LAB2_LOAD_FAR(jf2)
+      }
+    }
+  }
+  while (jf2 < Q2.n_far) {
+    const OffEnt fe = Q2.far[jf2];
+    float sq = 0.f, dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < D_T; ++c) { sq = fmaf(fv2[c], fv2[c], sq); dot = fmaf(xh[c], fv2[c], dot); }
+    const float rn = rnorm(sq, Q.inv_eps);
+    float cf2;
+    PEA_LAB2_PAIR(fe, dot * rn, fok2, fl2, fin2, cf2)
+    cf2 *= rn;
+#pragma unroll
+    for (int c = 0; c < D_T; ++c) G[c] = fmaf(cf2, fv2[c], G[c]);
+    ++jf2;
+    if (jf2 < Q2.n_far) PEA_LAB2_LOAD_FAR(jf2)
+  }
+#undef PEA_LAB2_LOAD_FAR
+#undef PEA_LAB2_PAIR
+
+  float proj = 0.f;
+#pragma unroll
+  for (int c = 0; c < D_T; ++c) proj = fmaf(xh[c], G[c], proj);
+  if (tiny) proj = 0.f;  // clamp_min branch of F.normalize: d ehat / d e = I / eps
+  const float sc = invp;  // dloss / dloss2 are already in the coefficients
+  if (lflags & PEA_TGT_ACCUMULATE) {  // uniform: de += (e.g. the EMA cross loss on top of the self loss' gradient)
+    float prev[D_T];
+#pragma unroll
+    for (int c = 0; c < D_T; ++c) prev[c] = bl_emb<T>(dB, pe, ezo + c * ecs);
+#pragma unroll
+    for (int c = 0; c < D_T; ++c) bs_emb<T>(dB, prev[c] + (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
+  } else {
+#pragma unroll
+    for (int c = 0; c < D_T; ++c) bs_emb<T>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
+  }
+
+  lds_barrier();
+  if (threadIdx.x < P.K) {
+    float v = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      v += s_part[w * P.K + threadIdx.x];
+      v2 += s_part2[w * P.K + threadIdx.x];
+    }
+    partials[(size_t)threadIdx.x * Q.ntiles + tile] = v;
+    partials2[(size_t)threadIdx.x * Q.ntiles + tile] = v2;
+  }
+}
+
+// counts of positive targets per (image, channel) straight from the labels (no target tensor), then the weight table
+
 // 2D mapping (no index divisions): a workgroup is 4 waves = 4 rows x 64 columns, every lane walks kCntRows rows spaced 4
 // apart; grid = (ceil(X / 64), ceil(Y / (4 * kCntRows)), B * Z).  Counts go wave ballot -> LDS -> one partial per
 // (workgroup, channel) in the workspace, summed in a fixed order by k_weight_table: no global atomics, no memset (one

@@ -479,6 +479,40 @@ bool try_fused_labels(const KParams& P, const T* x, const T* nb, const int32_t* 
   return true;
 }
 
+// self + detached-EMA cross loss from labels in one launch (k_fused_labels_dual): both plans must split the stencil
+// into the same near / far entries
+template <typename T, int D_T>
+bool try_fused_labels_dual(const KParams& P, const KParams& P2, const T* x, const T* ema, const int32_t* labels, const float* wtab,
+                           unsigned lflags, float* affs, float* partials, float* partials2, const float* dl, const float* dl2, T* dx,
+                           hipStream_t s, int* nparts) {
+  constexpr TileCfg c = bwd_cfg<D_T>(0);
+  TParams Q, Q2;
+  if (!plan_tiles(P, c, true, &Q) || !plan_tiles(P2, c, false, &Q2)) return false;
+  if (Q.n_near > kDualNear || Q2.n_near != Q.n_near || Q2.n_far != Q.n_far || Q2.ntiles != Q.ntiles) return false;
+  CrossPar C2 = {};
+  for (int k = 0; k < Q.n_near; ++k) {
+    if (Q2.near[k].i != Q.near[k].i) return false;
+    C2.d2[k] = Q2.near[k].d;
+  }
+  for (int k = 0; k < Q.n_far; ++k)
+    if (Q2.far[k].i != Q.far[k].i) return false;
+  for (int i = 0; i < PEA_MAX_K; ++i) C2.gscale[i] = P2.gscale[i];
+  const size_t lds = Lds<D_T, c.PLQ>::kBytes + 2 * (size_t)(c.TH * c.TW / 64) * P.K * sizeof(float);
+  if (lds > (size_t)kLdsMax) return false;
+  const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(c.TH * c.TW);
+  if (P.border == PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_fused_labels_dual<T, D_T, c.TH, c.TW, c.PLQ, false>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, Q2, C2, x, ema, labels, wtab, lflags, affs, partials, partials2, dl, dl2, dx);
+  } else {
+    constexpr auto kern = k_fused_labels_dual<T, D_T, c.TH, c.TW, c.PLQ, true>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, Q2, C2, x, ema, labels, wtab, lflags, affs, partials, partials2, dl, dl2, dx);
+  }
+  *nparts = Q.ntiles;
+  return true;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_scale_inplace(T* __restrict__ buf, size_t n4, size_t n, const float* __restrict__ scale) {
   const float sc = scale[0];
@@ -827,6 +861,46 @@ int pea_affinity_fwd_bwd_labels(const PeaDesc* desc, const void* e, const void* 
   rc = hip_rc();
   if (rc) return rc;
   hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P, partials, nparts, loss_out);
+  return hip_rc();
+}
+
+int pea_affinity_fwd_bwd_labels_dual(const PeaDesc* desc, const PeaDesc* desc_cross, const void* e, const void* ema,
+                                     const int32_t* labels, const float* wtab, unsigned flags, float* affs, float* loss_out,
+                                     float* loss_cross_out, const float* dloss, const float* dloss_cross, void* de,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = validate(desc);
+  if (rc) return rc;
+  rc = validate(desc_cross);
+  if (rc) return rc;
+  if (!e || !ema || !labels || !wtab || !loss_out || !loss_cross_out || !de) return PEA_E_NULL;
+  if (desc->B != desc_cross->B || desc->D != desc_cross->D || desc->K != desc_cross->K || desc->dtype != desc_cross->dtype ||
+      desc->border != desc_cross->border || memcmp(desc->dims, desc_cross->dims, sizeof(desc->dims)) != 0 ||
+      memcmp(desc->offsets, desc_cross->offsets, sizeof(desc->offsets)) != 0 || desc->flags != desc_cross->flags ||
+      desc->eps != desc_cross->eps)
+    return PEA_E_DESC;  // the two losses may differ in lambda and in the normaliser only
+  const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
+  if (misaligned(e, es) || misaligned(ema, es) || misaligned(de, es) || misaligned(affs, 4) || misaligned(labels, 4) ||
+      misaligned(wtab, 4) || misaligned(loss_out, 4) || misaligned(loss_cross_out, 4) || misaligned(dloss, 4) ||
+      misaligned(dloss_cross, 4) || misaligned(workspace, 4))
+    return PEA_E_ALIGN;
+  if (flags & ~(PEA_TGT_PADDING | PEA_TGT_BOTH_FOREGROUND | PEA_TGT_MASK_INSIDE)) return PEA_E_DESC;
+  const KParams P = make_params(desc), P2 = make_params(desc_cross);
+  const size_t np = fwd_partials(P) * P.K;
+  if (!workspace || workspace_bytes < 2 * np * sizeof(float)) return PEA_E_WORKSPACE;
+  if (P.D != 16 || env_int("PEA_FORCE_DIRECT", 0) != 0 || env_int("PEA_LABELS_DUAL", 1) == 0) return PEA_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  float *partials = (float*)workspace, *partials2 = partials + np;
+  int nparts = 0;
+  bool done = desc->dtype == PEA_F16
+                  ? try_fused_labels_dual<__half, 16>(P, P2, (const __half*)e, (const __half*)ema, labels, wtab, flags, affs, partials,
+                                                      partials2, dloss, dloss_cross, (__half*)de, s, &nparts)
+                  : try_fused_labels_dual<float, 16>(P, P2, (const float*)e, (const float*)ema, labels, wtab, flags, affs, partials,
+                                                     partials2, dloss, dloss_cross, (float*)de, s, &nparts);
+  if (!done) return PEA_E_UNSUPPORTED;
+  rc = hip_rc();
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P, partials, nparts, loss_out);
+  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P2, partials2, nparts, loss_cross_out);
   return hip_rc();
 }
 

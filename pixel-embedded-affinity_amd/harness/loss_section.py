@@ -252,65 +252,76 @@ class _LabelsSection(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         dev = embs[0].device
         L = _lib.lib()
-        flags2d, gen_flags, has_mask = specs[0].label_flags
+        lflags, gen_flags, has_mask = specs[0].label_flags
         ncall = len(specs)
         kmax = max(sp.K for sp in specs)
         with torch.cuda.device(dev):
             wdev = _weights_on(dev, weights)
             rows = torch.empty((ncall, 1 + kmax), dtype=torch.float32, device=dev)
-            grads, pred = [], None
-            wtab_full = None
-            for j in range(ncall):
-                cross = j == ncall - 1
-                e = embs[0] if cross else embs[j]
-                e_c = op._embedding_arg(e, "embedding")
-                o_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e_c.dtype) if cross else None
-                lab = labels_list[0] if cross else labels_list[j]
-                lab = lab.to(torch.int32).contiguous()
-                spec = specs[j]
-                d = op.make_desc(spec, e_c)
+            st = op._stream()
+
+            def prep(j):
+                e_c = op._embedding_arg(embs[j], "embedding")
+                lab = labels_list[j].to(torch.int32).contiguous()
+                d = op.make_desc(specs[j], e_c)
                 cb = L.pea_targets_workspace_bytes(ctypes.byref(d))
                 counts = torch.empty(max(cb, 4) // 4, dtype=torch.int32, device=dev)
-                if cross and wtab_full is not None:
-                    wtab = wtab_full  # same labels, same stencil as the full-resolution self loss
-                else:
-                    wtab = torch.empty(e_c.shape[0] * spec.K * 2, dtype=torch.float32, device=dev)
-                    _lib.check(L.pea_label_weights(ctypes.byref(d), op._ptr(lab), flags2d, op._ptr(wtab), op._ptr(counts), cb,
-                                                   op._stream()), "pea_label_weights")
-                    if j == 0:
-                        wtab_full = wtab
+                wtab = torch.empty(e_c.shape[0] * specs[j].K * 2, dtype=torch.float32, device=dev)
+                _lib.check(L.pea_label_weights(ctypes.byref(d), op._ptr(lab), lflags, op._ptr(wtab), op._ptr(counts), cb, st),
+                           "pea_label_weights")
+                return e_c, lab, d, wtab, counts, cb
+
+            def one(j, e_c, o_c, lab, d, wtab, counts, cb, affs, de, accumulate):
+                """loss j as one labels-in launch (or, where no labels kernel applies -- the coarsest scales are smaller
+                than a tile --, targets on the GPU + the two tensor launches), gradient weighted by weights[j]"""
                 wsb = L.pea_workspace_bytes(ctypes.byref(d))
                 work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=dev)
-                want_pred = j == 0
-                affs = torch.empty(op._affs_shape(e_c, spec.K), dtype=torch.float32, device=dev) if want_pred else None
-                de = grads[0] if cross else torch.empty_like(e_c)
-                fl = flags2d | (_lib.TGT_ACCUMULATE if cross else 0)
-                row = rows[j]
+                fl = lflags | (_lib.TGT_ACCUMULATE if accumulate else 0)
                 rc = L.pea_affinity_fwd_bwd_labels(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(lab), op._ptr(wtab), fl,
-                                                   op._ptr(affs), op._ptr(row), op._ptr(wdev[j:j + 1]), op._ptr(de), op._ptr(work),
-                                                   wsb, op._stream())
-                if rc == _lib.E_UNSUPPORTED:
-                    # no labels kernel for this call (the coarsest scales are smaller than a tile): targets on the GPU,
-                    # then the two tensor launches with the same weight as dloss
-                    if cross:
-                        raise NotImplementedError("the cross loss needs the labels-in kernel (D = 16 or 32)")
-                    kshape = op._affs_shape(e_c, spec.K)
-                    t = torch.empty(kshape, dtype=torch.float32, device=dev)
-                    m = torch.empty(kshape, dtype=torch.uint8, device=dev) if has_mask else None
-                    w = torch.empty(kshape, dtype=torch.float32, device=dev)
-                    _lib.check(L.pea_gen_targets(ctypes.byref(d), op._ptr(lab), gen_flags, op._ptr(t), op._ptr(m), op._ptr(w),
-                                                 op._ptr(counts), cb, op._stream()), "pea_gen_targets")
-                    g = torch.empty(kshape, dtype=torch.float32, device=dev)
-                    _lib.check(L.pea_affinity_fwd(ctypes.byref(d), op._ptr(e_c), None, op._ptr(t), op._ptr(w), op._ptr(m), op._ptr(affs),
-                                                  op._ptr(g), op._ptr(row), op._ptr(work), wsb, op._stream()), "pea_affinity_fwd")
-                    _lib.check(L.pea_affinity_bwd(ctypes.byref(d), op._ptr(e_c), None, op._ptr(g), op._ptr(wdev[j:j + 1]), op._ptr(de),
-                                                  None, op._stream()), "pea_affinity_bwd")
-                else:
+                                                   op._ptr(affs), op._ptr(rows[j]), op._ptr(wdev[j:j + 1]), op._ptr(de), op._ptr(work),
+                                                   wsb, st)
+                if rc != _lib.E_UNSUPPORTED:
                     _lib.check(rc, "pea_affinity_fwd_bwd_labels")
-                if not cross:
-                    grads.append(de)
-                if want_pred:
-                    pred = affs
+                    return
+                if accumulate:
+                    raise NotImplementedError("the cross loss needs the labels-in kernel (D = 16 or 32)")
+                kshape = op._affs_shape(e_c, specs[j].K)
+                t = torch.empty(kshape, dtype=torch.float32, device=dev)
+                m = torch.empty(kshape, dtype=torch.uint8, device=dev) if has_mask else None
+                w = torch.empty(kshape, dtype=torch.float32, device=dev)
+                _lib.check(L.pea_gen_targets(ctypes.byref(d), op._ptr(lab), gen_flags, op._ptr(t), op._ptr(m), op._ptr(w),
+                                             op._ptr(counts), cb, st), "pea_gen_targets")
+                g = torch.empty(kshape, dtype=torch.float32, device=dev)
+                _lib.check(L.pea_affinity_fwd(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(t), op._ptr(w), op._ptr(m), op._ptr(affs),
+                                              op._ptr(g), op._ptr(rows[j]), op._ptr(work), wsb, st), "pea_affinity_fwd")
+                _lib.check(L.pea_affinity_bwd(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(g), op._ptr(wdev[j:j + 1]), op._ptr(de),
+                                              None, st), "pea_affinity_bwd")
+
+            # ---- full resolution: self + cross.  One launch with two LDS phases when the library has it (same labels,
+            #      same weights, same own pixel), else two launches, the second accumulating onto the first's gradient
+            jx = ncall - 1
+            e0, lab0, d0, wtab0, counts0, cb0 = prep(0)
+            ema_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e0.dtype)
+            dx_ = op.make_desc(specs[jx], e0)
+            pred = torch.empty(op._affs_shape(e0, specs[0].K), dtype=torch.float32, device=dev)
+            de0 = torch.empty_like(e0)
+            wsb2 = 2 * L.pea_workspace_bytes(ctypes.byref(d0))
+            work2 = torch.empty(max(wsb2, 4) // 4, dtype=torch.float32, device=dev)
+            rc = L.pea_affinity_fwd_bwd_labels_dual(ctypes.byref(d0), ctypes.byref(dx_), op._ptr(e0), op._ptr(ema_c), op._ptr(lab0),
+                                                    op._ptr(wtab0), lflags, op._ptr(pred), op._ptr(rows[0]), op._ptr(rows[jx]),
+                                                    op._ptr(wdev[0:1]), op._ptr(wdev[jx:jx + 1]), op._ptr(de0), op._ptr(work2), wsb2, st)
+            if rc == _lib.E_UNSUPPORTED:
+                one(0, e0, None, lab0, d0, wtab0, counts0, cb0, pred, de0, False)
+                one(jx, e0, ema_c, lab0, dx_, wtab0, counts0, cb0, None, de0, True)
+            else:
+                _lib.check(rc, "pea_affinity_fwd_bwd_labels_dual")
+            grads = [de0]
+            # ---- the deep-supervision scales
+            for j in range(1, jx):
+                e_c, lab, d, wtab, counts, cb = prep(j)
+                de = torch.empty_like(e_c)
+                one(j, e_c, None, lab, d, wtab, counts, cb, None, de, False)
+                grads.append(de)
             losses = rows[:, 0]
             total = (losses * wdev).sum()
         ctx.grads = grads

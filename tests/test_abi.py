@@ -27,7 +27,7 @@ def test_header_declares_the_expected_entry_points():
                                          "pea_affinity_fwd_bwd", "pea_scale_inplace", "pea_fill_border_relu",
                                          "pea_targets_workspace_bytes", "pea_gen_targets",
                                          "pea_stitch_add", "pea_stitch_finalize", "pea_label_weights",
-                                         "pea_affinity_fwd_bwd_labels"])
+                                         "pea_affinity_fwd_bwd_labels", "pea_affinity_fwd_bwd_labels_dual"])
 
 
 def test_library_exports_every_declared_symbol(pkg, lib):
