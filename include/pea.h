@@ -148,6 +148,9 @@ int pea_affinity_fwd_bwd(const PeaDesc *desc, const void *e, const void *e_other
  * (autograd's grad_output): the kernel reads it and returns without touching buf when it is exactly 1, which is
  * what a plain loss.backward() hands to the gradient pea_affinity_fwd_bwd produced for dloss = 1. */
 int pea_scale_inplace(void *buf, int dtype, size_t n, const float *scale, void *stream);
+/* the same for up to 8 buffers (host arrays of device pointers / element counts) in one launch: the gradients of one loss
+ * section share their grad_output */
+int pea_scale_inplace_multi(void *const *bufs, const size_t *counts, int nbuf, int dtype, const float *scale, void *stream);
 
 /* Caller epilogue of the 3D path, in place on affs [B,K,Z,Y,X] (scripts_ac3ac4/main.py:233-237, 296-300;
  * scripts_ac3ac4/inference.py:160-164): pred[:,0,:s] = pred[:,0,s:2s] (z), pred[:,1,:,:s] = pred[:,1,:,s:2s] (y),

@@ -24,7 +24,7 @@ FLAG_RELU_AFFS = 1
 TGT_PADDING, TGT_BOTH_FOREGROUND, TGT_MASK_INSIDE, TGT_ACCUMULATE = 1, 2, 4, 8
 
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",
-           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_bwd", "pea_scale_inplace", "pea_fill_border_relu",
+           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_bwd", "pea_scale_inplace", "pea_scale_inplace_multi", "pea_fill_border_relu",
            "pea_targets_workspace_bytes", "pea_gen_targets", "pea_stitch_add", "pea_stitch_finalize",
            "pea_label_weights", "pea_affinity_fwd_bwd_labels", "pea_affinity_fwd_bwd_labels_dual")
 
@@ -106,6 +106,8 @@ def lib():
     L.pea_targets_workspace_bytes.argtypes = [dp]
     L.pea_gen_targets.restype = ctypes.c_int
     L.pea_gen_targets.argtypes = [dp, vp, ctypes.c_uint, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.pea_scale_inplace_multi.restype = ctypes.c_int
+    L.pea_scale_inplace_multi.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.c_int, vp, vp]
     L.pea_label_weights.restype = ctypes.c_int
     L.pea_label_weights.argtypes = [dp, vp, ctypes.c_uint, vp, vp, ctypes.c_size_t, vp]
     L.pea_affinity_fwd_bwd_labels.restype = ctypes.c_int

@@ -588,6 +588,28 @@ __global__ __launch_bounds__(256) void k_stitch_finalize(float* __restrict__ out
   for (int c = 0; c < C; ++c) out[c * S + i] = __fdiv_rn(out[c * S + i], w);
 }
 
+struct ScaleMulti { void* buf[8]; unsigned long long n[8]; };
+// up to 8 buffers in one launch (blockIdx.y = buffer): the gradients of one loss section share their grad_output
+template <typename T>
+__global__ __launch_bounds__(256) void k_scale_multi(const ScaleMulti M, const float* __restrict__ scale) {
+  const float sc = scale[0];
+  if (sc == 1.0f) return;  // the loss.backward() case: a few hundred workgroups that read one float
+  T* buf = (T*)M.buf[blockIdx.y];
+  const size_t n = (size_t)M.n[blockIdx.y];
+  const size_t stride = (size_t)gridDim.x * 256, t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (sizeof(T) == 4 && (((uintptr_t)buf) & 15) == 0) {
+    const size_t n4 = n / 4;
+    for (size_t i = t; i < n4; i += stride) {
+      f4 v = ((f4*)buf)[i];
+      v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+      ((f4*)buf)[i] = v;
+    }
+    for (size_t i = 4 * n4 + t; i < n; i += stride) st(buf, i, ld(buf, i) * sc);
+  } else {
+    for (size_t i = t; i < n; i += stride) st(buf, i, ld(buf, i) * sc);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -901,6 +923,26 @@ int pea_affinity_fwd_bwd_labels_dual(const PeaDesc* desc, const PeaDesc* desc_cr
   if (rc) return rc;
   hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P, partials, nparts, loss_out);
   hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P2, partials2, nparts, loss_cross_out);
+  return hip_rc();
+}
+
+int pea_scale_inplace_multi(void* const* bufs, const size_t* counts, int nbuf, int dtype, const float* scale, void* stream) {
+  if (!bufs || !counts || !scale) return PEA_E_NULL;
+  if (nbuf < 1 || nbuf > 8 || (dtype != PEA_F32 && dtype != PEA_F16)) return PEA_E_DESC;
+  ScaleMulti M = {};
+  size_t nmax = 0;
+  for (int i = 0; i < nbuf; ++i) {
+    if (!bufs[i]) return PEA_E_NULL;
+    if (misaligned(bufs[i], dtype == PEA_F32 ? 4 : 2)) return PEA_E_ALIGN;
+    M.buf[i] = bufs[i];
+    M.n[i] = counts[i];
+    nmax = std::max(nmax, counts[i]);
+  }
+  if (misaligned(scale, 4)) return PEA_E_ALIGN;
+  if (nmax == 0) return PEA_OK;
+  const unsigned gx = (unsigned)std::min<size_t>((nmax / 4 + 255) / 256 + 1, 512);  // grid-stride: a fixed, small grid
+  if (dtype == PEA_F32) hipLaunchKernelGGL(k_scale_multi<float>, dim3(gx, (unsigned)nbuf), dim3(256), 0, (hipStream_t)stream, M, scale);
+  else hipLaunchKernelGGL(k_scale_multi<__half>, dim3(gx, (unsigned)nbuf), dim3(256), 0, (hipStream_t)stream, M, scale);
   return hip_rc();
 }
 

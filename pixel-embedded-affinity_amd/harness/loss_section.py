@@ -88,17 +88,15 @@ def _section_backward(ctx, dtotal):
         return (None, None, None, None) + (None,) * n
     grads, ctx.grads = ctx.grads, None
     L = _lib.lib()
-    out = []
-    for k, de in enumerate(grads):
-        if not ctx.needs_input_grad[4 + k]:
-            out.append(None)
-            continue
-        with torch.cuda.device(de.device):
-            dl = dtotal.to(device=de.device, dtype=torch.float32).contiguous()
-            _lib.check(L.pea_scale_inplace(op._ptr(de), _lib.F16 if de.dtype == torch.float16 else _lib.F32, de.numel(), op._ptr(dl),
-                                           op._stream()), "pea_scale_inplace")
-        out.append(de)
-    return (None, None, None, None) + tuple(out)
+    dev = grads[0].device
+    with torch.cuda.device(dev):
+        # one launch rescales every gradient by grad_output (and returns untouched when that is exactly 1)
+        dl = dtotal.to(device=dev, dtype=torch.float32).contiguous()
+        bufs = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
+        cnts = (ctypes.c_size_t * n)(*[g.numel() for g in grads])
+        _lib.check(L.pea_scale_inplace_multi(bufs, cnts, n, _lib.F16 if grads[0].dtype == torch.float16 else _lib.F32, op._ptr(dl),
+                                             op._stream()), "pea_scale_inplace_multi")
+    return (None, None, None, None) + tuple(g if ctx.needs_input_grad[4 + k] else None for k, g in enumerate(grads))
 
 
 def _section_specs(offsets, nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb):
