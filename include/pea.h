@@ -131,6 +131,14 @@ int pea_affinity_fwd(const PeaDesc *desc, const void *e, const void *e_other, co
 int pea_affinity_bwd(const PeaDesc *desc, const void *e, const void *e_other, const float *g, const float *dloss,
                      void *de, void *de_other, void *stream);
 
+/* The backward of the full-resolution pair of the training loop in one launch: g is what pea_affinity_fwd wrote for the self
+ * loss (e_other = NULL), g_cross what it wrote for the detached-EMA cross loss of the same e (e_other = ema); the stencil
+ * and geometry are desc's (lambda and the normaliser are already inside g / g_cross).
+ *     de = dloss * sum_i g_i d a_i / d e  +  dloss_cross * sum_i g_cross_i d a^ema_i / d e
+ * Returns PEA_E_UNSUPPORTED when two pea_affinity_bwd calls (and an add) must be used instead. */
+int pea_affinity_bwd_dual(const PeaDesc *desc, const void *e, const void *ema, const float *g, const float *g_cross,
+                          const float *dloss, const float *dloss_cross, void *de, void *stream);
+
 /* Training step in ONE launch (the fused WeightedMSE path): the outputs of pea_affinity_fwd -- affs (nullable) and
  * loss_out[1 + K] -- and de = dloss * d loss / d e (same dtype / layout as e) without the g round trip through HBM.
  * Replaces, for the default criterion, the pair embedding_loss(...) + loss.backward()

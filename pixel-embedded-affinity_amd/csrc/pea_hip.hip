@@ -513,6 +513,35 @@ bool try_fused_labels_dual(const KParams& P, const KParams& P2, const T* x, cons
   return true;
 }
 
+// self backward + detached-EMA cross backward in one launch (k_bwd_tiled_dual)
+template <typename T, int D_T>
+bool try_bwd_dual(const KParams& P, const T* x, const T* ema, const float* g, const float* g2, const float* dl, const float* dl2, T* dx,
+                  hipStream_t s) {
+  constexpr TileCfg c = bwd_cfg<D_T>(0);
+  TParams Q, Q2;
+  if (!plan_tiles(P, c, true, &Q) || !plan_tiles(P, c, false, &Q2)) return false;
+  if (Q.n_near > 8 || Q2.n_near != Q.n_near || Q2.n_far != Q.n_far) return false;
+  BwdCross C2 = {};
+  for (int k = 0; k < Q.n_near; ++k) {
+    if (Q2.near[k].i != Q.near[k].i) return false;
+    C2.d2[k] = Q2.near[k].d;
+  }
+  for (int k = 0; k < Q.n_far; ++k)
+    if (Q2.far[k].i != Q.far[k].i) return false;
+  const size_t lds = Lds<D_T, c.PLQ>::kBytes;
+  const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(c.TH * c.TW);
+  if (P.border == PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_bwd_tiled_dual<T, D_T, c.TH, c.TW, c.PLQ, false>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, Q2, C2, x, ema, g, g2, dl, dl2, dx);
+  } else {
+    constexpr auto kern = k_bwd_tiled_dual<T, D_T, c.TH, c.TW, c.PLQ, true>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, Q2, C2, x, ema, g, g2, dl, dl2, dx);
+  }
+  return true;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_scale_inplace(T* __restrict__ buf, size_t n4, size_t n, const float* __restrict__ scale) {
   const float sc = scale[0];
@@ -943,6 +972,25 @@ int pea_scale_inplace_multi(void* const* bufs, const size_t* counts, int nbuf, i
   const unsigned gx = (unsigned)std::min<size_t>((nmax / 4 + 255) / 256 + 1, 512);  // grid-stride: a fixed, small grid
   if (dtype == PEA_F32) hipLaunchKernelGGL(k_scale_multi<float>, dim3(gx, (unsigned)nbuf), dim3(256), 0, (hipStream_t)stream, M, scale);
   else hipLaunchKernelGGL(k_scale_multi<__half>, dim3(gx, (unsigned)nbuf), dim3(256), 0, (hipStream_t)stream, M, scale);
+  return hip_rc();
+}
+
+int pea_affinity_bwd_dual(const PeaDesc* desc, const void* e, const void* ema, const float* g, const float* g_cross,
+                          const float* dloss, const float* dloss_cross, void* de, void* stream) {
+  const int rc = validate(desc);
+  if (rc) return rc;
+  if (!e || !ema || !g || !g_cross || !de) return PEA_E_NULL;
+  const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
+  if (misaligned(e, es) || misaligned(ema, es) || misaligned(de, es) || misaligned(g, 4) || misaligned(g_cross, 4) ||
+      misaligned(dloss, 4) || misaligned(dloss_cross, 4))
+    return PEA_E_ALIGN;
+  const KParams P = make_params(desc);
+  if (P.D != 16 || env_int("PEA_FORCE_DIRECT", 0) != 0 || env_int("PEA_BWD_DUAL", 1) == 0) return PEA_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const bool done = desc->dtype == PEA_F16
+                        ? try_bwd_dual<__half, 16>(P, (const __half*)e, (const __half*)ema, g, g_cross, dloss, dloss_cross, (__half*)de, s)
+                        : try_bwd_dual<float, 16>(P, (const float*)e, (const float*)ema, g, g_cross, dloss, dloss_cross, (float*)de, s);
+  if (!done) return PEA_E_UNSUPPORTED;
   return hip_rc();
 }
 

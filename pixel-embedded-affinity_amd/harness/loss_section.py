@@ -43,13 +43,13 @@ class _TensorSection(torch.autograd.Function):
             wdev = _weights_on(dev, weights)
             rows = torch.empty((ncall, 1 + kmax), dtype=torch.float32, device=dev)
             grads, pred = [], None
-            for j in range(ncall):
-                cross = j == ncall - 1
-                e_c = op._embedding_arg(embs[0] if cross else embs[j], "embedding")
-                o_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e_c.dtype) if cross else None
+            st = op._stream()
+
+            def forward_one(j, e_c, o_c, want_affs):
+                """forward launch of loss j -> (desc, g, affs)"""
                 spec = specs[j]
                 kshape = op._affs_shape(e_c, spec.K)
-                t, w, m = tensors[0] if cross else tensors[j]
+                t, w, m = tensors[0] if j == ncall - 1 else tensors[j]
                 t, ts = op._batch_strided(t, "target", torch.float32, kshape)
                 w, ws = op._batch_strided(w, "weightmap", torch.float32, kshape)
                 ms = 0
@@ -60,19 +60,38 @@ class _TensorSection(torch.autograd.Function):
                 d = op.make_desc(spec, e_c, ts, ws, ms)
                 wsb = L.pea_workspace_bytes(ctypes.byref(d))
                 work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=dev)
-                affs = torch.empty(kshape, dtype=torch.float32, device=dev) if j == 0 else None
+                affs = torch.empty(kshape, dtype=torch.float32, device=dev) if want_affs else None
                 g = torch.empty(kshape, dtype=torch.float32, device=dev)
                 _lib.check(L.pea_affinity_fwd(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(t), op._ptr(w), op._ptr(m),
-                                              op._ptr(affs), op._ptr(g), op._ptr(rows[j]), op._ptr(work), wsb, op._stream()), "pea_affinity_fwd")
+                                              op._ptr(affs), op._ptr(g), op._ptr(rows[j]), op._ptr(work), wsb, st), "pea_affinity_fwd")
+                return d, g, affs
+
+            def backward_one(j, d, e_c, o_c, g):
                 de = torch.empty_like(e_c)
                 _lib.check(L.pea_affinity_bwd(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(g), op._ptr(wdev[j:j + 1]),
-                                              op._ptr(de), None, op._stream()), "pea_affinity_bwd")
-                if cross:
-                    grads[0].add_(de)
-                else:
-                    grads.append(de)
-                if j == 0:
-                    pred = affs
+                                              op._ptr(de), None, st), "pea_affinity_bwd")
+                return de
+
+            # ---- full resolution: self + cross; their backwards run as one launch with two LDS phases when the library
+            #      has it (pea_affinity_bwd_dual), else as two launches and an add
+            jx = ncall - 1
+            e0 = op._embedding_arg(embs[0], "embedding")
+            ema_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e0.dtype)
+            d0, g0, pred = forward_one(0, e0, None, True)
+            dxx, gx, _ = forward_one(jx, e0, ema_c, False)
+            de0 = torch.empty_like(e0)
+            rc = L.pea_affinity_bwd_dual(ctypes.byref(d0), op._ptr(e0), op._ptr(ema_c), op._ptr(g0), op._ptr(gx), op._ptr(wdev[0:1]),
+                                         op._ptr(wdev[jx:jx + 1]), op._ptr(de0), st)
+            if rc == _lib.E_UNSUPPORTED:
+                de0 = backward_one(0, d0, e0, None, g0)
+                de0.add_(backward_one(jx, dxx, e0, ema_c, gx))
+            else:
+                _lib.check(rc, "pea_affinity_bwd_dual")
+            grads.append(de0)
+            for j in range(1, jx):
+                e_c = op._embedding_arg(embs[j], "embedding")
+                d, g, _ = forward_one(j, e_c, None, False)
+                grads.append(backward_one(j, d, e_c, None, g))
             losses = rows[:, 0]
             total = (losses * wdev).sum()
         ctx.grads = grads
