@@ -461,8 +461,11 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 // later.  An explicit s_nop after the store restores the wait states.
 template <bool NTL>
 __device__ __forceinline__ void bs128(rsrc_t r, f4 v, unsigned vo, unsigned so) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, vo, so, NTL ? kAuxNT : 0);
-  asm volatile("s_nop 1" ::: "memory");
+  const u4 d = __builtin_bit_cast(u4, v);
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, vo, so, NTL ? kAuxNT : 0);
+  // the data registers are an INPUT of the nop, so no VALU write to them can be scheduled between the two (seen: the
+  // scheduler moved `v_mov_b32 v44, 0` of the next quad in between, which zeroed g at scattered pixels)
+  asm volatile("s_nop 1" ::"v"(d) : "memory");
 }
 
 template <typename T, int D_T, int TH, int TW, int PLQ, bool OVL, bool CROP, bool TRAIN, bool SELF>
