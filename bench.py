@@ -95,13 +95,20 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    # one rank per GPU over RCCL; with more ranks than GPUs (a rehearsal on a smaller box) the ranks share devices and the
+    # two control-plane collectives (barrier, max of the wall time) go over gloo -- there is no data-path collective
+    shared = world > ndev
+    torch.cuda.set_device(local % ndev)
+    dev = torch.device("cuda", local % ndev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     pkg = ge.load_package()
     synth = __import__("importlib").import_module(ge.PKG_NAME + ".utils.synth")
@@ -134,7 +141,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     px_per_step = world * B * H * W
