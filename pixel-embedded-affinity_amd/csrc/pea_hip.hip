@@ -186,6 +186,9 @@ bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, TParams* Q) {
       if (near_mask >> i & 1u) q.near[q.n_near++] = OffEnt{i, oy * q.RW + ox, oyx, P.gscale[i]};
       else q.far[q.n_far++] = OffEnt{i, P.off[i][0], oyx, P.gscale[i]};
     }
+    q.zrun = 0;
+    for (int k = 0; k < q.n_far; ++k)
+      if (q.far[k].d != 0 && P.Z > 1 && env_int("PEA_ZFAST", 1) != 0) q.zrun = P.Z;
     *Q = q;
     return true;
   }

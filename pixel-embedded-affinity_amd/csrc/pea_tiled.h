@@ -52,6 +52,7 @@ struct TParams {
   float inv_eps;           // 1 / eps
   int tiles_y, tiles_x, tiles_per_plane;
   int ntiles, tiles_per_xcd;
+  int zrun;                // > 1: walk z fastest (zrun = Z) so that the planes an oz != 0 offset reaches are in L2
   int n_near, n_far;
   OffEnt near[PEA_MAX_K];  // served from LDS
   OffEnt far[PEA_MAX_K];   // served from global memory (d = oz: may also leave the z plane)
@@ -138,10 +139,19 @@ __device__ __forceinline__ void lds_pixel(const char* __restrict__ lds, int pi, 
   }
 }
 
-// tile id -> (plane = b*Z + z, y0, x0); XCD-aware: XCD group g walks tiles [g*tpx, (g+1)*tpx) in row-major order
+// tile id -> (plane = b*Z + z, y0, x0); XCD-aware: XCD group g walks tiles [g*tpx, (g+1)*tpx) in row-major order.
+// Volumes whose stencil leaves the plane (zrun = Z) walk z FASTEST instead: the tiles running together on an XCD are
+// then a few (y, x) columns over all z, and the z-neighbour blocks a tile gathers from global memory were staged by the
+// tiles just before it -- L2 hits instead of a second, third, ... HBM read of the volume.  The returned id stays
+// plane-major (the partial-sum slot of a tile does not depend on the walk).
 __device__ __forceinline__ int tile_id(const TParams& Q) {
   const int bid = blockIdx.x;
-  return (bid % kXcd) * Q.tiles_per_xcd + bid / kXcd;
+  const int lin = (bid % kXcd) * Q.tiles_per_xcd + bid / kXcd;
+  if (Q.zrun <= 1 || lin >= Q.ntiles) return lin;
+  const int per_b = Q.tiles_per_plane * Q.zrun;
+  const int b = lin / per_b, r = lin - b * per_b;
+  const int rem = r / Q.zrun, z = r - rem * Q.zrun;
+  return (b * Q.zrun + z) * Q.tiles_per_plane + rem;
 }
 
 // wrap (CIRCULAR) or test (CROP) an index one step; host guarantees |o| and the halo are <= the extent
