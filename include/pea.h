@@ -209,6 +209,20 @@ int pea_affinity_fwd_bwd_labels_dual(const PeaDesc *desc, const PeaDesc *desc_cr
                                      float *loss_cross_out, const float *dloss, const float *dloss_cross, void *de,
                                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- the step before the path: the embedding head ----
+ * OutConv = nn.Conv2d(C, D, 1) of scripts_cvppp/model/unet2d_residual.py:67-74 (outconv_emb :307, applied :346; the same
+ * class in scripts_bbbc039v1/model/unet2d_residual.py:67,235) and the 1x1x1 conv3dBlock heads out_put* of
+ * scripts_ac3ac4/model/model_superhuman.py:437-441 (applied :486-490):
+ *     e[b,d,p] = bias[d] + sum_c W[d,c] x[b,c,p]          x f32 [B,C,S] , W f32 [D,C] , bias f32 [D] or NULL , e f32 [B,D,S]
+ * with S = H*W or Z*Y*X contiguous pixels per channel plane.  The backward takes de = d loss / d e (what pea_affinity_bwd
+ * wrote) and returns dx [B,C,S] (nullable), dW [D,C] and db [D] (nullable); the sums over pixels run on the matrix cores in
+ * exact f32, per-workgroup partials in `workspace` (pea_head_workspace_bytes), reduced in a fixed order.
+ * Supported (C, D): (28|32|36|48|64, 16) and (32|64, 32); anything else returns PEA_E_UNSUPPORTED. */
+size_t pea_head_workspace_bytes(int C, int D);
+int pea_head_fwd(int B, int C, int D, size_t S, const float *x, const float *W, const float *bias, float *e, void *stream);
+int pea_head_bwd(int B, int C, int D, size_t S, const float *x, const float *W, const float *de, float *dx, float *dW,
+                 float *db, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- the step after the path: 3D inference stitcher ----
  * Provider_valid.add_vol / get_results of scripts_ac3ac4/data/provider_valid.py:320-349 on the device, so a predicted
  * window never leaves HBM: out_affs [C,Z,Y,X] and weight_map [Z,Y,X] accumulate affs_vol [C,oz,oy,ox] * weight_vol

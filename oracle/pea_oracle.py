@@ -348,3 +348,29 @@ def np_weight_binary_ratio(target, alpha=1.0):
             else:
                 w[b, i] = (alpha * (1 - f) / f * lab + (1 - lab)).astype(np.float32)
     return w
+
+
+# ---------------------------------------------------------------------------------------------------
+# the embedding head (the checker of pea_head_fwd / pea_head_bwd; test infrastructure)
+# ---------------------------------------------------------------------------------------------------
+def np_head_fwd(x, weight, bias=None):
+    """x [B,C,*spatial] f32, weight [D,C], bias [D] or None -> e [B,D,*spatial] f32.
+
+    Follows OutConv.forward = nn.Conv2d(in_ch, out_ch, 1) (scripts_cvppp/model/unet2d_residual.py:67-74) and the
+    1x1x1 conv3dBlock heads (scripts_ac3ac4/model/basic.py:114-127, model_superhuman.py:437-441):
+    e[b,d,p] = bias[d] + sum_c W[d,c] x[b,c,p], accumulated in float64.  Pinned by tests/golden/ghead_*.npz
+    (outputs and autograd gradients of the reference modules themselves)."""
+    e = np.einsum("dc,bc...->bd...", weight.astype(np.float64), x.astype(np.float64))
+    if bias is not None and bias.size:
+        e = e + bias.astype(np.float64).reshape((1, -1) + (1,) * (x.ndim - 2))
+    return e.astype(np.float32)
+
+
+def np_head_bwd(x, weight, de):
+    """-> dx [B,C,*spatial], dW [D,C], db [D] for upstream de [B,D,*spatial] (float64 accumulation)."""
+    B, C, D = x.shape[0], x.shape[1], de.shape[1]
+    x64, de64 = x.astype(np.float64).reshape(B, C, -1), de.astype(np.float64).reshape(B, D, -1)
+    dx = np.einsum("dc,bdp->bcp", weight.astype(np.float64), de64).reshape(x.shape)
+    dW = np.einsum("bdp,bcp->dc", de64, x64)
+    db = de64.sum(axis=(0, 2))
+    return dx.astype(np.float32), dW.astype(np.float32), db.astype(np.float32)

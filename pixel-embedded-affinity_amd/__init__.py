@@ -23,6 +23,7 @@ from .utils.affinity_ours import gen_offsets, multi_offset
 from .utils.postproc import fill_border_relu_, relu_
 from .utils.targets import gen_affs_ours, gen_targets
 from .harness.stitch import VolumeStitcher
+from .model.head import EmbeddingHead, OutConv, head_conv3d_block
 from .harness.loss_section import (ac3ac4_loss_section, ac3ac4_loss_section_composed, ac3ac4_loss_section_from_labels,
                                    cvppp_loss_section, cvppp_loss_section_composed,
                                    cvppp_loss_section_from_labels, deep_weight_factor,
@@ -37,5 +38,5 @@ __all__ = [
     "ema_embedding_loss_from_labels", "LabelsAffinityMSE", "cvppp_loss_section_from_labels", "cvppp_loss_section_composed", "ac3ac4_loss_section_composed",
     "ac3ac4_loss_section_from_labels",
     "embedding_loss_norm1_from_labels", "embedding_loss_norm5_from_labels", "ema_embedding_loss_norm5_from_labels",
-    "embedding_loss_norm6", "ema_embedding_loss_norm6",
+    "embedding_loss_norm6", "ema_embedding_loss_norm6", "EmbeddingHead", "OutConv", "head_conv3d_block",
 ]

@@ -24,7 +24,7 @@ FLAG_RELU_AFFS = 1
 TGT_PADDING, TGT_BOTH_FOREGROUND, TGT_MASK_INSIDE, TGT_ACCUMULATE = 1, 2, 4, 8
 
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",
-           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_bwd_dual", "pea_affinity_fwd_bwd", "pea_scale_inplace", "pea_scale_inplace_multi", "pea_fill_border_relu",
+           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_bwd_dual", "pea_affinity_fwd_bwd", "pea_scale_inplace", "pea_scale_inplace_multi", "pea_fill_border_relu", "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd",
            "pea_targets_workspace_bytes", "pea_gen_targets", "pea_stitch_add", "pea_stitch_finalize",
            "pea_label_weights", "pea_affinity_fwd_bwd_labels", "pea_affinity_fwd_bwd_labels_dual")
 
@@ -122,6 +122,12 @@ def lib():
     L.pea_stitch_finalize.argtypes = [vp, vp, ctypes.c_int, ctypes.c_size_t, vp]
     L.pea_fill_border_relu.restype = ctypes.c_int
     L.pea_fill_border_relu.argtypes = [vp] + [ctypes.c_int] * 7 + [vp]
+    L.pea_head_workspace_bytes.restype = ctypes.c_size_t
+    L.pea_head_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.pea_head_fwd.restype = ctypes.c_int
+    L.pea_head_fwd.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, vp, vp, vp, vp, vp]
+    L.pea_head_bwd.restype = ctypes.c_int
+    L.pea_head_bwd.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     if L.pea_version() != PEA_ABI_VERSION:
         raise PeaLibraryError("ABI mismatch: library %d, binding %d" % (L.pea_version(), PEA_ABI_VERSION))
     _lib = L

@@ -10,6 +10,8 @@ What is imported from the reference (nothing is copied; the files are loaded whe
     scripts_cvppp/loss/loss.py                 WeightedMSE  (run unmodified; its `.cuda()` call at
                                                loss.py:116 is made a no-op on this GPU-less host)
     scripts_cvppp/utils/affinity_ours.py       multi_offset, gen_affs_ours
+    scripts_cvppp/model/unet2d_residual.py     OutConv (the 2D embedding head)
+    scripts_ac3ac4/model/basic.py              conv3dBlock (the 3D embedding head, 1x1x1)
     scripts_cvppp/data/data_segmentation.py    not importable here (needs skimage): weight_binary_ratio
                                                (:205-228) is restated below for realistic class-balance weights.
 
@@ -203,6 +205,33 @@ def case_3d_norm6(name, seed, B, D, Z, Y, X, offsets, ema=False, both=False):
          loss=np.float32(loss.item()), affs=affs.detach().numpy(), grad=et.grad.numpy(), **kw)
 
 
+def case_head(name, seed, B, C, D, spatial, bias=True):
+    """The embedding head: OutConv (2D, unet2d_residual.py:67-74) or conv3dBlock([C],[D],[(1,1,1)]) (3D, basic.py:114-127;
+    model_superhuman.py:437) with seeded parameters; outputs and autograd gradients of sum(e * upstream)."""
+    torch.manual_seed(seed)
+    if len(spatial) == 2:
+        refm = load("ref_unet2d", "scripts_cvppp/model/unet2d_residual.py")
+        head = refm.OutConv(C, D)
+        conv = head.conv
+    else:
+        sys.path.insert(0, os.path.join(REF, "scripts_ac3ac4"))
+        refb = load("ref_basic3d", "scripts_ac3ac4/model/basic.py")
+        head = refb.conv3dBlock([C], [D], [(1, 1, 1)], bias=[bias], init_mode='kaiming_normal')
+        conv = head[0]
+    with torch.no_grad():  # non-trivial parameters whatever the init mode does
+        conv.weight.copy_(torch.randn_like(conv.weight) * 0.3)
+        if conv.bias is not None:
+            conv.bias.copy_(torch.randn_like(conv.bias))
+    x = torch.randn((B, C) + tuple(spatial), requires_grad=True)
+    up = torch.randn((B, D) + tuple(spatial))
+    e = head(x)
+    (e * up).sum().backward()
+    save(name, x=x.detach().numpy(), weight=conv.weight.detach().numpy().reshape(D, C),
+         bias=(conv.bias.detach().numpy() if conv.bias is not None else np.zeros(0, np.float32)),
+         upstream=up.numpy(), e=e.detach().numpy(), dx=x.grad.numpy(), dW=conv.weight.grad.numpy().reshape(D, C),
+         db=(conv.bias.grad.numpy() if conv.bias is not None else np.zeros(0, np.float32)))
+
+
 def case_full_summary(name, seed, B, D, H, W):
     """One full-size CVPPP case (B x 16 x 544 x 544, K=10): too big to store, so inputs are a closed-form
     function of the index (no RNG) and only summary statistics + samples of the outputs are kept."""
@@ -244,6 +273,11 @@ if __name__ == "__main__":
         case_3d_norm6("g3r_norm6_ema", 52, B=1, D=16, Z=4, Y=12, X=13, offsets=O6, ema=True)
         case_3d_norm6("g3r_norm6_ema_both", 53, B=1, D=8, Z=4, Y=11, X=12, offsets=O6[:6], ema=True, both=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "head":  # only the embedding-head fixtures
+        case_head("ghead_2d_c32_d16", 61, B=2, C=32, D=16, spatial=(19, 23))
+        case_head("ghead_2d_c64_d32", 62, B=1, C=64, D=32, spatial=(9, 31))
+        case_head("ghead_3d_c28_d16", 63, B=1, C=28, D=16, spatial=(3, 10, 13))
+        sys.exit(0)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     # 2D, shipped CVPPP stencil (shifts 1,3,5,9,27 x neighbor 4 -> K=10), ragged sizes
@@ -275,3 +309,6 @@ if __name__ == "__main__":
     case_3d_norm6("g3r_norm6_ema_both", 53, B=1, D=8, Z=4, Y=11, X=12, offsets=O6[:6], ema=True, both=True)
     # full CVPPP size, summary only
     case_full_summary("g2d_full544_summary", 555, B=2, D=16, H=544, W=544)
+    case_head("ghead_2d_c32_d16", 61, B=2, C=32, D=16, spatial=(19, 23))
+    case_head("ghead_2d_c64_d32", 62, B=1, C=64, D=32, spatial=(9, 31))
+    case_head("ghead_3d_c28_d16", 63, B=1, C=28, D=16, spatial=(3, 10, 13))

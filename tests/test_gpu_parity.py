@@ -6,6 +6,8 @@ Tolerances (north_star: affinity maps within 1e-4 of the reference; fp32 everywh
 """
 import importlib
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -838,3 +840,78 @@ def test_3d_loss_section_variants_agree(pkg, dev, orc, synth):
         assert np.abs(res[k][1] - res[0][1]).max() < 2e-6
         for a, b in zip(res[k][2], res[0][2]):
             assert relmax(a, b) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["ghead_2d_c32_d16", "ghead_2d_c64_d32", "ghead_3d_c28_d16"])
+def test_head_matches_reference_golden(pkg, dev, name):
+    """pea_head_fwd / pea_head_bwd (through the drop-in modules, parameters loaded the way a checkpoint would be) against
+    the reference's OutConv / conv3dBlock outputs and autograd gradients.  Tolerance 1e-5 of the largest magnitude
+    (f32, other summation order)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    D, C = g["weight"].shape
+    three_d = g["x"].ndim == 5
+    head = (pkg.head_conv3d_block(C, D, bias=bool(g["bias"].size)) if three_d else pkg.OutConv(C, D)).to(dev)
+    wkey, bkey = ("0.weight", "0.bias") if three_d else ("conv.weight", "conv.bias")
+    state = {wkey: torch.from_numpy(g["weight"].reshape((D, C) + (1,) * (g["x"].ndim - 2)))}
+    if g["bias"].size:
+        state[bkey] = torch.from_numpy(g["bias"])
+    head.load_state_dict(state)  # the reference's parameter names
+    x = cu(g["x"], dev).requires_grad_(True)
+    e = head(x)
+    assert np.abs(e.detach().cpu().numpy() - g["e"]).max() <= 1e-5 * np.abs(g["e"]).max()
+    (e * cu(g["upstream"], dev)).sum().backward()
+    conv = head[0] if three_d else head.conv
+    assert relmax(x.grad.cpu().numpy(), g["dx"]) <= 1e-5
+    assert relmax(conv.weight.grad.cpu().numpy().reshape(D, C), g["dW"]) <= 1e-5
+    if g["bias"].size:
+        assert relmax(conv.bias.grad.cpu().numpy(), g["db"]) <= 1e-5
+
+
+def test_head_full_size_vs_oracle_and_into_the_loss(pkg, dev, orc, synth):
+    """the head at a CVPPP-sized batch against the float64 restatement (ragged pixel count: 2 x 530 x 500 is not a
+    multiple of the 256-pixel chunks), dx-less backward, C ABI error codes, and head -> embedding_loss -> backward as one
+    autograd graph"""
+    import ctypes
+    L = pkg._lib.lib()
+    rng = np.random.default_rng(5)
+    B, C, D, H, W = 2, 32, 16, 530, 500
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((D, C)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(D).astype(np.float32)
+    up = rng.standard_normal((B, D, H, W)).astype(np.float32)
+    X, Wt, Bt, UP = cu(x, dev), cu(w, dev), cu(b, dev), cu(up, dev)
+    E = torch.empty(B, D, H, W, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.pea_head_fwd(B, C, D, H * W, p(X), p(Wt), p(Bt), p(E), st) == 0
+    e_ref = orc.np_head_fwd(x, w, b)
+    assert np.abs(E.cpu().numpy() - e_ref).max() <= 1e-5 * np.abs(e_ref).max()
+    wsb = L.pea_head_workspace_bytes(C, D)
+    work = torch.empty(wsb // 4, device=dev)
+    dX, dW, dB = torch.empty_like(X), torch.empty(D, C, device=dev), torch.empty(D, device=dev)
+    assert L.pea_head_bwd(B, C, D, H * W, p(X), p(Wt), p(UP), p(dX), p(dW), p(dB), p(work), wsb, st) == 0
+    dx_ref, dw_ref, db_ref = orc.np_head_bwd(x, w, up)
+    assert relmax(dX.cpu().numpy(), dx_ref) <= 1e-5
+    # 530,000 products per entry: the f32 chains are 130 pixels per wave pass, then per-workgroup partials
+    assert relmax(dW.cpu().numpy(), dw_ref) <= 2e-5 and relmax(dB.cpu().numpy(), db_ref) <= 2e-5
+    dW2 = torch.empty_like(dW)
+    assert L.pea_head_bwd(B, C, D, H * W, p(X), p(Wt), p(UP), None, p(dW2), None, p(work), wsb, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dW2, dW)  # deterministic, and independent of the optional outputs
+    assert L.pea_head_fwd(B, 33, D, H * W, p(X), p(Wt), p(Bt), p(E), st) == pkg._lib.E_UNSUPPORTED
+    assert L.pea_head_bwd(B, C, D, H * W, p(X), p(Wt), p(UP), p(dX), p(dW), p(dB), p(work), wsb - 4, st) == -4  # PEA_E_WORKSPACE
+    # ---- as a module in front of the loss
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    e0, t, wm, m = synth.synth_inputs_2d(1, D, 64, 96, offsets, 9)
+    head = pkg.OutConv(C, D).to(dev)
+    xs = cu(rng.standard_normal((1, C, 64, 96)).astype(np.float32), dev)
+    loss, _, _ = pkg.embedding_loss(head(xs), cu(t, dev), cu(wm, dev), cu(m, dev), pkg.WeightedMSE(), offsets)
+    loss.backward()
+    e_np = orc.np_head_fwd(xs.cpu().numpy(), head.conv.weight.detach().cpu().numpy().reshape(D, C), head.conv.bias.detach().cpu().numpy())
+    d = orc.desc_2d(e_np, offsets)
+    de, _ = orc.c_bwd(d, e_np, None, t, wm, m)
+    _, dw_o, db_o = orc.np_head_bwd(xs.cpu().numpy(), head.conv.weight.detach().cpu().numpy().reshape(D, C), de)
+    assert relmax(head.conv.weight.grad.cpu().numpy().reshape(D, C), dw_o) <= 5e-5
+    assert relmax(head.conv.bias.grad.cpu().numpy(), db_o) <= 5e-5
+    with pytest.raises(RuntimeError):
+        pkg.OutConv(C, D)(torch.zeros(1, C, 8, 8))  # CPU tensors are refused, no fallback

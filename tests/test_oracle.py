@@ -160,3 +160,21 @@ def test_replicate_border_restatement_matches_reference(name):
     assert np.abs(de - g["grad"]).max() <= 2e-5 * np.abs(g["grad"]).max()
     if "grad_ema" in g:
         assert np.abs(de_o - g["grad_ema"]).max() <= 2e-5 * np.abs(g["grad_ema"]).max()
+
+
+@pytest.mark.parametrize("name", ["ghead_2d_c32_d16", "ghead_2d_c64_d32", "ghead_3d_c28_d16"])
+def test_head_restatement_matches_reference(name):
+    """np_head_fwd / np_head_bwd against the outputs and autograd gradients of the reference's OutConv / conv3dBlock
+    (tests/golden/make_golden.py::case_head).  Tolerance: f32 sums of 28-64 products (forward, dx) and of a few hundred
+    to a few thousand (dW, db) in another order: 1e-5 of the largest magnitude."""
+    import oracle.pea_oracle as orc
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    bias = g["bias"] if g["bias"].size else None
+    e = orc.np_head_fwd(g["x"], g["weight"], bias)
+    assert e.shape == g["e"].shape
+    assert np.abs(e - g["e"]).max() <= 1e-5 * np.abs(g["e"]).max()
+    dx, dW, db = orc.np_head_bwd(g["x"], g["weight"], g["upstream"])
+    assert np.abs(dx - g["dx"]).max() <= 1e-5 * np.abs(g["dx"]).max()
+    assert np.abs(dW - g["dW"]).max() <= 1e-5 * np.abs(g["dW"]).max()
+    if bias is not None:
+        assert np.abs(db - g["db"]).max() <= 1e-5 * np.abs(g["db"]).max()
