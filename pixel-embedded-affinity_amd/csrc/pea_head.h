@@ -7,7 +7,7 @@
 //
 // Both kernels stream: one lane per pixel, planar [B,C,S] / [B,D,S] tensors, every access a coalesced 256-byte row of
 // one channel.  They are HBM-bound (forward 4(C+D) bytes per pixel, backward 4(2C+D)); the arithmetic (2CD flops per
-// pixel forward, 4CD backward) is a fifth of the memory time.  W is read through the scalar cache (uniform addresses,
+// pixel forward, 4CD backward) is a fraction of the memory time.  W is read through the scalar cache (uniform addresses,
 // compile-time offsets), so the forward and dx are plain v_fmac with an SGPR operand.  dW = sum_p de[:,p] x[:,p]^T is
 // the one contraction over PIXELS here and goes to the matrix cores: v_mfma_f32_16x16x4_f32 (exact f32, k-ordered fma
 // chain) with A = de[16 d x 4 px], B = x[4 px x 16 c]; the pixel-per-lane registers are turned into that operand
@@ -47,13 +47,38 @@ __global__ __launch_bounds__(kHeadBlock) void k_head_fwd(const float* __restrict
   }
 }
 
-// dx[b,c,p] = sum_d W[d,c] de[b,d,p] (nullable: the input may not need a gradient);
-// partials[wg][D*C + D] = this workgroup's share of dW[d,c] = sum_{b,p} de[b,d,p] x[b,c,p] and db[d] = sum_{b,p} de[b,d,p]
+// dx[b,c,p] = sum_d W[d,c] de[b,d,p]: a streaming kernel of its own (like the forward: loads, 2CD flops, stores, exit).
+// Fused with the dW kernel below it ran 1.6x slower than the two together: vmcnt retires in order, so the next
+// pixels' loads of a looping workgroup wait for the acknowledgements of the dx stores before them.
 template <int C, int D>
-__global__ __launch_bounds__(kHeadBlock) void k_head_bwd(const float* __restrict__ x, const float* __restrict__ W,
-                                                         const float* __restrict__ de, float* __restrict__ dx,
-                                                         float* __restrict__ partials, long long S, int chunks_per_b,
-                                                         int nchunks) {
+__global__ __launch_bounds__(kHeadBlock) void k_head_dx(const float* __restrict__ W, const float* __restrict__ de,
+                                                        float* __restrict__ dx, long long S, int chunks_per_b) {
+  const int b = blockIdx.x / chunks_per_b;
+  const long long p = (long long)(blockIdx.x - b * chunks_per_b) * kHeadBlock + threadIdx.x;
+  if (p >= S) return;
+  const float* deb = de + (size_t)b * D * S + p;
+  float* dxb = dx + (size_t)b * C * S + p;
+  float dv[D], dxv[C];
+#pragma unroll
+  for (int d = 0; d < D; ++d) dv[d] = deb[(size_t)d * S];  // read again by k_head_dw: no non-temporal hint
+#pragma unroll
+  for (int c = 0; c < C; ++c) dxv[c] = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int c = 0; c < C; ++c) dxv[c] = fmaf(W[d * C + c], dv[d], dxv[c]);
+#pragma unroll
+  for (int c = 0; c < C; ++c) __builtin_nontemporal_store(dxv[c], dxb + (size_t)c * S);
+}
+
+// partials[wg][D*C + D] = this workgroup's share of dW[d,c] = sum_{b,p} de[b,d,p] x[b,c,p] and db[d] = sum_{b,p} de[b,d,p].
+// Loads only.  What it needs is rows in flight (HBM latency under load is several times the ~1 us a wave spends on 256
+// pixels): D + C rows per wave, four workgroups per CU where the registers allow (C <= 48, D = 16).  Prefetching the next
+// 256 pixels instead (twice the registers, half the waves) was slower: 114 vs 9x us.
+template <int C, int D>
+__global__ __launch_bounds__(kHeadBlock, (C <= 48 && D == 16) ? 4 : 2) void k_head_dw(const float* __restrict__ x, const float* __restrict__ de,
+                                                        float* __restrict__ partials, long long S, int chunks_per_b,
+                                                        int nchunks) {
   static_assert(D % 16 == 0, "the dW tiles are 16 x 16");
   constexpr int DT = D / 16, CC = (C + 15) / 16, NW = kHeadBlock / 64;
   constexpr int kTileA = D * kHeadRow, kTileB = 16 * kHeadRow;
@@ -74,17 +99,14 @@ __global__ __launch_bounds__(kHeadBlock) void k_head_bwd(const float* __restrict
   float dbv[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) dbv[d] = 0.f;
-  const bool want_dx = dx != nullptr;
 
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {  // uniform trip count per workgroup
     const int b = chunk / chunks_per_b;
     const long long p = (long long)(chunk - b * chunks_per_b) * kHeadBlock + threadIdx.x;
     const bool live = p < S;
-    const size_t pc = live ? (size_t)p : 0;
+    const size_t pc = live ? (size_t)p : 0;  // clamped address, value masked below: no branches around the loads
     const float* deb = de + (size_t)b * D * S + pc;
     const float* xb = x + (size_t)b * C * S + pc;
-    // every load of the iteration is requested up front (addresses are clamped, values masked afterwards): one memory
-    // round trip per 256 pixels with D + C rows in flight per wave
     float dv[D], xv[C];
 #pragma unroll
     for (int d = 0; d < D; ++d) dv[d] = __builtin_nontemporal_load(deb + (size_t)d * S);
@@ -92,23 +114,9 @@ __global__ __launch_bounds__(kHeadBlock) void k_head_bwd(const float* __restrict
     for (int c = 0; c < C; ++c) xv[c] = __builtin_nontemporal_load(xb + (size_t)c * S);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      dv[d] = live ? dv[d] : 0.f;
-      dbv[d] += dv[d];
-      tA[d * kHeadRow + lane] = dv[d];
-    }
-    if (want_dx) {
-      float dxv[C];
-#pragma unroll
-      for (int c = 0; c < C; ++c) dxv[c] = 0.f;
-#pragma unroll
-      for (int d = 0; d < D; ++d)
-#pragma unroll
-        for (int c = 0; c < C; ++c) dxv[c] = fmaf(W[d * C + c], dv[d], dxv[c]);
-      if (live) {
-        float* dxb = dx + (size_t)b * C * S + pc;
-#pragma unroll
-        for (int c = 0; c < C; ++c) __builtin_nontemporal_store(dxv[c], dxb + (size_t)c * S);
-      }
+      const float v = live ? dv[d] : 0.f;
+      dbv[d] += v;
+      tA[d * kHeadRow + lane] = v;
     }
     __builtin_amdgcn_wave_barrier();
     // A operands of the 16 k-steps (4 pixels each), kept for every channel chunk
@@ -168,23 +176,35 @@ __global__ __launch_bounds__(kHeadBlock) void k_head_bwd(const float* __restrict
   }
 }
 
-// dW[d,c], db[d] = sum over the workgroup partials, in workgroup order
+// dW[d,c], db[d] = sum over the workgroup partials in a fixed order.  One workgroup per 16 outputs: thread (o, g) adds
+// the partials of workgroups g, g + 16, g + 32, ... (64-byte coalesced reads, nwg / 16 loads per thread instead of nwg:
+// a thread per output walking all 1024 partials took 75 us, longer than the kernel that produced them), then the 16
+// group sums are added in group order.
 __global__ __launch_bounds__(256) void k_head_finalize(const float* __restrict__ partials, int nwg, int dc, int n,
                                                        float* __restrict__ dW, float* __restrict__ db) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four interleaved chains: shorter dependency, still a fixed order
-  int w = 0;
-  for (; w + 3 < nwg; w += 4) {
-    s0 += partials[(size_t)w * n + t];
-    s1 += partials[(size_t)(w + 1) * n + t];
-    s2 += partials[(size_t)(w + 2) * n + t];
-    s3 += partials[(size_t)(w + 3) * n + t];
+  __shared__ float red[16][17];
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + o;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains: loads in flight, still a fixed order
+  if (t < n) {
+    int w = g;
+    for (; w + 48 < nwg; w += 64) {
+      s0 += partials[(size_t)w * n + t];
+      s1 += partials[(size_t)(w + 16) * n + t];
+      s2 += partials[(size_t)(w + 32) * n + t];
+      s3 += partials[(size_t)(w + 48) * n + t];
+    }
+    for (; w < nwg; w += 16) s0 += partials[(size_t)w * n + t];
   }
-  for (; w < nwg; ++w) s0 += partials[(size_t)w * n + t];
-  const float s = (s0 + s1) + (s2 + s3);
-  if (t < dc) dW[t] = s;
-  else if (db) db[t - dc] = s;
+  red[g][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (threadIdx.x < 16 && t < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][o];
+    if (t < dc) dW[t] = s;
+    else if (db) db[t - dc] = s;
+  }
 }
 
 }  // namespace pea

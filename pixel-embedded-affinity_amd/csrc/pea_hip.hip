@@ -1043,19 +1043,27 @@ int pea_head_bwd(int B, int C, int D, size_t S, const float* x, const float* W, 
   const size_t chunks = (S + kHeadBlock - 1) / kHeadBlock;
   if (chunks * (size_t)B > 0x7fffffffULL) return PEA_E_UNSUPPORTED;
   const int nchunks = (int)(chunks * B);
-  const int nwg = std::min(nchunks, kHeadMaxWg);
+  // dW: a multiple of the CU count that the instantiation keeps resident, no partial round
+  const int nwg = std::min(nchunks, std::min(kHeadMaxWg, ((C <= 48 && D == 16) ? 4 : 2) * device_cus()));
   hipStream_t s = (hipStream_t)stream;
   float* partials = (float*)workspace;
-#define PEA_HEAD_B(c, d)                                                                                                  \
-  if (C == c && D == d)                                                                                                   \
-    hipLaunchKernelGGL((k_head_bwd<c, d>), dim3((unsigned)nwg), dim3(kHeadBlock), 0, s, x, W, de, dx, partials, (long long)S, \
+  if (dx) {
+    const dim3 grid((unsigned)nchunks), blk(kHeadBlock);
+#define PEA_HEAD_X(c, d) \
+  if (C == c && D == d) hipLaunchKernelGGL((k_head_dx<c, d>), grid, blk, 0, s, W, de, dx, (long long)S, (int)chunks);
+    PEA_HEAD_CASES(PEA_HEAD_X)
+#undef PEA_HEAD_X
+  }
+#define PEA_HEAD_B(c, d)                                                                                              \
+  if (C == c && D == d)                                                                                               \
+    hipLaunchKernelGGL((k_head_dw<c, d>), dim3((unsigned)nwg), dim3(kHeadBlock), 0, s, x, de, partials, (long long)S, \
                        (int)chunks, nchunks);
   PEA_HEAD_CASES(PEA_HEAD_B)
 #undef PEA_HEAD_B
   const int rc = hip_rc();
   if (rc) return rc;
   const int n = D * C + D;
-  hipLaunchKernelGGL(k_head_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, partials, nwg, D * C, n, dW, db);
+  hipLaunchKernelGGL(k_head_finalize, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, partials, nwg, D * C, n, dW, db);
   return hip_rc();
 }
 

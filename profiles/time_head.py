@@ -34,11 +34,12 @@ for (B, C, D, sp) in ((8, 32, 16, (544, 544)), (8, 64, 16, (272, 272)), (8, 32, 
     w2 = w.reshape(D, C).contiguous()
     t_f = timed(lambda: L.pea_head_fwd(B, C, D, S, P(x), P(w2), P(b), P(e), st))
     t_b = timed(lambda: L.pea_head_bwd(B, C, D, S, P(x), P(w2), P(de), P(dx), P(dW), P(db), P(work), wsb, st))
+    t_w = timed(lambda: L.pea_head_bwd(B, C, D, S, P(x), P(w2), P(de), None, P(dW), P(db), P(work), wsb, st))
     conv = F.conv3d if len(sp) == 3 else F.conv2d
     xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
     t_tf = timed(lambda: conv(xr, wr, br))
     out = conv(xr, wr, br)
     t_tb = timed(lambda: torch.autograd.grad(out, (xr, wr, br), de, retain_graph=True))
     px = B * S
-    print("B=%d C=%d D=%d %-14s  pea fwd %7.1f us (%4.0f GB/s)  bwd %7.1f us (%4.0f GB/s)   torch fwd %7.1f us  bwd %7.1f us"
-          % (B, C, D, "x".join(map(str, sp)), t_f, 4 * (C + D) * px / t_f / 1e3, t_b, 4 * (2 * C + D) * px / t_b / 1e3, t_tf, t_tb), flush=True)
+    print("B=%d C=%d D=%d %-14s  pea fwd %7.1f us (%4.0f GB/s)  bwd %7.1f us (%4.0f GB/s; dW+db alone %6.1f us)   torch fwd %7.1f us  bwd %7.1f us"
+          % (B, C, D, "x".join(map(str, sp)), t_f, 4 * (C + D) * px / t_f / 1e3, t_b, 4 * (2 * C + D) * px / t_b / 1e3, t_w, t_tf, t_tb), flush=True)
