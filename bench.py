@@ -177,8 +177,19 @@ def main():
         labels_step = lambda: (L.pea_label_weights(ctypes.byref(desc), P(lab), lflags, P(wtab), P(cnt), cnt_bytes, st),
                                L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(Ed), None, P(lab), P(wtab), lflags, P(affs),
                                                              P(lossv), None, P(dE), P(work), wsb, st))
+        # the embedding head in front of the path (OutConv 32 -> D, scripts_cvppp/model/unet2d_residual.py:307): forward and
+        # backward (dx, dW, db) of the 1x1 convolution on the decoder's 32-channel feature map
+        HC = 32
+        hx = torch.randn(B, HC, H, W, device=dev)
+        hw, hb = torch.randn(D, HC, device=dev) * 0.2, torch.randn(D, device=dev)
+        hdx, hdw, hdb = torch.empty_like(hx), torch.empty(D, HC, device=dev), torch.empty(D, device=dev)
+        hws = L.pea_head_workspace_bytes(HC, D)
+        hwork = torch.empty(hws // 4, device=dev)
+        head_fwd = lambda: L.pea_head_fwd(B, HC, D, H * W, P(hx), P(hw), P(hb), P(dE), st)
+        head_bwd = lambda: L.pea_head_bwd(B, HC, D, H * W, P(hx), P(hw), P(dE), P(hdx), P(hdw), P(hdb), P(hwork), hws, st)
         kt = {}
-        for name, fn in (("fwd", fwd), ("bwd", bwd), ("infer", inf), ("fused_fwd_bwd", fused), ("labels_step", labels_step)):
+        for name, fn in (("fwd", fwd), ("bwd", bwd), ("infer", inf), ("fused_fwd_bwd", fused), ("labels_step", labels_step),
+                         ("head_fwd", head_fwd), ("head_bwd", head_bwd)):
             event_time_ms(fn, 10)
             kt[name] = event_time_ms(fn, max(20, min(args.steps, 200)))
         # ---- the training loop's loss section (five self losses over the scales + EMA cross loss + backward + relu,
