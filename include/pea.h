@@ -217,7 +217,8 @@ int pea_affinity_fwd_bwd_labels_dual(const PeaDesc *desc, const PeaDesc *desc_cr
  * with S = H*W or Z*Y*X contiguous pixels per channel plane.  The backward takes de = d loss / d e (what pea_affinity_bwd
  * wrote) and returns dx [B,C,S] (nullable), dW [D,C] and db [D] (nullable); the sums over pixels run on the matrix cores in
  * exact f32, per-workgroup partials in `workspace` (pea_head_workspace_bytes), reduced in a fixed order.
- * Supported (C, D): (28|32|36|48|64, 16) and (32|64, 32); anything else returns PEA_E_UNSUPPORTED. */
+ * Supported (C, D): every head of the reference's models -- (28|32|36|48|64|80|128|256, 16) and (32|64|128|256, 32);
+ * anything else returns PEA_E_UNSUPPORTED. */
 size_t pea_head_workspace_bytes(int C, int D);
 int pea_head_fwd(int B, int C, int D, size_t S, const float *x, const float *W, const float *bias, float *e, void *stream);
 int pea_head_bwd(int B, int C, int D, size_t S, const float *x, const float *W, const float *de, float *dx, float *dW,

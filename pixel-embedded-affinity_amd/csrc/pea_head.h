@@ -24,6 +24,7 @@ typedef float hv4 __attribute__((ext_vector_type(4)));
 constexpr int kHeadBlock = 256;    // 4 waves
 constexpr int kHeadMaxWg = 1024;   // backward: workgroups (= partial sums of dW / db)
 constexpr int kHeadRow = 68;       // LDS row stride (floats) of a [channel][64 px] tile
+constexpr int kHeadCB = 64;        // input channels held in registers at a time (the wide low-resolution heads are chunked)
 
 template <int C, int D>
 __global__ __launch_bounds__(kHeadBlock) void k_head_fwd(const float* __restrict__ x, const float* __restrict__ W,
@@ -34,16 +35,35 @@ __global__ __launch_bounds__(kHeadBlock) void k_head_fwd(const float* __restrict
   if (p >= S) return;
   const float* xb = x + (size_t)b * C * S + p;
   float* eb = e + (size_t)b * D * S + p;
-  float xv[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) xv[c] = __builtin_nontemporal_load(xb + (size_t)c * S);
   const bool has_bias = bias != nullptr;
+  if (C <= kHeadCB) {
+    float xv[C];
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
-    float a = has_bias ? bias[d] : 0.f;
+    for (int c = 0; c < C; ++c) xv[c] = __builtin_nontemporal_load(xb + (size_t)c * S);
 #pragma unroll
-    for (int c = 0; c < C; ++c) a = fmaf(W[d * C + c], xv[c], a);
-    eb[(size_t)d * S] = a;  // the affinity kernels read it next: keep it in the caches
+    for (int d = 0; d < D; ++d) {
+      float a = has_bias ? bias[d] : 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) a = fmaf(W[d * C + c], xv[c], a);
+      eb[(size_t)d * S] = a;  // the affinity kernels read it next: keep it in the caches
+    }
+  } else {  // wide heads (C = 80 / 128 / 256 at the coarse scales): D accumulators, kHeadCB channels at a time
+    float a[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) a[d] = has_bias ? bias[d] : 0.f;
+    for (int c0 = 0; c0 < C; c0 += kHeadCB) {
+      constexpr int kN = kHeadCB;
+      float xv[kN];
+#pragma unroll
+      for (int c = 0; c < kN; ++c) xv[c] = (c0 + c < C) ? __builtin_nontemporal_load(xb + (size_t)(c0 + c) * S) : 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int c = 0; c < kN; ++c)
+          if (c0 + c < C) a[d] = fmaf(W[d * C + c0 + c], xv[c], a[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) eb[(size_t)d * S] = a[d];
   }
 }
 
@@ -58,17 +78,23 @@ __global__ __launch_bounds__(kHeadBlock) void k_head_dx(const float* __restrict_
   if (p >= S) return;
   const float* deb = de + (size_t)b * D * S + p;
   float* dxb = dx + (size_t)b * C * S + p;
-  float dv[D], dxv[C];
+  float dv[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) dv[d] = deb[(size_t)d * S];  // read again by k_head_dw: no non-temporal hint
+  for (int c0 = 0; c0 < C; c0 += kHeadCB) {  // one pass for C <= kHeadCB
+    constexpr int kN = C < kHeadCB ? C : kHeadCB;
+    float dxv[kN];
 #pragma unroll
-  for (int c = 0; c < C; ++c) dxv[c] = 0.f;
+    for (int c = 0; c < kN; ++c) dxv[c] = 0.f;
 #pragma unroll
-  for (int d = 0; d < D; ++d)
+    for (int d = 0; d < D; ++d)
 #pragma unroll
-    for (int c = 0; c < C; ++c) dxv[c] = fmaf(W[d * C + c], dv[d], dxv[c]);
+      for (int c = 0; c < kN; ++c)
+        if (c0 + c < C) dxv[c] = fmaf(W[d * C + c0 + c], dv[d], dxv[c]);
 #pragma unroll
-  for (int c = 0; c < C; ++c) __builtin_nontemporal_store(dxv[c], dxb + (size_t)c * S);
+    for (int c = 0; c < kN; ++c)
+      if (c0 + c < C) __builtin_nontemporal_store(dxv[c], dxb + (size_t)(c0 + c) * S);
+  }
 }
 
 // partials[wg][D*C + D] = this workgroup's share of dW[d,c] = sum_{b,p} de[b,d,p] x[b,c,p] and db[d] = sum_{b,p} de[b,d,p].
@@ -76,7 +102,7 @@ __global__ __launch_bounds__(kHeadBlock) void k_head_dx(const float* __restrict_
 // pixels): D + C rows per wave, four workgroups per CU where the registers allow (C <= 48, D = 16).  Prefetching the next
 // 256 pixels instead (twice the registers, half the waves) was slower: 114 vs 9x us.
 template <int C, int D>
-__global__ __launch_bounds__(kHeadBlock, (C <= 48 && D == 16) ? 4 : 2) void k_head_dw(const float* __restrict__ x, const float* __restrict__ de,
+__global__ __launch_bounds__(kHeadBlock, (C <= 48 && D == 16) ? 4 : (C <= 128 ? 2 : 1)) void k_head_dw(const float* __restrict__ x, const float* __restrict__ de,
                                                         float* __restrict__ partials, long long S, int chunks_per_b,
                                                         int nchunks) {
   static_assert(D % 16 == 0, "the dW tiles are 16 x 16");
@@ -107,11 +133,14 @@ __global__ __launch_bounds__(kHeadBlock, (C <= 48 && D == 16) ? 4 : 2) void k_he
     const size_t pc = live ? (size_t)p : 0;  // clamped address, value masked below: no branches around the loads
     const float* deb = de + (size_t)b * D * S + pc;
     const float* xb = x + (size_t)b * C * S + pc;
-    float dv[D], xv[C];
+    constexpr bool kAll = C <= kHeadCB;  // every row of the 256 pixels requested up front (else 16 channels at a time)
+    float dv[D], xv[kAll ? C : 16];
 #pragma unroll
     for (int d = 0; d < D; ++d) dv[d] = __builtin_nontemporal_load(deb + (size_t)d * S);
+    if (kAll) {
 #pragma unroll
-    for (int c = 0; c < C; ++c) xv[c] = __builtin_nontemporal_load(xb + (size_t)c * S);
+      for (int c = 0; c < C; ++c) xv[c] = __builtin_nontemporal_load(xb + (size_t)c * S);
+    }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const float v = live ? dv[d] : 0.f;
@@ -130,7 +159,12 @@ __global__ __launch_bounds__(kHeadBlock, (C <= 48 && D == 16) ? 4 : 2) void k_he
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = 16 * j + r;
-        tB[r * kHeadRow + lane] = (c < C && live) ? xv[c < C ? c : 0] : 0.f;
+        if (!kAll) xv[r] = c < C ? __builtin_nontemporal_load(xb + (size_t)c * S) : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = 16 * j + r;
+        tB[r * kHeadRow + lane] = (c < C && live) ? xv[kAll ? (c < C ? c : 0) : r] : 0.f;
       }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll

@@ -999,9 +999,10 @@ int pea_affinity_bwd_dual(const PeaDesc* desc, const void* e, const void* ema, c
 }
 
 // ---- the embedding head (1x1 convolution, pea_head.h) ---------------------------------------------------------------
-// (C, D) pairs of the reference's full- and half-resolution heads: ResUNet 32 / 64 -> 16 (CVPPP) or 32 (BBBC039V1),
-// superhuman 3D U-Net 28 / 36 / 48 / 64 -> 16
-#define PEA_HEAD_CASES(X) X(28, 16) X(32, 16) X(36, 16) X(48, 16) X(64, 16) X(32, 32) X(64, 32)
+// (C, D) pairs of the reference's heads: ResUNet 32 / 64 / 128 / 256 -> 16 (CVPPP) or 32 (BBBC039V1),
+// superhuman 3D U-Net 28 / 36 / 48 / 64 / 80 -> 16
+#define PEA_HEAD_CASES(X) \
+  X(28, 16) X(32, 16) X(36, 16) X(48, 16) X(64, 16) X(80, 16) X(128, 16) X(256, 16) X(32, 32) X(64, 32) X(128, 32) X(256, 32)
 
 static bool head_supported(int C, int D) {
 #define PEA_HEAD_Q(c, d) if (C == c && D == d) return true;

@@ -8,9 +8,9 @@ Mirrors, with the same parameter names (so the reference's checkpoints load unch
                                                scripts_ac3ac4/model/model_superhuman.py:437-441 (applied :486-490)
 
 Forward and backward are pea_head_fwd / pea_head_bwd (include/pea.h): hand-written streaming kernels, the weight
-gradient on the matrix cores in exact f32.  Channel pairs the library has no kernel for (the low-resolution
-deep-supervision heads with 128 / 256 input channels: 6 % of the head's pixels) go through torch's own GPU convolution;
-CPU tensors are refused like everywhere else in this package."""
+gradient on the matrix cores in exact f32.  The library has kernels for every head of the reference's models (2D ResUNet:
+32 / 64 / 128 / 256 input channels -> 16 or 32; 3D superhuman U-Net: 28 / 36 / 48 / 64 / 80 -> 16); any other channel
+pair goes through torch's own GPU convolution.  CPU tensors are refused like everywhere else in this package."""
 import ctypes
 
 import torch
@@ -22,7 +22,7 @@ from ..affinity_op import _ptr, _require_gpu, _stream
 
 
 def head_supported(C, D):
-    return (D == 16 and C in (28, 32, 36, 48, 64)) or (D == 32 and C in (32, 64))
+    return (D == 16 and C in (28, 32, 36, 48, 64, 80, 128, 256)) or (D == 32 and C in (32, 64, 128, 256))
 
 
 class EmbeddingHead(torch.autograd.Function):

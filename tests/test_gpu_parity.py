@@ -915,3 +915,30 @@ def test_head_full_size_vs_oracle_and_into_the_loss(pkg, dev, orc, synth):
     assert relmax(head.conv.bias.grad.cpu().numpy(), db_o) <= 5e-5
     with pytest.raises(RuntimeError):
         pkg.OutConv(C, D)(torch.zeros(1, C, 8, 8))  # CPU tensors are refused, no fallback
+
+
+@pytest.mark.parametrize("C,D,sp", [(256, 16, (34, 34)), (128, 32, (17, 40)), (80, 16, (3, 20, 20)), (36, 16, (5, 16, 24)),
+                                    (48, 16, (40, 40)), (256, 32, (9, 11))])
+def test_head_wide_and_3d_channel_pairs_vs_oracle(pkg, dev, orc, C, D, sp):
+    """the coarse-scale heads (channel-chunked kernels: C = 80 / 128 / 256) and the remaining 3D pairs against the
+    float64 restatement; 1e-5 of the largest magnitude (2e-5 for the sums over pixels)"""
+    rng = np.random.default_rng(C + D)
+    B = 2
+    x = rng.standard_normal((B, C) + sp).astype(np.float32)
+    w = (rng.standard_normal((D, C)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(D).astype(np.float32)
+    up = rng.standard_normal((B, D) + sp).astype(np.float32)
+    head = (pkg.head_conv3d_block(C, D) if len(sp) == 3 else pkg.OutConv(C, D)).to(dev)
+    conv = head[0] if len(sp) == 3 else head.conv
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(w.reshape(conv.weight.shape)))
+        conv.bias.copy_(torch.from_numpy(b))
+    assert pkg.model.head.head_supported(C, D)
+    xt = cu(x, dev).requires_grad_(True)
+    e = head(xt)
+    (e * cu(up, dev)).sum().backward()
+    assert relmax(e.detach().cpu().numpy(), orc.np_head_fwd(x, w, b)) <= 1e-5
+    dx, dW, db = orc.np_head_bwd(x, w, up)
+    assert relmax(xt.grad.cpu().numpy(), dx) <= 1e-5
+    assert relmax(conv.weight.grad.cpu().numpy().reshape(D, C), dW) <= 2e-5
+    assert relmax(conv.bias.grad.cpu().numpy(), db) <= 2e-5
