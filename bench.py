@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-section", action="store_true",
+                    help="skip the multi-scale loss-section timings (profiling runs: per-kernel averages then cover the full-size launches only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,7 +227,7 @@ def main():
                 out[which] = round(min(event_time_ms(lambda: run(which), 10) for _ in range(3)) * 1e3, 1)
             return out
 
-        section = section_us()
+        section = None if args.no_section else section_us()
         ab = algorithmic_bytes_per_px(D, K)
         dom = "bwd" if kt["bwd"] >= kt["fwd"] else "fwd"
         launch_bytes = ab[dom] * B * H * W
