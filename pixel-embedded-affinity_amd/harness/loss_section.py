@@ -7,6 +7,7 @@ happens inside (the reference's K `.item()` calls per loss are gone), so the sec
 (tests/test_gpu_parity.py::test_loss_section_graph_replay).
 """
 import ctypes
+import os
 
 import torch
 
@@ -27,6 +28,44 @@ def deep_weight_factor(deep_weight):
     return [deep_weight, 1.0, 1.0, 1.0, 1.0]
 
 
+_SIDE_STREAMS = {}
+
+
+class _side_stream(object):
+    """`with fork:` (fork = _side_stream(dev)) runs its launches on a second HIP stream of the device, forked from the
+    current stream on entry; `fork.join()`, called after the full-resolution kernels are enqueued on the main stream,
+    makes the main stream wait for them.  The deep-supervision scales are small grids (578 tiles at 272^2 down to 8 at 34^2):
+    one after the other on the full-resolution kernels' stream they cost their launch latencies, 150-200 us per
+    section; on their own stream they fill the CUs the big kernels leave idle.  Capturable in a HIP graph (fork / join
+    are stream waits).  PEA_SECTION_STREAMS=0 keeps everything on one stream."""
+
+    def __init__(self, dev):
+        self.on = os.environ.get("PEA_SECTION_STREAMS", "1") != "0"
+        self.dev = dev
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        self.main = torch.cuda.current_stream(self.dev)
+        side = _SIDE_STREAMS.get(self.dev.index)
+        if side is None:
+            side = _SIDE_STREAMS[self.dev.index] = torch.cuda.Stream(device=self.dev)
+        self.side = side
+        side.wait_stream(self.main)  # fork: everything the callers produced is ordered before the side work
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)  # the gradients / loss rows of the small scales are ready for what follows
+
+
 class _TensorSection(torch.autograd.Function):
     """cvppp_loss_section's six losses as ONE autograd node on the tensor path: per loss one forward launch (saving g)
     and one backward launch whose dloss is the loss' weight; the EMA cross gradient is added to the self gradient with one
@@ -43,7 +82,6 @@ class _TensorSection(torch.autograd.Function):
             wdev = _weights_on(dev, weights)
             rows = torch.empty((ncall, 1 + kmax), dtype=torch.float32, device=dev)
             grads, pred = [], None
-            st = op._stream()
 
             def forward_one(j, e_c, o_c, want_affs):
                 """forward launch of loss j -> (desc, g, affs)"""
@@ -63,35 +101,40 @@ class _TensorSection(torch.autograd.Function):
                 affs = torch.empty(kshape, dtype=torch.float32, device=dev) if want_affs else None
                 g = torch.empty(kshape, dtype=torch.float32, device=dev)
                 _lib.check(L.pea_affinity_fwd(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(t), op._ptr(w), op._ptr(m),
-                                              op._ptr(affs), op._ptr(g), op._ptr(rows[j]), op._ptr(work), wsb, st), "pea_affinity_fwd")
+                                              op._ptr(affs), op._ptr(g), op._ptr(rows[j]), op._ptr(work), wsb, op._stream()), "pea_affinity_fwd")
                 return d, g, affs
 
             def backward_one(j, d, e_c, o_c, g):
                 de = torch.empty_like(e_c)
                 _lib.check(L.pea_affinity_bwd(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(g), op._ptr(wdev[j:j + 1]),
-                                              op._ptr(de), None, st), "pea_affinity_bwd")
+                                              op._ptr(de), None, op._stream()), "pea_affinity_bwd")
                 return de
 
             # ---- full resolution: self + cross; their backwards run as one launch with two LDS phases when the library
             #      has it (pea_affinity_bwd_dual), else as two launches and an add
             jx = ncall - 1
+            small = []
+            fork = _side_stream(dev)
+            with fork:  # the deep-supervision scales, on their own stream beside the full-resolution pair
+                for j in range(1, jx):
+                    e_c = op._embedding_arg(embs[j], "embedding")
+                    d, g, _ = forward_one(j, e_c, None, False)
+                    small.append(backward_one(j, d, e_c, None, g))
             e0 = op._embedding_arg(embs[0], "embedding")
             ema_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e0.dtype)
             d0, g0, pred = forward_one(0, e0, None, True)
             dxx, gx, _ = forward_one(jx, e0, ema_c, False)
             de0 = torch.empty_like(e0)
             rc = L.pea_affinity_bwd_dual(ctypes.byref(d0), op._ptr(e0), op._ptr(ema_c), op._ptr(g0), op._ptr(gx), op._ptr(wdev[0:1]),
-                                         op._ptr(wdev[jx:jx + 1]), op._ptr(de0), st)
+                                         op._ptr(wdev[jx:jx + 1]), op._ptr(de0), op._stream())
             if rc == _lib.E_UNSUPPORTED:
                 de0 = backward_one(0, d0, e0, None, g0)
                 de0.add_(backward_one(jx, dxx, e0, ema_c, gx))
             else:
                 _lib.check(rc, "pea_affinity_bwd_dual")
             grads.append(de0)
-            for j in range(1, jx):
-                e_c = op._embedding_arg(embs[j], "embedding")
-                d, g, _ = forward_one(j, e_c, None, False)
-                grads.append(backward_one(j, d, e_c, None, g))
+            grads.extend(small)
+            fork.join()
             losses = rows[:, 0]
             total = (losses * wdev).sum()
         ctx.grads = grads
@@ -275,7 +318,6 @@ class _LabelsSection(torch.autograd.Function):
         with torch.cuda.device(dev):
             wdev = _weights_on(dev, weights)
             rows = torch.empty((ncall, 1 + kmax), dtype=torch.float32, device=dev)
-            st = op._stream()
 
             def prep(j):
                 e_c = op._embedding_arg(embs[j], "embedding")
@@ -284,7 +326,7 @@ class _LabelsSection(torch.autograd.Function):
                 cb = L.pea_targets_workspace_bytes(ctypes.byref(d))
                 counts = torch.empty(max(cb, 4) // 4, dtype=torch.int32, device=dev)
                 wtab = torch.empty(e_c.shape[0] * specs[j].K * 2, dtype=torch.float32, device=dev)
-                _lib.check(L.pea_label_weights(ctypes.byref(d), op._ptr(lab), lflags, op._ptr(wtab), op._ptr(counts), cb, st),
+                _lib.check(L.pea_label_weights(ctypes.byref(d), op._ptr(lab), lflags, op._ptr(wtab), op._ptr(counts), cb, op._stream()),
                            "pea_label_weights")
                 return e_c, lab, d, wtab, counts, cb
 
@@ -296,7 +338,7 @@ class _LabelsSection(torch.autograd.Function):
                 fl = lflags | (_lib.TGT_ACCUMULATE if accumulate else 0)
                 rc = L.pea_affinity_fwd_bwd_labels(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(lab), op._ptr(wtab), fl,
                                                    op._ptr(affs), op._ptr(rows[j]), op._ptr(wdev[j:j + 1]), op._ptr(de), op._ptr(work),
-                                                   wsb, st)
+                                                   wsb, op._stream())
                 if rc != _lib.E_UNSUPPORTED:
                     _lib.check(rc, "pea_affinity_fwd_bwd_labels")
                     return
@@ -307,16 +349,24 @@ class _LabelsSection(torch.autograd.Function):
                 m = torch.empty(kshape, dtype=torch.uint8, device=dev) if has_mask else None
                 w = torch.empty(kshape, dtype=torch.float32, device=dev)
                 _lib.check(L.pea_gen_targets(ctypes.byref(d), op._ptr(lab), gen_flags, op._ptr(t), op._ptr(m), op._ptr(w),
-                                             op._ptr(counts), cb, st), "pea_gen_targets")
+                                             op._ptr(counts), cb, op._stream()), "pea_gen_targets")
                 g = torch.empty(kshape, dtype=torch.float32, device=dev)
                 _lib.check(L.pea_affinity_fwd(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(t), op._ptr(w), op._ptr(m), op._ptr(affs),
-                                              op._ptr(g), op._ptr(rows[j]), op._ptr(work), wsb, st), "pea_affinity_fwd")
+                                              op._ptr(g), op._ptr(rows[j]), op._ptr(work), wsb, op._stream()), "pea_affinity_fwd")
                 _lib.check(L.pea_affinity_bwd(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(g), op._ptr(wdev[j:j + 1]), op._ptr(de),
-                                              None, st), "pea_affinity_bwd")
+                                              None, op._stream()), "pea_affinity_bwd")
 
             # ---- full resolution: self + cross.  One launch with two LDS phases when the library has it (same labels,
             #      same weights, same own pixel), else two launches, the second accumulating onto the first's gradient
             jx = ncall - 1
+            small = []
+            fork = _side_stream(dev)
+            with fork:  # the deep-supervision scales, on their own stream beside the full-resolution pair
+                for j in range(1, jx):
+                    e_c, lab, d, wtab, counts, cb = prep(j)
+                    de = torch.empty_like(e_c)
+                    one(j, e_c, None, lab, d, wtab, counts, cb, None, de, False)
+                    small.append(de)
             e0, lab0, d0, wtab0, counts0, cb0 = prep(0)
             ema_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e0.dtype)
             dx_ = op.make_desc(specs[jx], e0)
@@ -326,19 +376,14 @@ class _LabelsSection(torch.autograd.Function):
             work2 = torch.empty(max(wsb2, 4) // 4, dtype=torch.float32, device=dev)
             rc = L.pea_affinity_fwd_bwd_labels_dual(ctypes.byref(d0), ctypes.byref(dx_), op._ptr(e0), op._ptr(ema_c), op._ptr(lab0),
                                                     op._ptr(wtab0), lflags, op._ptr(pred), op._ptr(rows[0]), op._ptr(rows[jx]),
-                                                    op._ptr(wdev[0:1]), op._ptr(wdev[jx:jx + 1]), op._ptr(de0), op._ptr(work2), wsb2, st)
+                                                    op._ptr(wdev[0:1]), op._ptr(wdev[jx:jx + 1]), op._ptr(de0), op._ptr(work2), wsb2, op._stream())
             if rc == _lib.E_UNSUPPORTED:
                 one(0, e0, None, lab0, d0, wtab0, counts0, cb0, pred, de0, False)
                 one(jx, e0, ema_c, lab0, dx_, wtab0, counts0, cb0, None, de0, True)
             else:
                 _lib.check(rc, "pea_affinity_fwd_bwd_labels_dual")
-            grads = [de0]
-            # ---- the deep-supervision scales
-            for j in range(1, jx):
-                e_c, lab, d, wtab, counts, cb = prep(j)
-                de = torch.empty_like(e_c)
-                one(j, e_c, None, lab, d, wtab, counts, cb, None, de, False)
-                grads.append(de)
+            grads = [de0] + small
+            fork.join()
             losses = rows[:, 0]
             total = (losses * wdev).sum()
         ctx.grads = grads
