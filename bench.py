@@ -212,12 +212,15 @@ def main():
             def run(which):
                 x = [e.detach().requires_grad_(True) for e in embs]
                 if which == "labels":
-                    loss, pred, _ = pkg.cvppp_loss_section_from_labels(x[0], x[1:], ema, labs[0], labs[1:], crit, offsets, nb_half)
+                    loss, pred, _ = pkg.cvppp_loss_section_from_labels(x[0], x[1:], ema, labs[0], labs[1:], crit, offsets, nb_half,
+                                                                       relu_pred=True)
+                elif which == "one_node":
+                    loss, pred, _ = pkg.cvppp_loss_section(x[0], x[1:], ema, tt, ww, mm, downs, crit, offsets, nb_half, relu_pred=True)
                 else:
-                    fn = pkg.cvppp_loss_section_composed if which == "composed" else pkg.cvppp_loss_section
-                    loss, pred, _ = fn(x[0], x[1:], ema, tt, ww, mm, downs, crit, offsets, nb_half)
+                    loss, pred, _ = pkg.cvppp_loss_section_composed(x[0], x[1:], ema, tt, ww, mm, downs, crit, offsets, nb_half)
                 loss.backward()
-                pkg.finish_pred_2d_(pred)
+                if which == "composed":
+                    pkg.finish_pred_2d_(pred)  # F.relu(pred), main.py:312 (the other two return it already clamped)
 
             out = {}
             for which in ("composed", "one_node", "labels"):

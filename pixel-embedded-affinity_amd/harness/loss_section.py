@@ -181,7 +181,7 @@ def _section_parts(losses, weights, self_emb, cross_emb):
 
 
 def cvppp_loss_section(embedding, emds, ema_embedding, target, weightmap, affs_mask, downs, criterion, offsets, nb_half,
-                       affs0_weight=1, dis_mode='ours', deep_weight=1, self_emb=1.0, cross_emb=1.0):
+                       affs0_weight=1, dis_mode='ours', deep_weight=1, self_emb=1.0, cross_emb=1.0, relu_pred=False):
     """scripts_cvppp/main.py:284-310 (and scripts_bbbc/main.py:279-305): five self losses over the deep-supervision
     scales + the EMA cross loss at full resolution.
 
@@ -192,9 +192,14 @@ def cvppp_loss_section(embedding, emds, ema_embedding, target, weightmap, affs_m
     reference does at :312) and parts the individual weighted losses (device scalars).
 
     With the fused criterion (WeightedMSE) and a detached EMA operand the six losses run as one autograd node
-    (_TensorSection); otherwise they are composed from embedding_loss / ema_embedding_loss call by call."""
+    (_TensorSection); otherwise they are composed from embedding_loss / ema_embedding_loss call by call.
+
+    relu_pred=True: pred comes back already clamped at 0 -- the kernel that writes the map applies the reference's next
+    statement, `pred = F.relu(pred)` (:312), on the way out, so that line (finish_pred_2d_) and its pass over
+    [B,K,H,W] are dropped; nothing else reads pred in the training loop."""
     if getattr(criterion, 'pea_fused', False) and not ema_embedding.requires_grad:
         specs, weights = _section_specs(offsets, nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb)
+        specs[0].relu = specs[-1].relu = bool(relu_pred)  # (the cross loss writes no map; its descriptor must match)
         tensors = [(target, weightmap, affs_mask)]
         for j, down in enumerate(downs):
             k = nb_half * (4 - j)
@@ -202,8 +207,9 @@ def cvppp_loss_section(embedding, emds, ema_embedding, target, weightmap, affs_m
             tensors.append((down[:, 0:k], down[:, k:2 * k], m if m.dtype in (torch.uint8, torch.bool) else m.to(torch.uint8)))
         loss, pred, losses = _TensorSection.apply(specs, weights, ema_embedding, tensors, embedding, *emds)
         return loss, pred, _section_parts(losses, weights, self_emb, cross_emb)
-    return cvppp_loss_section_composed(embedding, emds, ema_embedding, target, weightmap, affs_mask, downs, criterion, offsets,
-                                       nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb)
+    loss, pred, parts = cvppp_loss_section_composed(embedding, emds, ema_embedding, target, weightmap, affs_mask, downs, criterion,
+                                                    offsets, nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb)
+    return loss, (finish_pred_2d_(pred) if relu_pred else pred), parts
 
 
 def cvppp_loss_section_composed(embedding, emds, ema_embedding, target, weightmap, affs_mask, downs, criterion, offsets, nb_half,
@@ -407,17 +413,18 @@ def _weights_on(dev, weights):
 
 
 def cvppp_loss_section_from_labels(embedding, emds, ema_embedding, labels, label_downs, criterion, offsets, nb_half,
-                                   affs0_weight=1, dis_mode='ours', deep_weight=1, self_emb=1.0, cross_emb=1.0):
+                                   affs0_weight=1, dis_mode='ours', deep_weight=1, self_emb=1.0, cross_emb=1.0, relu_pred=False):
     """cvppp_loss_section without any target / weight / mask tensor: `labels` [B,H,W] and `label_downs` = the four
     nearest-downsampled label images (scripts_cvppp/data/data_provider.py:199-208) replace target, weightmap, affs_mask
     and down1..down4 (gen_affs_ours(padding=True) + weight_binary_ratio are evaluated inside the kernels).  The six
     losses run as one autograd node (_LabelsSection).  Returns (loss, pred, parts) like cvppp_loss_section; the entries
-    of parts are the weighted per-loss values (device scalars, no gradient of their own)."""
+    of parts are the weighted per-loss values (device scalars, no gradient of their own).  relu_pred: as there."""
     if not getattr(criterion, 'pea_fused', False):
         raise NotImplementedError("the labels-in section fuses WeightedMSE; use cvppp_loss_section for another criterion")
     if ema_embedding.requires_grad:
         raise NotImplementedError("the EMA operand must be detached (convert_consistency_flip)")
     specs, weights = _section_specs(offsets, nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb)
     specs[0].label_flags = (_lib.TGT_PADDING | _lib.TGT_MASK_INSIDE, _lib.TGT_PADDING, True)  # gen_affs_ours(padding=True) + its mask
+    specs[0].relu = specs[-1].relu = bool(relu_pred)
     loss, pred, losses = _LabelsSection.apply(specs, weights, ema_embedding, [labels] + list(label_downs), embedding, *emds)
     return loss, pred, _section_parts(losses, weights, self_emb, cross_emb)

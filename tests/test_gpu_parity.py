@@ -942,3 +942,29 @@ def test_head_wide_and_3d_channel_pairs_vs_oracle(pkg, dev, orc, C, D, sp):
     assert relmax(xt.grad.cpu().numpy(), dx) <= 1e-5
     assert relmax(conv.weight.grad.cpu().numpy().reshape(D, C), dW) <= 2e-5
     assert relmax(conv.bias.grad.cpu().numpy(), db) <= 2e-5
+
+
+def test_loss_section_relu_pred_option(pkg, dev, synth):
+    """relu_pred=True: the section's affinity map comes back already clamped (the reference's `pred = F.relu(pred)`,
+    scripts_cvppp/main.py:312, applied by the kernel that writes it); loss and gradients are untouched"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    nb_half, B, D, H, W = 2, 2, 16, 96, 96
+    e, ema, t, w, m, emds, downs = _section_inputs(synth, offsets, nb_half, B, D, H, W, 77)
+    crit = pkg.WeightedMSE()
+    labs = synth.synth_labels(B, (1, H, W), 78)[:, 0]
+    lab_t = [torch.from_numpy(np.ascontiguousarray(labs[:, ::2 ** j, ::2 ** j])).to(dev) for j in range(5)]
+    for path in ("tensor", "labels"):
+        res = []
+        for flag in (False, True):
+            et = cu(e, dev).requires_grad_(True)
+            emd_t = [cu(x, dev).requires_grad_(True) for x in emds]
+            if path == "tensor":
+                loss, pred, _ = pkg.cvppp_loss_section(et, emd_t, cu(ema, dev), cu(t, dev), cu(w, dev), cu(m, dev),
+                                                       [cu(x, dev) for x in downs], crit, offsets, nb_half, relu_pred=flag)
+            else:
+                loss, pred, _ = pkg.cvppp_loss_section_from_labels(et, emd_t, cu(ema, dev), lab_t[0], lab_t[1:], crit, offsets, nb_half,
+                                                                   relu_pred=flag)
+            loss.backward()
+            res.append((loss.item(), pred.clone(), et.grad.clone()))
+        assert res[0][0] == res[1][0] and torch.equal(res[0][2], res[1][2])
+        assert float(res[0][1].min()) < 0.0 and torch.equal(torch.relu(res[0][1]), res[1][1])
