@@ -49,6 +49,21 @@ def event_time_ms(fn, iters):
     return a.elapsed_time(b) / iters
 
 
+def isolated_time_ms(fn, iters):
+    """average duration of fn() when every call is drained before the next is launched: what a profiler that separates
+    dispatches reports (no overlap of one launch's tail with the next one's ramp-up)"""
+    s = torch.cuda.current_stream()
+    tot = 0.0
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s)
+        fn()
+        b.record(s)
+        b.synchronize()
+        tot += a.elapsed_time(b)
+    return tot / iters
+
+
 def cpu_baseline(offsets, e, t, w, m, budget_s=20.0):
     """The reference's arithmetic (F.normalize -> K x roll/mul/sum -> WeightedMSE -> autograd backward) as the
     oracle's torch-CPU restatement, on all host cores, same workload; at most ~budget_s of CPU work."""
@@ -230,6 +245,7 @@ def main():
                 out[which] = round(min(event_time_ms(lambda: run(which), 10) for _ in range(3)) * 1e3, 1)
             return out
 
+        kt_iso = {name: isolated_time_ms(fn, 20) for name, fn in (("fwd", fwd), ("bwd", bwd))}
         section = None if args.no_section else section_us()
         ab = algorithmic_bytes_per_px(D, K)
         dom = "bwd" if kt["bwd"] >= kt["fwd"] else "fwd"
@@ -257,6 +273,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "pea_affinity_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_px": ab[dom], "px_per_launch": B * H * W,
+                         "ms": round(kt[dom], 5), "ms_drained": round(kt_iso[dom], 5),
                          "fwd_plus_bwd_GBs": round(step_gbs, 1), "fwd_plus_bwd_frac": round(step_gbs / HBM_PEAK_GBS, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
