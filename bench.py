@@ -265,6 +265,10 @@ def main():
                                    "K=%d offsets (shifts 1,3,5,9,27 x neighbor 4), circular border, u8 mask" % (B, D, H, W, K),
                        "images_per_gpu": B, "embedding_dim": D, "height": H, "width": W, "offsets": K,
                        "sharding": "batch across ranks, no data-path collective"},
+            # pixels are counted on the padded tensor the op processes (544^2 per CVPPP image); the same rate in
+            # images and in pixels of the un-padded 530x500 image
+            "images_per_s_op_only": round(value * 1e6 / (H * W), 1),
+            "value_530x500_equiv": round(value * (530 * 500) / (H * W), 2),
             "kernel_ms": {k: round(v, 5) for k, v in kt.items()},
             "kernel_sum_mpx_s": round(B * H * W / ((kt["fwd"] + kt["bwd"]) * 1e-3) / 1e6, 1),
             "infer_mpx_s": round(B * H * W / (kt["infer"] * 1e-3) / 1e6, 1),
