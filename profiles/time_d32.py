@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""time fwd / bwd / inf at a D = 32 shape (BBBC-like: B=8 x 32 x 544 x 544, shifts 1,3,5,9,11 x neighbor 4); honours PEA_* env"""
+"""time fwd / bwd / inf at a D = 32 shape (BBBC-like: B=8 x 32 x 544 x 544, shifts 1,3,5,9,11 x neighbor 4); D=64 with the env
+variable D; honours PEA_* env"""
 import ctypes, importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,7 +27,8 @@ LAB = torch.from_numpy(synth.synth_labels(B, (1, H, W), 555)[:, 0].copy()).to(de
 WTAB = torch.empty(B * K * 2, device=dev)
 CNTB = L.pea_targets_workspace_bytes(ctypes.byref(desc)); CNT = torch.empty(CNTB // 4, dtype=torch.int32, device=dev)
 assert L.pea_label_weights(ctypes.byref(desc), P(LAB), 5, P(WTAB), P(CNT), CNTB, st) == 0
-fns["labels_step"] = lambda: L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(E), None, P(LAB), P(WTAB), 5, P(affs), P(lossv), None, P(dE), P(work), wsb, st)
+if D in (16, 32):
+    fns["labels_step"] = lambda: L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(E), None, P(LAB), P(WTAB), 5, P(affs), P(lossv), None, P(dE), P(work), wsb, st)
 fns["fwd"]()
 for name, fn in fns.items():
     for _ in range(5): fn()

@@ -968,3 +968,43 @@ def test_loss_section_relu_pred_option(pkg, dev, synth):
             res.append((loss.item(), pred.clone(), et.grad.clone()))
         assert res[0][0] == res[1][0] and torch.equal(res[0][2], res[1][2])
         assert float(res[0][1].min()) < 0.0 and torch.equal(torch.relu(res[0][1]), res[1][1])
+
+
+@pytest.mark.parametrize("case", ["self_f32", "ema_f32", "self_f16", "zero_px"])
+def test_chunked_d64_forward_vs_oracle(pkg, dev, orc, synth, monkeypatch, case):
+    """D = 64 (BASELINE config 5) through the channel-chunked tiled forward (two chunks of 32 channels staged raw, norms
+    applied to the raw dot products): training forward + inference against the C oracle, with the CVPPP stencil (two far
+    offsets), and against the direct kernels it replaces (PEA_FORCE_DIRECT=1)"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    B, D, H, W = 2, 64, 70, 100
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 63)
+    if case == "zero_px":
+        e[:, :, 10:14, 20:60] = 0.0  # zero-norm pixels: ehat = 0, no NaN
+    f16 = case == "self_f16"
+    if f16:
+        e = e.astype(np.float16).astype(np.float32)  # the oracle sees the values the kernel loads
+    other = synth.synth_embedding((B, D, H, W), 64) if case == "ema_f32" else None
+    crit = pkg.WeightedMSE()
+
+    def run():
+        et = cu(e, dev)
+        et = (et.half() if f16 else et).requires_grad_(True)
+        if other is not None:
+            loss, affs = pkg.ema_embedding_loss(et, cu(other, dev), cu(t, dev), cu(w, dev), cu(m, dev), crit, offsets)
+        else:
+            loss, affs, _ = pkg.embedding_loss(et, cu(t, dev), cu(w, dev), cu(m, dev), crit, offsets)
+        loss.backward()
+        inf = pkg.embedding2affs(et.detach(), offsets) if other is None else affs
+        return loss.item(), affs.cpu().numpy(), inf.cpu().numpy(), et.grad.float().cpu().numpy()
+
+    got = run()
+    d = orc.desc_2d(e, offsets)
+    o_affs, o_loss = orc.c_fwd(d, e, other, t, w, m)
+    o_grad, _ = orc.c_bwd(d, e, other, t, w, m)
+    assert np.isfinite(got[1]).all()
+    assert np.abs(got[1] - o_affs).max() < AFFS_ATOL and np.abs(got[2] - o_affs).max() < AFFS_ATOL
+    assert abs(got[0] - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+    assert relmax(got[3], o_grad) < (2e-3 if f16 else GRAD_RTOL)  # f16: the gradient itself is stored in half precision
+    monkeypatch.setenv("PEA_FORCE_DIRECT", "1")
+    ref = run()
+    assert np.abs(got[1] - ref[1]).max() < 2e-6 and abs(got[0] - ref[0]) <= 2e-6 * abs(ref[0])
