@@ -1,5 +1,5 @@
-// pea_chunked.h -- tiled forward for embeddings too wide for one LDS region (D = 64): the channels go through LDS in
-// chunks of DC = 32.  Included by pea_hip.hip only.
+// pea_chunked.h -- tiled forward with the channels going through LDS in chunks: D = 64 as two chunks of 32 (too wide for
+// one region), D = 32 as two chunks of 16 (a 64-byte region pixel: two workgroups per CU).  Included by pea_hip.hip only.
 //
 // <ehat(p), ehat(q)> = <e(p), e(q)> / (|e(p)| |e(q)|) separates over channels once the norms are taken out: every chunk is
 // staged RAW (the D = 32 region geometry: 16x32 tile, 128 bytes of LDS per region pixel), each lane adds the chunk's
@@ -57,7 +57,7 @@ __device__ __forceinline__ void stage_region_raw(const KParams& P, const TParams
 }
 
 template <typename T, int D_T, int DC, int TH, int TW, int PLQ, bool CROP, bool TRAIN, bool SELF>
-__global__ __launch_bounds__(TH* TW, 2) void k_fwd_tiled_chunked(const KParams P, const TParams Q, const T* __restrict__ e,
+__global__ __launch_bounds__(TH* TW, (DC > 16 ? 2 : 4)) void k_fwd_tiled_chunked(const KParams P, const TParams Q, const T* __restrict__ e,
                                                                  const T* __restrict__ eo, const float* __restrict__ target,
                                                                  const float* __restrict__ weight,
                                                                  const uint8_t* __restrict__ mask, float* __restrict__ affs,

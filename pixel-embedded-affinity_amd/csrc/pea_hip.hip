@@ -307,34 +307,36 @@ bool try_fwd_tiled(const KParams& P, const T* e, const T* eo, const float* t, co
   return true;
 }
 
-// D = 64: channels through LDS in two chunks of 32 (k_fwd_tiled_chunked, the D = 32 region geometry)
-template <typename T, bool TRAIN, bool SELF>
+// D = 64: channels through LDS in two chunks of 32 (k_fwd_tiled_chunked, the D = 32 region geometry);
+// D = 32: two chunks of 16 in the D = 16 geometry, i.e. two workgroups per CU instead of one (inference 176 -> 139 us,
+// training forward 255 -> 237 us at B=8 x 32 x 544^2; PEA_FWD_CHUNKED32=0 restores the one-region kernels)
+template <typename T, int D_T, int DC, bool TRAIN, bool SELF>
 void launch_fwd_chunked(const KParams& P, const TParams& Q, size_t lds, const T* e, const T* eo, const float* t, const float* w,
                         const uint8_t* m, float* affs, float* gout, float* partials, hipStream_t s) {
-  constexpr TileCfg c = kCfg32;
+  constexpr TileCfg c = kCfg32;  // 16 x 32 tile, 1041 region pixels: 128 B (DC = 32) or 64 B (DC = 16) of LDS each
   const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(c.TH * c.TW);
   if (P.border == PEA_BORDER_CIRCULAR) {
-    constexpr auto kern = k_fwd_tiled_chunked<T, 64, 32, c.TH, c.TW, c.PLQ, false, TRAIN, SELF>;
+    constexpr auto kern = k_fwd_tiled_chunked<T, D_T, DC, c.TH, c.TW, c.PLQ, false, TRAIN, SELF>;
     allow_lds<kern>(lds);
     hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials);
   } else {
-    constexpr auto kern = k_fwd_tiled_chunked<T, 64, 32, c.TH, c.TW, c.PLQ, true, TRAIN, SELF>;
+    constexpr auto kern = k_fwd_tiled_chunked<T, D_T, DC, c.TH, c.TW, c.PLQ, true, TRAIN, SELF>;
     allow_lds<kern>(lds);
     hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials);
   }
 }
 
-template <typename T, bool TRAIN>
+template <typename T, int D_T, int DC, bool TRAIN>
 bool try_fwd_chunked(const KParams& P, const T* e, const T* eo, const float* t, const float* w, const uint8_t* m, float* affs,
                      float* gout, float* partials, hipStream_t s, int* nparts) {
-  if (P.D != 64 || env_int("PEA_FWD_CHUNKED", 1) == 0) return false;
+  if (P.D != D_T || env_int("PEA_FWD_CHUNKED", 1) == 0) return false;
   constexpr TileCfg c = kCfg32;
   TParams Q;
   if (!plan_tiles(P, c, false, &Q) || Q.n_near > kChN || Q.n_far > kChF) return false;
-  const size_t lds = Lds<32, c.PLQ>::kBytes + (size_t)c.PLQ * 4 + (size_t)(c.TH * c.TW / 64) * P.K * 4;
+  const size_t lds = Lds<DC, c.PLQ>::kBytes + (size_t)c.PLQ * 4 + (size_t)(c.TH * c.TW / 64) * P.K * 4;
   if (lds > (size_t)kLdsMax) return false;
-  if (eo == e) launch_fwd_chunked<T, TRAIN, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
-  else launch_fwd_chunked<T, TRAIN, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
+  if (eo == e) launch_fwd_chunked<T, D_T, DC, TRAIN, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
+  else launch_fwd_chunked<T, D_T, DC, TRAIN, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
   *nparts = Q.ntiles;
   return true;
 }
@@ -348,9 +350,11 @@ int launch_fwd(const KParams& P, const void* e, const void* eo, const float* t, 
     bool done = false;
     if (P.D == 16 && TRAIN) done = try_fwd_v<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
     if (!done && P.D == 16) done = try_fwd_tiled<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
-    if (P.D == 32 && TRAIN) done = try_fwd_v<T, 32, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
+    if (P.D == 32 && env_int("PEA_FWD_CHUNKED32", 1) != 0)  // 64 B of LDS per region pixel: two workgroups per CU
+      done = try_fwd_chunked<T, 32, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
+    if (!done && P.D == 32 && TRAIN) done = try_fwd_v<T, 32, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
     if (!done && P.D == 32) done = try_fwd_tiled<T, 32, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
-    if (P.D == 64) done = try_fwd_chunked<T, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
+    if (P.D == 64) done = try_fwd_chunked<T, 64, 32, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
     if (done) return hip_rc();
   }
   const size_t lds = TRAIN ? (size_t)P.K * kBlock * sizeof(float) : 0;
