@@ -23,11 +23,9 @@
 
 #include "pea_direct.h"
 #include "pea_tiled.h"
-#include "pea_phased.h"
 #include "pea_fused.h"
 #include "pea_targets.h"
 #include "pea_fused_labels.h"
-#include "pea_plan.h"
 #include "pea_head.h"
 #include "pea_chunked.h"
 
@@ -403,51 +401,12 @@ bool try_bwd_tiled(const KParams& P, const T* x, const T* nb, const float* g, co
   return true;
 }
 
-long long* g_stamps = nullptr;  // diagnostic: device buffer [grid][64] for s_memtime stamps (pea_debug_stamps)
-
-// phase-machine backward (pea_phased.h): experimental, PEA_BWD_PHASED=1
-template <typename T, int D_T>
-bool try_bwd_phased(const KParams& P, int roles, const T* x, const T* nb, const float* g, const float* dl, T* dx,
-                    hipStream_t s) {
-  if (env_int("PEA_BWD_PHASED", 0) == 0) return false;  // opt-in: see the header of pea_phased.h
-  const size_t qa = 4 * sizeof(T);  // a pixel quad is one load / store
-  if (misaligned(x, qa) || misaligned(nb, qa) || misaligned(dx, qa)) return false;
-  // planning enumerates block layouts (tens of microseconds): memoise the last plan of this thread
-  struct Key { KParams P; int roles, self, es; };
-  thread_local Key ck;
-  thread_local MParams cm;
-  thread_local int cstate = 0;  // 0 = empty, 1 = plan, 2 = no plan
-  Key k;
-  memset(&k, 0, sizeof(k));
-  k.P = P; k.roles = roles; k.self = nb == x; k.es = (int)sizeof(T);
-  if (cstate == 0 || memcmp(&k, &ck, sizeof(k)) != 0) {
-    cstate = plan_phased(P, roles, nb == x, sizeof(T), device_cus(), &cm) ? 1 : 2;
-    ck = k;
-  }
-  if (cstate != 1) return false;
-  const MParams& M = cm;
-  const size_t lds = Lds<D_T, kPhPlq>::kBytes + kPhNT * sizeof(float);
-  if (lds > (size_t)kLdsMax) return false;
-  const dim3 grid((unsigned)(M.wg_per_xcd * kXcd)), blk(kPhNT);
-  if (P.border == PEA_BORDER_CIRCULAR) {
-    constexpr auto kern = k_bwd_phased<T, D_T, false>;
-    allow_lds<kern>(lds);
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, M, x, nb, g, dl, dx, g_stamps);
-  } else {
-    constexpr auto kern = k_bwd_phased<T, D_T, true>;
-    allow_lds<kern>(lds);
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, M, x, nb, g, dl, dx, g_stamps);
-  }
-  return true;
-}
-
 template <typename T, int D_T>
 int launch_bwd_roles(const KParams& P, int roles, const T* x, const T* nbA, const T* nbB, const float* g, const float* dl,
                      T* dx, hipStream_t s) {
   if ((D_T == 16 || D_T == 32) && env_int("PEA_FORCE_DIRECT", 0) == 0) {
     constexpr int DT = D_T == 32 ? 32 : 16;
-    bool done = D_T == 16 && try_bwd_phased<T, 16>(P, roles, x, roles == 2 ? nbB : nbA, g, dl, dx, s);
-    if (done) return hip_rc();
+    bool done = false;
     if (roles == 3) done = try_bwd_tiled<T, DT, true, true>(P, x, nbA, g, dl, dx, s);
     else if (roles == 1) done = try_bwd_tiled<T, DT, true, false>(P, x, nbA, g, dl, dx, s);
     else done = try_bwd_tiled<T, DT, false, true>(P, x, nbB, g, dl, dx, s);
@@ -686,9 +645,6 @@ __global__ __launch_bounds__(256) void k_scale_multi(const ScaleMulti M, const f
 extern "C" {
 
 int pea_version(void) { return PEA_ABI_VERSION; }
-
-/* diagnostic only (not in include/pea.h): device buffer [grid][64] int64 that receives in-kernel stamps; NULL = off */
-void pea_debug_stamps(void* buf) { g_stamps = (long long*)buf; }
 
 const char* pea_strerror(int code) {
   switch (code) {

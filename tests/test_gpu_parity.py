@@ -387,38 +387,6 @@ def test_tiled_and_direct_kernels_agree(pkg, dev, synth, monkeypatch):
     assert relmax(g1, g0) < 1e-5
 
 
-@pytest.mark.parametrize("case", ["2d_nb4", "2d_nb8", "2d_ema", "3d_norm5"])
-def test_phased_backward_agrees_with_tiled(pkg, dev, orc, synth, monkeypatch, case):
-    """the experimental phase-machine backward (PEA_BWD_PHASED=1, pea_phased.h) against the default backward:
-    near rects, aligned and unaligned shifted tiles, wrap-straddling quads, EMA (own block from x), 3D planes"""
-    crit = pkg.WeightedMSE()
-
-    def run():
-        if case == "3d_norm5":
-            B, D, Z, Y, X = 1, 16, 6, 72, 76
-            e, t, w = synth.synth_inputs_3d(B, D, Z, Y, X, orc.norm_offsets([1, 1, 1, 2, 3, 3, 3, 9, 9, 4, 27, 27]), 31)
-            et = cu(e, dev).requires_grad_(True)
-            loss, _ = pkg.embedding_loss_norm5(et, cu(t, dev), cu(w, dev), crit, affs0_weight=2)
-        else:
-            offsets = pkg.multi_offset([1, 3, 5, 9, 27], 8 if case == "2d_nb8" else 4)
-            B, D, H, W = 2, 16, 80, 136
-            e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 37)
-            et = cu(e, dev).requires_grad_(True)
-            if case == "2d_ema":
-                ema = cu(np.roll(e, 3, axis=1).copy(), dev)
-                loss, _ = pkg.ema_embedding_loss(et, ema, cu(t, dev), cu(w, dev), cu(m, dev), crit, offsets)
-            else:
-                loss, _, _ = pkg.embedding_loss(et, cu(t, dev), cu(w, dev), cu(m, dev), crit, offsets)
-        (loss * 0.5).backward()
-        return et.grad.cpu().numpy()
-
-    monkeypatch.delenv("PEA_BWD_PHASED", raising=False)
-    g0 = run()
-    monkeypatch.setenv("PEA_BWD_PHASED", "1")
-    g1 = run()
-    assert relmax(g1, g0) < 1e-5
-
-
 @pytest.mark.parametrize("case", ["2d_self", "2d_ema", "3d_norm5", "2d_f16"])
 def test_fused_launch_agrees_with_two_launches(pkg, dev, orc, synth, monkeypatch, case):
     """pea_affinity_fwd_bwd (one launch, PEA_FUSED=1) against the default pea_affinity_fwd +
