@@ -319,6 +319,7 @@ class _LabelsSection(torch.autograd.Function):
         dev = embs[0].device
         L = _lib.lib()
         lflags, gen_flags, has_mask = specs[0].label_flags
+        tables = getattr(specs[0], "weight_tables", None)  # precomputed by *_label_weight_tables (off the critical path)
         ncall = len(specs)
         kmax = max(sp.K for sp in specs)
         with torch.cuda.device(dev):
@@ -331,6 +332,11 @@ class _LabelsSection(torch.autograd.Function):
                 d = op.make_desc(specs[j], e_c)
                 cb = L.pea_targets_workspace_bytes(ctypes.byref(d))
                 counts = torch.empty(max(cb, 4) // 4, dtype=torch.int32, device=dev)
+                if tables is not None:
+                    wtab = tables[j]
+                    if wtab.numel() != e_c.shape[0] * specs[j].K * 2 or wtab.dtype != torch.float32 or wtab.device != dev:
+                        raise ValueError("weight table %d does not fit this batch / stencil" % j)
+                    return e_c, lab, d, wtab, counts, cb
                 wtab = torch.empty(e_c.shape[0] * specs[j].K * 2, dtype=torch.float32, device=dev)
                 _lib.check(L.pea_label_weights(ctypes.byref(d), op._ptr(lab), lflags, op._ptr(wtab), op._ptr(counts), cb, op._stream()),
                            "pea_label_weights")
@@ -412,13 +418,40 @@ def _weights_on(dev, weights):
     return t
 
 
+def cvppp_label_weight_tables(labels, label_downs, offsets, nb_half, dis_mode='ours'):
+    """The class-balance weight tables (weight_binary_ratio per image and channel, scripts_cvppp/data/data_segmentation.py:
+    205-228) of the five scales, straight from the label images.  They depend on the labels only: call this as soon as the
+    label batch is on the GPU -- e.g. before the backbone's forward -- and hand the result to
+    cvppp_loss_section_from_labels(weight_tables=...), which then starts with the loss kernels instead of the count
+    reductions (33 us at full resolution on the critical path otherwise)."""
+    specs, _ = _section_specs(offsets, nb_half, 1, dis_mode, 1, 1.0, 1.0)
+    flags = _lib.TGT_PADDING | _lib.TGT_MASK_INSIDE
+    L = _lib.lib()
+    tables = []
+    for j, lab in enumerate([labels] + list(label_downs)):
+        op._require_gpu(lab, "labels")
+        lab = lab.to(torch.int32).contiguous()
+        like = torch.empty((lab.shape[0], 16) + tuple(lab.shape[1:]), device="meta")  # geometry only
+        d = op.make_desc(specs[j], like)
+        with torch.cuda.device(lab.device):
+            cb = L.pea_targets_workspace_bytes(ctypes.byref(d))
+            counts = torch.empty(max(cb, 4) // 4, dtype=torch.int32, device=lab.device)
+            wtab = torch.empty(lab.shape[0] * specs[j].K * 2, dtype=torch.float32, device=lab.device)
+            _lib.check(L.pea_label_weights(ctypes.byref(d), op._ptr(lab), flags, op._ptr(wtab), op._ptr(counts), cb, op._stream()),
+                       "pea_label_weights")
+        tables.append(wtab)
+    return tables
+
+
 def cvppp_loss_section_from_labels(embedding, emds, ema_embedding, labels, label_downs, criterion, offsets, nb_half,
-                                   affs0_weight=1, dis_mode='ours', deep_weight=1, self_emb=1.0, cross_emb=1.0, relu_pred=False):
+                                   affs0_weight=1, dis_mode='ours', deep_weight=1, self_emb=1.0, cross_emb=1.0, relu_pred=False,
+                                   weight_tables=None):
     """cvppp_loss_section without any target / weight / mask tensor: `labels` [B,H,W] and `label_downs` = the four
     nearest-downsampled label images (scripts_cvppp/data/data_provider.py:199-208) replace target, weightmap, affs_mask
     and down1..down4 (gen_affs_ours(padding=True) + weight_binary_ratio are evaluated inside the kernels).  The six
     losses run as one autograd node (_LabelsSection).  Returns (loss, pred, parts) like cvppp_loss_section; the entries
-    of parts are the weighted per-loss values (device scalars, no gradient of their own).  relu_pred: as there."""
+    of parts are the weighted per-loss values (device scalars, no gradient of their own).  relu_pred: as there.
+    weight_tables: the result of cvppp_label_weight_tables for this label batch, computed earlier in the step."""
     if not getattr(criterion, 'pea_fused', False):
         raise NotImplementedError("the labels-in section fuses WeightedMSE; use cvppp_loss_section for another criterion")
     if ema_embedding.requires_grad:
@@ -426,5 +459,6 @@ def cvppp_loss_section_from_labels(embedding, emds, ema_embedding, labels, label
     specs, weights = _section_specs(offsets, nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb)
     specs[0].label_flags = (_lib.TGT_PADDING | _lib.TGT_MASK_INSIDE, _lib.TGT_PADDING, True)  # gen_affs_ours(padding=True) + its mask
     specs[0].relu = specs[-1].relu = bool(relu_pred)
+    specs[0].weight_tables = None if weight_tables is None else list(weight_tables)
     loss, pred, losses = _LabelsSection.apply(specs, weights, ema_embedding, [labels] + list(label_downs), embedding, *emds)
     return loss, pred, _section_parts(losses, weights, self_emb, cross_emb)

@@ -76,13 +76,24 @@ def graphed(fn):
     return g.replay
 
 
+TABS = pkg.cvppp_label_weight_tables(labs[0], labs[1:], offsets, nb_half)
+
+
+def labels_section_tables():
+    x = leaves()
+    loss, pred, _ = pkg.cvppp_loss_section_from_labels(x[0], x[1:], ema, labs[0], labs[1:], crit, offsets, nb_half, relu_pred=True,
+                                                       weight_tables=TABS)
+    loss.backward()
+
+
 px = B * H * W
 for _ in range(30):  # clocks and allocator pools settle before the first timed case
     tensor_section(False)
 torch.cuda.synchronize()
 for name, fn in (("tensor path, targets resident", lambda: tensor_section(False)),
                  ("tensor path + gen_targets each step", lambda: tensor_section(True)),
-                 ("labels-in path", labels_section)):
+                 ("labels-in path", labels_section),
+                 ("labels-in path, weight tables computed ahead", labels_section_tables)):
     us = timed(fn)
     ug = timed(graphed(fn))
     print("%s loss section (%s): eager %8.1f us, HIP-graph replay %8.1f us = %6.0f Mpx/s of full-resolution pixels"

@@ -936,6 +936,14 @@ def test_loss_section_relu_pred_option(pkg, dev, synth):
             res.append((loss.item(), pred.clone(), et.grad.clone()))
         assert res[0][0] == res[1][0] and torch.equal(res[0][2], res[1][2])
         assert float(res[0][1].min()) < 0.0 and torch.equal(torch.relu(res[0][1]), res[1][1])
+    # the class-balance tables computed ahead of the section: bit-identical results
+    tabs = pkg.cvppp_label_weight_tables(lab_t[0], lab_t[1:], offsets, nb_half)
+    et = cu(e, dev).requires_grad_(True)
+    emd_t = [cu(x, dev).requires_grad_(True) for x in emds]
+    loss, pred, _ = pkg.cvppp_loss_section_from_labels(et, emd_t, cu(ema, dev), lab_t[0], lab_t[1:], crit, offsets, nb_half,
+                                                       relu_pred=True, weight_tables=tabs)
+    loss.backward()
+    assert loss.item() == res[1][0] and torch.equal(pred, res[1][1]) and torch.equal(et.grad, res[1][2])
 
 
 @pytest.mark.parametrize("case", ["self_f32", "ema_f32", "self_f16", "zero_px"])
