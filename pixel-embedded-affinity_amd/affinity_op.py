@@ -71,7 +71,24 @@ def _batch_strided(t, name, dtype, shape):
     return t, (t.stride(0) if t.shape[0] > 1 else 0)
 
 
+_DESC_CACHE = {}
+
+
 def make_desc(spec, e, tstride=0, wstride=0, mstride=0):
+    """PeaDesc for `spec` on a tensor shaped like e.  Descriptors are immutable once built (the library takes them as
+    const), so they are memoised: filling and validating one costs more host time than the launch it describes."""
+    key = (spec.ndim, tuple(spec.offsets), tuple(spec.lam), spec.border, spec.norm, spec.eps, spec.relu, tuple(e.shape),
+           e.dtype == torch.float16, int(tstride), int(wstride), int(mstride))
+    d = _DESC_CACHE.get(key)
+    if d is not None:
+        return d
+    if len(_DESC_CACHE) > 512:
+        _DESC_CACHE.clear()
+    d = _DESC_CACHE[key] = _build_desc(spec, e, tstride, wstride, mstride)
+    return d
+
+
+def _build_desc(spec, e, tstride, wstride, mstride):
     dims = _spatial(e, spec.ndim)
     d = PeaDesc()
     d.abi, d.ndim, d.B, d.D = _lib.PEA_ABI_VERSION, spec.ndim, e.shape[0], e.shape[1]

@@ -6,6 +6,7 @@ can replace scripts_cvppp/main.py:282-312 / scripts_ac3ac4/main.py:216-238 by on
 happens inside (the reference's K `.item()` calls per loss are gone), so the section can be captured in a HIP graph
 (tests/test_gpu_parity.py::test_loss_section_graph_replay).
 """
+import copy
 import ctypes
 import os
 
@@ -161,7 +162,22 @@ def _section_backward(ctx, dtotal):
     return (None, None, None, None) + tuple(g if ctx.needs_input_grad[4 + k] else None for k, g in enumerate(grads))
 
 
+_SPEC_CACHE = {}
+
+
 def _section_specs(offsets, nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb):
+    """the six AffinitySpecs and loss weights of the section; built once per configuration (the callers get shallow
+    copies: they set relu / label flags on theirs)"""
+    key = (tuple(tuple(o) for o in offsets), nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb)
+    hit = _SPEC_CACHE.get(key)
+    if hit is None:
+        if len(_SPEC_CACHE) > 64:
+            _SPEC_CACHE.clear()
+        hit = _SPEC_CACHE[key] = _build_section_specs(offsets, nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb)
+    return [copy.copy(sp) for sp in hit[0]], hit[1]
+
+
+def _build_section_specs(offsets, nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb):
     from ..loss.loss_embedding_mse import _spec
     dwf = deep_weight_factor(deep_weight)
     specs = [_spec(offsets, [1.0] * len(offsets), dis_mode)]
