@@ -984,3 +984,21 @@ def test_chunked_d64_forward_vs_oracle(pkg, dev, orc, synth, monkeypatch, case):
     monkeypatch.setenv("PEA_FORCE_DIRECT", "1")
     ref = run()
     assert np.abs(got[1] - ref[1]).max() < 2e-6 and abs(got[0] - ref[0]) <= 2e-6 * abs(ref[0])
+
+
+def test_plain_c_consumer_of_the_abi(tmp_path):
+    """examples/abi_demo.c: the library driven from plain C (gcc, HIP runtime for memory, no Python / torch in the process)
+    against a scalar double-precision restatement of the reference's op sequence written out in the program"""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("needs gcc and the ROCm headers")
+    csrc = os.path.join(root, ge.PKG_DIR if hasattr(ge, "PKG_DIR") else "pixel-embedded-affinity_amd", "csrc")
+    exe = str(tmp_path / "abi_demo")
+    subprocess.check_call(["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "abi_demo.c"), "-L" + csrc, "-lpea_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-lm", "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=csrc + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "abi_demo: OK" in out.stdout, out.stdout + out.stderr
