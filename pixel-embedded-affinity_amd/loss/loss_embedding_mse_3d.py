@@ -10,7 +10,6 @@ Semantics kept from the reference (file:line there):
   * norm5's shift table is the literal [1,1,1,2,3,3,3,9,9,4,27,27] (:176); its `shift`/`fill` arguments are unused
   * ema_*: the EMA embedding is the shifted-from operand (:35,:241)
 """
-import torch
 
 from .. import _lib
 from ..affinity_op import AffinityMap, AffinitySpec, FusedAffinityMSE, LabelsAffinityMSE, LabelsStepUnsupported, affinity_infer

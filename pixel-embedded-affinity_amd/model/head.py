@@ -11,7 +11,6 @@ Forward and backward are pea_head_fwd / pea_head_bwd (include/pea.h): hand-writt
 gradient on the matrix cores in exact f32.  The library has kernels for every head of the reference's models (2D ResUNet:
 32 / 64 / 128 / 256 input channels -> 16 or 32; 3D superhuman U-Net: 28 / 36 / 48 / 64 / 80 -> 16); any other channel
 pair goes through torch's own GPU convolution.  CPU tensors are refused like everywhere else in this package."""
-import ctypes
 
 import torch
 import torch.nn as nn
