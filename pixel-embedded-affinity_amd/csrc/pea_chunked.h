@@ -104,11 +104,11 @@ __global__ __launch_bounds__(TH* TW, (DC > 16 ? 2 : 4)) void k_fwd_tiled_chunked
   const unsigned pe = live ? po * (unsigned)sizeof(T) : kOOB;
   const int pr = (ly + Q.hy0) * Q.RW + lx + Q.hx0;
 
-  // streaming operands of the first near offsets and the first two far offsets: in flight during all the staging
+  // (target / weight / mask are requested in the epilogue, not up front as in k_fwd_tiled: holding them across the
+  // chunk loop made the register allocator spill, and this toolchain's spill stores are exposed to the same
+  // store-data hazard as bs128 -- a randomised sweep caught a wrong g in one f16 instantiation with 25 spilled VGPRs)
   Twm<KN> sa;
   Twm<2> sf;
-  if (TRAIN && Q.n_near > 0) fwd_load_twm<KN>(sa, U, Q.near, 0, Q.n_near, pb, pm);
-  if (TRAIN && Q.n_far > 0) fwd_load_twm<2>(sf, U, Q.far, 0, Q.n_far, pb, pm);
 
   // far neighbours: address and validity once
   unsigned fvo[kChF], fzo[kChF];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(TH* TW, (DC > 16 ? 2 : 4)) void k_fwd_tiled_chunked
 #pragma unroll
   for (int k0 = 0; k0 < kChN; k0 += KN) {
     if (k0 < Q.n_near) {
-      if (TRAIN && k0 > 0) fwd_load_twm<KN>(sa, U, Q.near, k0, Q.n_near, pb, pm);
+      if (TRAIN) fwd_load_twm<KN>(sa, U, Q.near, k0, Q.n_near, pb, pm);
 #pragma unroll
       for (int u = 0; u < KN; ++u) {
         if (k0 + u < kChN && k0 + u < Q.n_near) {  // uniform
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(TH* TW, (DC > 16 ? 2 : 4)) void k_fwd_tiled_chunked
 #pragma unroll
   for (int k = 0; k < kChF; k += 2) {
     if (k < Q.n_far) {
-      if (TRAIN && k > 0) fwd_load_twm<2>(sf, U, Q.far, k, Q.n_far, pb, pm);
+      if (TRAIN) fwd_load_twm<2>(sf, U, Q.far, k, Q.n_far, pb, pm);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         if (k + u < Q.n_far) {

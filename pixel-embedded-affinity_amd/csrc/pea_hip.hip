@@ -333,8 +333,13 @@ bool try_fwd_chunked(const KParams& P, const T* e, const T* eo, const float* t, 
   if (!plan_tiles(P, c, false, &Q) || Q.n_near > kChN || Q.n_far > kChF) return false;
   const size_t lds = Lds<DC, c.PLQ>::kBytes + (size_t)c.PLQ * 4 + (size_t)(c.TH * c.TW / 64) * P.K * 4;
   if (lds > (size_t)kLdsMax) return false;
-  if (eo == e) launch_fwd_chunked<T, D_T, DC, TRAIN, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
-  else launch_fwd_chunked<T, D_T, DC, TRAIN, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
+  if (eo == e) {
+    launch_fwd_chunked<T, D_T, DC, TRAIN, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
+  } else {
+    // a second operand under the 128-VGPR budget of DC = 16 spills: not instantiated (the caller keeps the one-region kernels)
+    if constexpr (DC > 16) launch_fwd_chunked<T, D_T, DC, TRAIN, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
+    else return false;
+  }
   *nparts = Q.ntiles;
   return true;
 }
@@ -348,7 +353,9 @@ int launch_fwd(const KParams& P, const void* e, const void* eo, const float* t, 
     bool done = false;
     if (P.D == 16 && TRAIN) done = try_fwd_v<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
     if (!done && P.D == 16) done = try_fwd_tiled<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
-    if (P.D == 32 && env_int("PEA_FWD_CHUNKED32", 1) != 0)  // 64 B of LDS per region pixel: two workgroups per CU
+    // 64 B of LDS per region pixel: two workgroups per CU.  Self loss / inference only: with a second operand the
+    // 128-VGPR budget of that occupancy spills (and see pea_chunked.h on spill stores), so EMA calls keep the one-region kernels
+    if (P.D == 32 && env_int("PEA_FWD_CHUNKED32", 1) != 0)
       done = try_fwd_chunked<T, 32, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
     if (!done && P.D == 32 && TRAIN) done = try_fwd_v<T, 32, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
     if (!done && P.D == 32) done = try_fwd_tiled<T, 32, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Randomised agreement sweep: the LDS-tiled kernels (default dispatch) against the direct kernels (PEA_FORCE_DIRECT=1)
+on shapes wide enough for the tiles: D in {16, 32, 64}, f32 / f16, self / EMA (with and without a gradient for the second
+operand), 2D circular / 3D cropped, random stencils (both signs, up to +-30), masks on / off, every normaliser.
+Prints the worst deviations; exits non-zero on a disagreement.  usage: fuzz_tiled_vs_direct.py [cases] [seed]"""
+import importlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+pkg = ge.load_package()
+op = pkg.affinity_op
+dev = torch.device("cuda:0")
+ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+worst = {"affs": 0.0, "loss": 0.0, "grad": 0.0, "grad_o": 0.0}
+bad = 0
+for it in range(ncase):
+    three_d = rng.random() < 0.3
+    D = int(rng.choice([16, 16, 32, 64]))
+    f16 = rng.random() < 0.3
+    B = int(rng.integers(1, 3))
+    if three_d:
+        dims = [int(rng.integers(2, 6)), int(rng.integers(34, 80)), int(rng.integers(40, 110))]
+    else:
+        dims = [1, int(rng.integers(34, 150)), int(rng.integers(40, 200))]
+    K = int(rng.integers(1, 13))
+    offs = []
+    for _ in range(K):
+        o = [int(rng.integers(-2, 3)) if three_d and rng.random() < 0.4 else 0,
+             int(rng.integers(-30, 31)), int(rng.integers(-30, 31))]
+        o = [max(-(d - 1), min(d - 1, v)) for v, d in zip(o, dims)]
+        if o == [0, 0, 0]:
+            o[2] = -1
+        offs.append(o)
+    border = 1 if three_d else int(rng.integers(0, 2))
+    norm = int(rng.integers(0, 3))
+    lam = [float(v) for v in rng.uniform(0.25, 2.0, K)]
+    shape_e, shape_k = [B, D] + dims, [B, K] + dims
+    g = torch.Generator(device=dev); g.manual_seed(1000 + it)
+    dt = torch.float16 if f16 else torch.float32
+    e = torch.randn(shape_e, device=dev, generator=g).to(dt)
+    mode = int(rng.integers(0, 3))  # 0 self, 1 EMA detached, 2 EMA with gradient
+    o = torch.randn(shape_e, device=dev, generator=g).to(dt) if mode else None
+    t = (torch.rand(shape_k, device=dev, generator=g) < 0.6).float()
+    w = torch.rand(shape_k, device=dev, generator=g) + 0.5
+    m = (torch.rand(shape_k, device=dev, generator=g) < 0.9).to(torch.uint8) if rng.random() < 0.6 else None
+    spec = op.AffinitySpec(3, offs, lam, border, norm)
+    res = []
+    for direct in ("0", "1"):
+        os.environ["PEA_FORCE_DIRECT"] = direct
+        et = e.clone().requires_grad_(True)
+        ot = o.clone().requires_grad_(mode == 2) if o is not None else None
+        loss, affs, _ = op.FusedAffinityMSE.apply(et, ot, t, w, m, spec)
+        (loss * 0.75).backward()
+        inf = op.affinity_infer(et.detach(), ot.detach() if ot is not None else None, spec)
+        res.append((loss.item(), affs.float(), inf.float(), et.grad.float(), ot.grad.float() if mode == 2 else None))
+    os.environ["PEA_FORCE_DIRECT"] = "0"
+    a, b = res
+    tol_g = 3e-3 if f16 else 1e-4
+    d_affs = max(float((a[1] - b[1]).abs().max()), float((a[2] - b[2]).abs().max()))
+    d_loss = abs(a[0] - b[0]) / max(abs(b[0]), 1e-6)
+    d_grad = float((a[3] - b[3]).abs().max() / b[3].abs().max().clamp_min(1e-30))
+    d_go = float((a[4] - b[4]).abs().max() / b[4].abs().max().clamp_min(1e-30)) if mode == 2 else 0.0
+    for k, v in (("affs", d_affs), ("loss", d_loss), ("grad", d_grad), ("grad_o", d_go)):
+        worst[k] = max(worst[k], v)
+    ok = d_affs < 1e-5 and d_loss < 1e-5 and d_grad < tol_g and d_go < tol_g and bool(torch.isfinite(a[3]).all())
+    if not ok:
+        bad += 1
+        orc = ge.load_oracle(); orc.build()  # the referee (test infrastructure, only on a disagreement)
+        en, on_ = e.float().cpu().numpy(), (o.float().cpu().numpy() if o is not None else None)
+        dd = orc.make_desc(B, D, dims, offs, lam, border, norm, ndim=3)
+        o_affs, o_loss = orc.c_fwd(dd, en, on_, t.cpu().numpy(), w.cpu().numpy(), m.cpu().numpy() if m is not None else None)
+        o_grad, _ = orc.c_bwd(dd, en, on_, t.cpu().numpy(), w.cpu().numpy(), m.cpu().numpy() if m is not None else None, dloss=0.75)
+        for nm, r in (("tiled", a), ("direct", b)):
+            print("   %s vs oracle: loss rel %.2e  grad rel %.2e" % (nm, abs(r[0] - o_loss[0]) / abs(o_loss[0]),
+                  float(np.abs(r[3].cpu().numpy() - o_grad).max() / np.abs(o_grad).max())))
+        print("MISMATCH case %d: D=%d f16=%d dims=%s K=%d offs=%s border=%d norm=%d mode=%d mask=%d -> affs %.2e loss %.2e grad %.2e grad_o %.2e"
+              % (it, D, f16, dims, K, offs, border, norm, mode, m is not None, d_affs, d_loss, d_grad, d_go), flush=True)
+print("fuzz: %d cases, %d mismatches; worst affs %.2e loss %.2e grad %.2e grad_other %.2e" % (ncase, bad, worst["affs"], worst["loss"], worst["grad"], worst["grad_o"]))
+sys.exit(1 if bad else 0)
