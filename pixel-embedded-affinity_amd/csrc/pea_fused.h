@@ -28,7 +28,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fused_tiled(const KParams P, cons
   typedef Lds<D_T, PLQ> L;
   constexpr int NT = TH * TW, NW = NT / 64;
   constexpr int NR = ROLE_B ? 2 : 1;
-  constexpr int KN = 4;  // near offsets per chunk (x NR roles of target / weight / mask samples held in registers)
+  constexpr int KN = 3;  // near offsets per chunk (x NR roles of target / weight / mask samples held in registers; 4 made the allocator spill)
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   float* s_part = (float*)(lds + L::kBytes);  // [NW][K] loss partials per wave

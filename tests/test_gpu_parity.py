@@ -1002,3 +1002,15 @@ def test_plain_c_consumer_of_the_abi(tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH=csrc + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "abi_demo: OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_randomised_tiled_vs_direct_sweep():
+    """profiles/fuzz_tiled_vs_direct.py: 80 random configurations (D 16 / 32 / 64, f32 / f16, self / EMA, 2D / 3D, random
+    stencils, masks, normalisers) on shapes wide enough for the LDS-tiled kernels, default dispatch against the direct
+    kernels, the oracle as referee on a disagreement"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "profiles", "fuzz_tiled_vs_direct.py"), "80", "23"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
