@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Randomised agreement sweep over the alternative paths to the same numbers:
+  (a) the labels-in step (embedding_loss_from_labels / ema_...) against gen_targets + the tensor path,
+  (b) the one-launch step (PEA_FUSED=1) against forward + backward,
+  (c) the embedding head against torch's GPU convolution (every supported channel pair, ragged pixel counts).
+usage: fuzz_paths.py [cases] [seed]; exits non-zero on a disagreement."""
+import os, sys
+import numpy as np, torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+pkg = ge.load_package()
+dev = torch.device("cuda:0")
+ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+crit = pkg.WeightedMSE()
+bad = 0
+worst = {}
+
+
+def rel(a, b):
+    return float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-30))
+
+
+def note(tag, ok, ctx, **vals):
+    global bad
+    for k, v in vals.items():
+        worst[tag + "." + k] = max(worst.get(tag + "." + k, 0.0), v)
+    if not ok:
+        bad += 1
+        print("MISMATCH %s %s %s" % (tag, ctx, {k: "%.2e" % v for k, v in vals.items()}), flush=True)
+
+
+for it in range(ncase):
+    g = torch.Generator(device=dev); g.manual_seed(500 + it)
+    D = int(rng.choice([16, 16, 32]))
+    f16 = rng.random() < 0.25
+    dt = torch.float16 if f16 else torch.float32
+    B, H, W = int(rng.integers(1, 4)), int(rng.integers(34, 140)), int(rng.integers(40, 180)) // 4 * 4
+    shifts = sorted(set(int(v) for v in rng.choice([1, 2, 3, 5, 9, 11, 27], size=int(rng.integers(1, 5)))))
+    offsets = pkg.multi_offset(shifts, int(rng.choice([4, 8])))[:12]
+    K = len(offsets)
+    e = torch.randn(B, D, H, W, device=dev, generator=g).to(dt)
+    ema = torch.randn(B, D, H, W, device=dev, generator=g).to(dt) if rng.random() < 0.4 else None
+    cell = int(rng.integers(4, 24))
+    lab = torch.randint(0, 6, (B, (H + cell - 1) // cell, (W + cell - 1) // cell), device=dev, generator=g)
+    lab = lab.repeat_interleave(cell, 1).repeat_interleave(cell, 2)[:, :H, :W].contiguous().to(torch.int32)
+    ctx = "case %d D=%d f16=%d B=%d %dx%d shifts=%s K=%d ema=%d" % (it, D, f16, B, H, W, shifts, K, ema is not None)
+    tol_g = 3e-3 if f16 else 1e-4
+
+    # ---- (a) labels-in against targets + tensor path
+    t, m, w = pkg.gen_targets(lab, offsets, padding=True)
+    res = []
+    for path in ("tensor", "labels"):
+        et = e.clone().requires_grad_(True)
+        if path == "tensor":
+            out = pkg.ema_embedding_loss(et, ema, t, w, m, crit, offsets, affs0_weight=2) if ema is not None else \
+                pkg.embedding_loss(et, t, w, m, crit, offsets)
+        else:
+            out = pkg.ema_embedding_loss_from_labels(et, ema, lab, crit, offsets, affs0_weight=2) if ema is not None else \
+                pkg.embedding_loss_from_labels(et, lab, crit, offsets)
+        (out[0] * 1.25).backward()
+        res.append((out[0].item(), out[1], et.grad))
+    da = float((res[0][1] - res[1][1]).abs().max())
+    dl = abs(res[0][0] - res[1][0]) / max(abs(res[0][0]), 1e-9)
+    dg = rel(res[1][2], res[0][2])
+    note("labels", da < 1e-5 and dl < 1e-5 and dg < tol_g, ctx, affs=da, loss=dl, grad=dg)
+
+    # ---- (b) one launch against two (self loss or detached EMA)
+    res = []
+    for fused in ("0", "1"):
+        os.environ["PEA_FUSED"] = fused
+        et = e.clone().requires_grad_(True)
+        out = pkg.ema_embedding_loss(et, ema, t, w, m, crit, offsets) if ema is not None else pkg.embedding_loss(et, t, w, m, crit, offsets)
+        (out[0] * 0.5).backward()
+        res.append((out[0].item(), out[1], et.grad))
+    os.environ["PEA_FUSED"] = "0"
+    da = float((res[0][1] - res[1][1]).abs().max())
+    dl = abs(res[0][0] - res[1][0]) / max(abs(res[0][0]), 1e-9)
+    dg = rel(res[1][2], res[0][2])
+    note("fused", da < 1e-5 and dl < 1e-5 and dg < tol_g, ctx, affs=da, loss=dl, grad=dg)
+
+    # ---- (c) head against torch's convolution
+    D_h = int(rng.choice([16, 32]))
+    C = int(rng.choice([28, 32, 36, 48, 64, 80, 128, 256] if D_h == 16 else [32, 64, 128, 256]))
+    sp = (int(rng.integers(1, 4)), int(rng.integers(3, 40)), int(rng.integers(3, 50))) if rng.random() < 0.3 else \
+        (int(rng.integers(3, 90)), int(rng.integers(3, 120)))
+    Bh = int(rng.integers(1, 4))
+    x = torch.randn((Bh, C) + sp, device=dev, generator=g)
+    wt = torch.randn((D_h, C) + (1,) * len(sp), device=dev, generator=g) * 0.2
+    bs = torch.randn(D_h, device=dev, generator=g)
+    up = torch.randn((Bh, D_h) + sp, device=dev, generator=g)
+    conv = F.conv3d if len(sp) == 3 else F.conv2d
+    outs = []
+    for mine in (False, True):
+        xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)
+        eh = pkg.EmbeddingHead.apply(xr, wr, br) if mine else conv(xr, wr, br)
+        (eh * up).sum().backward()
+        outs.append((eh.detach(), xr.grad, wr.grad, br.grad))
+    d = [rel(outs[1][k], outs[0][k]) for k in range(4)]
+    note("head", max(d) < 5e-5, "case %d C=%d D=%d B=%d sp=%s" % (it, C, D_h, Bh, sp), e=d[0], dx=d[1], dW=d[2], db=d[3])
+
+print("fuzz_paths: %d cases, %d mismatches; worst %s" % (ncase, bad, {k: "%.1e" % v for k, v in sorted(worst.items())}))
+sys.exit(1 if bad else 0)

@@ -1014,3 +1014,15 @@ def test_randomised_tiled_vs_direct_sweep():
     out = subprocess.run([sys.executable, os.path.join(root, "profiles", "fuzz_tiled_vs_direct.py"), "80", "23"], capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_randomised_alternative_paths_sweep():
+    """profiles/fuzz_paths.py: 40 random configurations of the paths that must give the same numbers -- the labels-in step
+    against gen_targets + the tensor path, the one-launch step against forward + backward, the embedding head against
+    torch's GPU convolution (every supported channel pair, ragged pixel counts)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "profiles", "fuzz_paths.py"), "40", "31"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
