@@ -2,7 +2,8 @@
 """Randomised agreement sweep over the alternative paths to the same numbers:
   (a) the labels-in step (embedding_loss_from_labels / ema_...) against gen_targets + the tensor path,
   (b) the one-launch step (PEA_FUSED=1) against forward + backward,
-  (c) the embedding head against torch's GPU convolution (every supported channel pair, ragged pixel counts).
+  (c) the embedding head against torch's GPU convolution (every supported channel pair, ragged pixel counts),
+  (d) the six-loss section as one autograd node and from labels against its call-by-call composition.
 usage: fuzz_paths.py [cases] [seed]; exits non-zero on a disagreement."""
 import os, sys
 import numpy as np, torch
@@ -99,6 +100,45 @@ for it in range(ncase):
         outs.append((eh.detach(), xr.grad, wr.grad, br.grad))
     d = [rel(outs[1][k], outs[0][k]) for k in range(4)]
     note("head", max(d) < 5e-5, "case %d C=%d D=%d B=%d sp=%s" % (it, C, D_h, Bh, sp), e=d[0], dx=d[1], dW=d[2], db=d[3])
+
+    # ---- (d) the loss section: one autograd node (two-phase dual kernels, second stream) and the labels-in section
+    #          against the call-by-call composition
+    if it % 3 == 0:
+        nb_half = 2
+        offs_s = pkg.multi_offset([1, 3, 5, 9, 27][:int(rng.integers(3, 6))], 4)
+        Hs, Ws = int(rng.integers(3, 10)) * 16, int(rng.integers(3, 12)) * 16
+        Bs = int(rng.integers(1, 3))
+        es = torch.randn(Bs, 16, Hs, Ws, device=dev, generator=g)
+        emas = torch.randn(Bs, 16, Hs, Ws, device=dev, generator=g)
+        labs = torch.randint(0, 5, (Bs, Hs // 8 + 1, Ws // 8 + 1), device=dev, generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
+        labs = labs[:, :Hs, :Ws].contiguous().to(torch.int32)
+        lab_l = [labs[:, ::2 ** j, ::2 ** j].contiguous() for j in range(5)]
+        emds = [torch.randn(Bs, 16, Hs >> (j + 1), Ws >> (j + 1), device=dev, generator=g) for j in range(4)]
+        tt, mm, ww = pkg.gen_targets(lab_l[0], offs_s, padding=True)
+        downs = []
+        for j in range(1, 5):
+            k = nb_half * (5 - j)
+            if k > len(offs_s):
+                break
+            tj, mj, wj = pkg.gen_targets(lab_l[j], offs_s[:k], padding=True)
+            downs.append(torch.cat([tj, wj, mj.float()], dim=1))
+        if len(downs) == 4:
+            kw = dict(affs0_weight=2, deep_weight=int(rng.integers(0, 3)), self_emb=0.8, cross_emb=1.2)
+            rs = []
+            for which in ("composed", "node", "labels"):
+                xs = [es.clone().requires_grad_(True)] + [v.clone().requires_grad_(True) for v in emds]
+                if which == "labels":
+                    loss, pred, _ = pkg.cvppp_loss_section_from_labels(xs[0], xs[1:], emas, lab_l[0], lab_l[1:], crit, offs_s, nb_half, **kw)
+                else:
+                    fn = pkg.cvppp_loss_section_composed if which == "composed" else pkg.cvppp_loss_section
+                    loss, pred, _ = fn(xs[0], xs[1:], emas, tt, ww, mm, downs, crit, offs_s, nb_half, **kw)
+                (loss * 0.5).backward()
+                rs.append((loss.item(), pred, [v.grad for v in xs]))
+            for k_, nm in ((1, "section_node"), (2, "section_labels")):
+                dl = abs(rs[k_][0] - rs[0][0]) / abs(rs[0][0])
+                da = float((rs[k_][1] - rs[0][1]).abs().max())
+                dg = max(rel(a_, b_) for a_, b_ in zip(rs[k_][2], rs[0][2]))
+                note(nm, dl < 1e-5 and da < 1e-5 and dg < 1e-4, "case %d B=%d %dx%d K=%d %s" % (it, Bs, Hs, Ws, len(offs_s), kw), loss=dl, affs=da, grad=dg)
 
 print("fuzz_paths: %d cases, %d mismatches; worst %s" % (ncase, bad, {k: "%.1e" % v for k, v in sorted(worst.items())}))
 sys.exit(1 if bad else 0)
