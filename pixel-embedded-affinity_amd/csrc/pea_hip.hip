@@ -943,15 +943,16 @@ int pea_affinity_fwd_bwd_labels_dual(const PeaDesc* desc, const PeaDesc* desc_cr
   const KParams P = make_params(desc), P2 = make_params(desc_cross);
   const size_t np = fwd_partials(P) * P.K;
   if (!workspace || workspace_bytes < 2 * np * sizeof(float)) return PEA_E_WORKSPACE;
-  if (P.D != 16 || env_int("PEA_FORCE_DIRECT", 0) != 0 || env_int("PEA_LABELS_DUAL", 1) == 0) return PEA_E_UNSUPPORTED;
+  if ((P.D != 16 && P.D != 32) || env_int("PEA_FORCE_DIRECT", 0) != 0 || env_int("PEA_LABELS_DUAL", 1) == 0) return PEA_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float *partials = (float*)workspace, *partials2 = partials + np;
   int nparts = 0;
-  bool done = desc->dtype == PEA_F16
-                  ? try_fused_labels_dual<__half, 16>(P, P2, (const __half*)e, (const __half*)ema, labels, wtab, flags, affs, partials,
-                                                      partials2, dloss, dloss_cross, (__half*)de, s, &nparts)
-                  : try_fused_labels_dual<float, 16>(P, P2, (const float*)e, (const float*)ema, labels, wtab, flags, affs, partials,
-                                                     partials2, dloss, dloss_cross, (float*)de, s, &nparts);
+  bool done;
+#define PEA_LD(T_, D_) try_fused_labels_dual<T_, D_>(P, P2, (const T_*)e, (const T_*)ema, labels, wtab, flags, affs, partials, partials2, \
+                                                     dloss, dloss_cross, (T_*)de, s, &nparts)
+  if (P.D == 16) done = desc->dtype == PEA_F16 ? PEA_LD(__half, 16) : PEA_LD(float, 16);
+  else done = desc->dtype == PEA_F16 ? PEA_LD(__half, 32) : PEA_LD(float, 32);
+#undef PEA_LD
   if (!done) return PEA_E_UNSUPPORTED;
   rc = hip_rc();
   if (rc) return rc;
@@ -990,11 +991,13 @@ int pea_affinity_bwd_dual(const PeaDesc* desc, const void* e, const void* ema, c
       misaligned(dloss, 4) || misaligned(dloss_cross, 4))
     return PEA_E_ALIGN;
   const KParams P = make_params(desc);
-  if (P.D != 16 || env_int("PEA_FORCE_DIRECT", 0) != 0 || env_int("PEA_BWD_DUAL", 1) == 0) return PEA_E_UNSUPPORTED;
+  if ((P.D != 16 && P.D != 32) || env_int("PEA_FORCE_DIRECT", 0) != 0 || env_int("PEA_BWD_DUAL", 1) == 0) return PEA_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  const bool done = desc->dtype == PEA_F16
-                        ? try_bwd_dual<__half, 16>(P, (const __half*)e, (const __half*)ema, g, g_cross, dloss, dloss_cross, (__half*)de, s)
-                        : try_bwd_dual<float, 16>(P, (const float*)e, (const float*)ema, g, g_cross, dloss, dloss_cross, (float*)de, s);
+  bool done;
+#define PEA_BD(T_, D_) try_bwd_dual<T_, D_>(P, (const T_*)e, (const T_*)ema, g, g_cross, dloss, dloss_cross, (T_*)de, s)
+  if (P.D == 16) done = desc->dtype == PEA_F16 ? PEA_BD(__half, 16) : PEA_BD(float, 16);
+  else done = desc->dtype == PEA_F16 ? PEA_BD(__half, 32) : PEA_BD(float, 32);
+#undef PEA_BD
   if (!done) return PEA_E_UNSUPPORTED;
   return hip_rc();
 }

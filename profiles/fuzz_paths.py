@@ -108,12 +108,13 @@ for it in range(ncase):
         offs_s = pkg.multi_offset([1, 3, 5, 9, 27][:int(rng.integers(3, 6))], 4)
         Hs, Ws = int(rng.integers(3, 10)) * 16, int(rng.integers(3, 12)) * 16
         Bs = int(rng.integers(1, 3))
-        es = torch.randn(Bs, 16, Hs, Ws, device=dev, generator=g)
-        emas = torch.randn(Bs, 16, Hs, Ws, device=dev, generator=g)
+        Ds = int(rng.choice([16, 32]))
+        es = torch.randn(Bs, Ds, Hs, Ws, device=dev, generator=g)
+        emas = torch.randn(Bs, Ds, Hs, Ws, device=dev, generator=g)
         labs = torch.randint(0, 5, (Bs, Hs // 8 + 1, Ws // 8 + 1), device=dev, generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
         labs = labs[:, :Hs, :Ws].contiguous().to(torch.int32)
         lab_l = [labs[:, ::2 ** j, ::2 ** j].contiguous() for j in range(5)]
-        emds = [torch.randn(Bs, 16, Hs >> (j + 1), Ws >> (j + 1), device=dev, generator=g) for j in range(4)]
+        emds = [torch.randn(Bs, Ds, Hs >> (j + 1), Ws >> (j + 1), device=dev, generator=g) for j in range(4)]
         tt, mm, ww = pkg.gen_targets(lab_l[0], offs_s, padding=True)
         downs = []
         for j in range(1, 5):
@@ -138,7 +139,7 @@ for it in range(ncase):
                 dl = abs(rs[k_][0] - rs[0][0]) / abs(rs[0][0])
                 da = float((rs[k_][1] - rs[0][1]).abs().max())
                 dg = max(rel(a_, b_) for a_, b_ in zip(rs[k_][2], rs[0][2]))
-                note(nm, dl < 1e-5 and da < 1e-5 and dg < 1e-4, "case %d B=%d %dx%d K=%d %s" % (it, Bs, Hs, Ws, len(offs_s), kw), loss=dl, affs=da, grad=dg)
+                note(nm, dl < 1e-5 and da < 1e-5 and dg < 1e-4, "case %d D=%d B=%d %dx%d K=%d %s" % (it, Ds, Bs, Hs, Ws, len(offs_s), kw), loss=dl, affs=da, grad=dg)
 
 print("fuzz_paths: %d cases, %d mismatches; worst %s" % (ncase, bad, {k: "%.1e" % v for k, v in sorted(worst.items())}))
 sys.exit(1 if bad else 0)

@@ -9,9 +9,9 @@ import __graft_entry__ as ge
 pkg = ge.load_package()
 synth = importlib.import_module(ge.PKG_NAME + ".utils.synth")
 dev = torch.device("cuda:0")
-B, D, H, W, nb_half = 8, 16, 544, 544, 2
+B, D, H, W, nb_half = 8, int(os.environ.get("D", 16)), 544, 544, 2
 f16 = os.environ.get("F16", "0") == "1"
-offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+offsets = pkg.multi_offset([1, 3, 5, 9, 27] if D == 16 else [1, 3, 5, 9, 11], 4)  # cvppp.yaml / bbbc039v1.yaml shifts
 crit = pkg.WeightedMSE()
 lab = synth.synth_labels(B, (1, H, W), 555)[:, 0]
 labs = [torch.from_numpy(np.ascontiguousarray(lab[:, ::2 ** j, ::2 ** j])).to(dev) for j in range(5)]
@@ -96,5 +96,5 @@ for name, fn in (("tensor path, targets resident", lambda: tensor_section(False)
                  ("labels-in path, weight tables computed ahead", labels_section_tables)):
     us = timed(fn)
     ug = timed(graphed(fn))
-    print("%s loss section (%s): eager %8.1f us, HIP-graph replay %8.1f us = %6.0f Mpx/s of full-resolution pixels"
-          % ("f16" if f16 else "f32", name, us, ug, px / ug), flush=True)
+    print("%s D=%d loss section (%s): eager %8.1f us, HIP-graph replay %8.1f us = %6.0f Mpx/s of full-resolution pixels"
+          % ("f16" if f16 else "f32", D, name, us, ug, px / ug), flush=True)
