@@ -47,7 +47,7 @@ for it in range(ncase):
     lab = torch.randint(0, 6, (B, (H + cell - 1) // cell, (W + cell - 1) // cell), device=dev, generator=g)
     lab = lab.repeat_interleave(cell, 1).repeat_interleave(cell, 2)[:, :H, :W].contiguous().to(torch.int32)
     ctx = "case %d D=%d f16=%d B=%d %dx%d shifts=%s K=%d ema=%d" % (it, D, f16, B, H, W, shifts, K, ema is not None)
-    tol_g = 3e-3 if f16 else 1e-4
+    tol_g = 5e-3 if f16 else 1e-4  # f16: the gradient itself is stored in half precision (two roundings may differ by an ulp)
 
     # ---- (a) labels-in against targets + tensor path
     t, m, w = pkg.gen_targets(lab, offsets, padding=True)

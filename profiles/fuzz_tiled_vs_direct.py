@@ -56,7 +56,7 @@ for it in range(ncase):
         res.append((loss.item(), affs.float(), inf.float(), et.grad.float(), ot.grad.float() if mode == 2 else None))
     os.environ["PEA_FORCE_DIRECT"] = "0"
     a, b = res
-    tol_g = 3e-3 if f16 else 1e-4
+    tol_g = 5e-3 if f16 else 1e-4  # f16: the gradient itself is stored in half precision (two roundings may differ by an ulp)
     d_affs = max(float((a[1] - b[1]).abs().max()), float((a[2] - b[2]).abs().max()))
     d_loss = abs(a[0] - b[0]) / max(abs(b[0]), 1e-6)
     d_grad = float((a[3] - b[3]).abs().max() / b[3].abs().max().clamp_min(1e-30))
