@@ -1026,3 +1026,14 @@ def test_randomised_alternative_paths_sweep():
     out = subprocess.run([sys.executable, os.path.join(root, "profiles", "fuzz_paths.py"), "40", "31"], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_end_to_end_training_step_demo():
+    """examples/train_step_demo.py: stand-in backbone -> HIP embedding heads -> labels-in loss section (one node, second
+    stream, tables computed ahead) -> backward -> Adam -> EMA teacher, a few steps; the loss must fall"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "train_step_demo.py"), "6"], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and "train_step_demo: OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
