@@ -26,7 +26,8 @@ from .harness.stitch import VolumeStitcher
 from .model.head import EmbeddingHead, OutConv, head_conv3d_block
 from .harness.loss_section import (ac3ac4_loss_section, ac3ac4_loss_section_composed, ac3ac4_loss_section_from_labels,
                                    cvppp_loss_section, cvppp_loss_section_composed,
-                                   cvppp_loss_section_from_labels, cvppp_label_weight_tables, deep_weight_factor,
+                                   cvppp_loss_section_from_labels, cvppp_label_weight_tables, cvppp_validation_section,
+                                   deep_weight_factor,
                                    finish_pred_2d_, finish_pred_3d_)
 
 __all__ = [
@@ -38,5 +39,5 @@ __all__ = [
     "ema_embedding_loss_from_labels", "LabelsAffinityMSE", "cvppp_loss_section_from_labels", "cvppp_loss_section_composed", "ac3ac4_loss_section_composed",
     "ac3ac4_loss_section_from_labels",
     "embedding_loss_norm1_from_labels", "embedding_loss_norm5_from_labels", "ema_embedding_loss_norm5_from_labels",
-    "embedding_loss_norm6", "ema_embedding_loss_norm6", "EmbeddingHead", "OutConv", "head_conv3d_block", "cvppp_label_weight_tables",
+    "embedding_loss_norm6", "ema_embedding_loss_norm6", "EmbeddingHead", "OutConv", "head_conv3d_block", "cvppp_label_weight_tables", "cvppp_validation_section",
 ]

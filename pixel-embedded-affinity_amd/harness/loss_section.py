@@ -316,6 +316,30 @@ def finish_pred_3d_(pred, shift=1):
     return fill_border_relu_(pred, shift=shift, relu=True)
 
 
+def cvppp_validation_section(embedding, emds, target, weightmap, affs_mask, downs, criterion, offsets, nb_half,
+                             affs0_weight=1, dis_mode='ours', test_mode=False):
+    """The validation / test caller of scripts_cvppp/inference.py:179-193 (and the validation branch of main.py:380-395):
+    under no_grad, either embedding2affs alone (mode == 'test') or the five self losses -- unweighted sum, as the reference
+    adds them at :190 -- and the full-resolution map; `pred` comes back as F.relu(pred) (:193).  Returns (loss or None,
+    pred); the caller adds its own loss_mask term.  emds = (emd1, .., emd4), downs = (down1, .., down4) as in training."""
+    with torch.no_grad():
+        if test_mode:
+            from ..loss.loss_embedding_mse import embedding2affs
+            return None, finish_pred_2d_(embedding2affs(embedding, offsets, mode=dis_mode))
+        total = None
+        fork = _side_stream(embedding.device)
+        with fork:  # the small scales beside the full-resolution call, as in training
+            for j, (emd, down) in enumerate(zip(emds, downs)):
+                k = nb_half * (4 - j)
+                l, _, _ = embedding_loss(emd, down[:, 0:k], down[:, k:2 * k], down[:, 2 * k:3 * k], criterion, offsets[:k],
+                                         affs0_weight=affs0_weight, mode=dis_mode)
+                total = l if total is None else total + l
+        loss_embedding, pred, _ = embedding_loss(embedding, target, weightmap, affs_mask, criterion, offsets,
+                                                 affs0_weight=affs0_weight, mode=dis_mode)
+        fork.join()
+        return total + loss_embedding, finish_pred_2d_(pred)
+
+
 def finish_pred_2d_(pred):
     """scripts_cvppp/main.py:312"""
     return relu_(pred)

@@ -1037,3 +1037,27 @@ def test_end_to_end_training_step_demo():
     out = subprocess.run([sys.executable, os.path.join(root, "examples", "train_step_demo.py"), "6"], capture_output=True, text=True,
                          timeout=300)
     assert out.returncode == 0 and "train_step_demo: OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_validation_section_matches_call_by_call(pkg, dev, orc, synth):
+    """cvppp_validation_section (scripts_cvppp/inference.py:179-193): the five losses summed unweighted and relu(pred)
+    against the same calls made one by one, and against the oracle for the full-resolution loss; test mode = embedding2affs"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    nb_half, B, D, H, W = 2, 2, 16, 96, 128
+    e, _, t, w, m, emds, downs = _section_inputs(synth, offsets, nb_half, B, D, H, W, 91)
+    crit = pkg.WeightedMSE()
+    E, T, Wt, M = cu(e, dev), cu(t, dev), cu(w, dev), cu(m, dev)
+    emd_t, down_t = [cu(x, dev) for x in emds], [cu(x, dev) for x in downs]
+    loss, pred = pkg.cvppp_validation_section(E, emd_t, T, Wt, M, down_t, crit, offsets, nb_half)
+    ref = 0.0
+    for j in range(4):
+        k = nb_half * (4 - j)
+        l, _, _ = pkg.embedding_loss(emd_t[j], down_t[j][:, 0:k], down_t[j][:, k:2 * k], down_t[j][:, 2 * k:3 * k], crit, offsets[:k])
+        ref += l.item()
+    l0, a0, _ = pkg.embedding_loss(E, T, Wt, M, crit, offsets)
+    assert abs(loss.item() - (ref + l0.item())) <= 1e-6 * abs(ref + l0.item())
+    assert torch.equal(pred, torch.relu(a0)) and not loss.requires_grad
+    o_affs, o_loss = orc.c_fwd(orc.desc_2d(e, offsets), e, None, t, w, m)
+    assert abs(l0.item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+    none, pred_t = pkg.cvppp_validation_section(E, emd_t, T, Wt, M, down_t, crit, offsets, nb_half, test_mode=True)
+    assert none is None and np.abs(pred_t.cpu().numpy() - np.maximum(o_affs, 0)).max() < AFFS_ATOL
