@@ -1061,3 +1061,15 @@ def test_validation_section_matches_call_by_call(pkg, dev, orc, synth):
     assert abs(l0.item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
     none, pred_t = pkg.cvppp_validation_section(E, emd_t, T, Wt, M, down_t, crit, offsets, nb_half, test_mode=True)
     assert none is None and np.abs(pred_t.cpu().numpy() - np.maximum(o_affs, 0)).max() < AFFS_ATOL
+
+
+def test_randomised_data_format_paths_sweep():
+    """profiles/fuzz_formats.py: 30 random configurations of the data-format paths either side of the loss -- target
+    generation bit-exact against the numpy restatement, the 3D labels-in losses against targets + tensor functions, the
+    replicate-border variant against the C oracle, the device stitcher bit-exact against the reference's numpy statements"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "profiles", "fuzz_formats.py"), "30", "17"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
