@@ -7,7 +7,7 @@
 usage: fuzz_formats.py [cases] [seed]; exits non-zero on a disagreement.  The oracle is the checker (test infrastructure)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 orc = ge.load_oracle(); orc.build()

@@ -8,7 +8,7 @@ usage: fuzz_paths.py [cases] [seed]; exits non-zero on a disagreement."""
 import os, sys
 import numpy as np, torch
 import torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 dev = torch.device("cuda:0")

@@ -5,7 +5,7 @@ operand), 2D circular / 3D cropped, random stencils (both signs, up to +-30), ma
 Prints the worst deviations; exits non-zero on a disagreement.  usage: fuzz_tiled_vs_direct.py [cases] [seed]"""
 import importlib, os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 op = pkg.affinity_op

@@ -1005,25 +1005,25 @@ def test_plain_c_consumer_of_the_abi(tmp_path):
 
 
 def test_randomised_tiled_vs_direct_sweep():
-    """profiles/fuzz_tiled_vs_direct.py: 80 random configurations (D 16 / 32 / 64, f32 / f16, self / EMA, 2D / 3D, random
+    """tests/fuzz/fuzz_tiled_vs_direct.py: 80 random configurations (D 16 / 32 / 64, f32 / f16, self / EMA, 2D / 3D, random
     stencils, masks, normalisers) on shapes wide enough for the LDS-tiled kernels, default dispatch against the direct
     kernels, the oracle as referee on a disagreement"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "profiles", "fuzz_tiled_vs_direct.py"), "80", "23"], capture_output=True,
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_tiled_vs_direct.py"), "80", "23"], capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 def test_randomised_alternative_paths_sweep():
-    """profiles/fuzz_paths.py: 40 random configurations of the paths that must give the same numbers -- the labels-in step
+    """tests/fuzz/fuzz_paths.py: 40 random configurations of the paths that must give the same numbers -- the labels-in step
     against gen_targets + the tensor path, the one-launch step against forward + backward, the embedding head against
     torch's GPU convolution (every supported channel pair, ragged pixel counts)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "profiles", "fuzz_paths.py"), "40", "31"], capture_output=True, text=True,
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_paths.py"), "40", "31"], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
@@ -1064,12 +1064,12 @@ def test_validation_section_matches_call_by_call(pkg, dev, orc, synth):
 
 
 def test_randomised_data_format_paths_sweep():
-    """profiles/fuzz_formats.py: 30 random configurations of the data-format paths either side of the loss -- target
+    """tests/fuzz/fuzz_formats.py: 30 random configurations of the data-format paths either side of the loss -- target
     generation bit-exact against the numpy restatement, the 3D labels-in losses against targets + tensor functions, the
     replicate-border variant against the C oracle, the device stitcher bit-exact against the reference's numpy statements"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "profiles", "fuzz_formats.py"), "30", "17"], capture_output=True, text=True,
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_formats.py"), "30", "17"], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]

@@ -54,6 +54,24 @@ def test_product_never_imports_oracle(pkg):
                 assert not re.search(r"^\s*(from|import)\s+oracle|pea_oracle", src, flags=re.M), f
 
 
+def test_oracle_is_used_by_the_checkers_only():
+    """outside tests/ the oracle may be touched by __graft_entry__.smoke() and bench.py's cpu_baseline leg only: the
+    profiling scripts and the examples must not import it"""
+    import os
+    import re
+    from conftest import ROOT
+    for sub in ("profiles", "examples"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, sub)):
+            for f in fs:
+                if f.endswith((".py", ".sh", ".c", ".hip")):
+                    src = open(os.path.join(dp, f)).read()
+                    assert not re.search(r"load_oracle|pea_oracle|^\s*(from|import)\s+oracle", src, flags=re.M), os.path.join(dp, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"load_oracle", bench)]
+    lo, hi = bench.index("def cpu_baseline"), bench.index("def main")
+    assert uses and all(lo < u < hi for u in uses), "bench.py may use the oracle inside cpu_baseline only"
+
+
 def test_weighted_mse_module_formula(pkg):
     crit = pkg.WeightedMSE()
     pred, tgt, w = torch.rand(2, 5, 7), torch.rand(2, 5, 7), torch.rand(2, 5, 7)
