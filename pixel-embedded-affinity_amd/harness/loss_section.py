@@ -287,8 +287,8 @@ def ac3ac4_loss_section_from_labels(embedding, emds, ema_embedding, labels, labe
     if ema_embedding.requires_grad:
         raise NotImplementedError("the EMA operand must be detached (convert_consistency_flip)")
     specs, weights = _specs_3d(embedding_mode, affs0_weight)
-    specs[0].label_flags = (_lib.TGT_BOTH_FOREGROUND, _lib.TGT_BOTH_FOREGROUND, False)
-    loss, pred, _ = _LabelsSection.apply(specs, weights, ema_embedding, [labels] + list(label_downs[::-1]), embedding, *emds)
+    label_cfg = _LabelCfg([labels] + list(label_downs[::-1]), _lib.TGT_BOTH_FOREGROUND, _lib.TGT_BOTH_FOREGROUND, False, None)
+    loss, pred, _ = _LabelsSection.apply(specs, weights, ema_embedding, label_cfg, embedding, *emds)
     return loss, pred
 
 
@@ -345,6 +345,15 @@ def finish_pred_2d_(pred):
     return relu_(pred)
 
 
+class _LabelCfg(object):
+    """what the labels-in section needs besides the embeddings: the label images (full resolution first), the target flags
+    of the fused kernels / of pea_gen_targets (the fallback for scales smaller than a tile), whether a mask exists, and
+    optionally the class-balance tables computed ahead"""
+
+    def __init__(self, labels, lflags, gen_flags, has_mask, tables):
+        self.labels, self.lflags, self.gen_flags, self.has_mask, self.tables = labels, lflags, gen_flags, has_mask, tables
+
+
 class _LabelsSection(torch.autograd.Function):
     """The whole loss section as ONE autograd node: every loss is a labels-in launch that writes its gradient already
     multiplied by its weight (deep_weight_factor x self_emb / cross_emb is known before the launch), the EMA cross loss
@@ -354,12 +363,12 @@ class _LabelsSection(torch.autograd.Function):
     when it is composed from the per-loss functions, profiles/r1c_loss_section.txt)."""
 
     @staticmethod
-    def forward(ctx, specs, weights, ema_embedding, labels_list, *embs):
+    def forward(ctx, specs, weights, ema_embedding, label_cfg, *embs):
         ctx.set_materialize_grads(False)
         dev = embs[0].device
         L = _lib.lib()
-        lflags, gen_flags, has_mask = specs[0].label_flags
-        tables = getattr(specs[0], "weight_tables", None)  # precomputed by *_label_weight_tables (off the critical path)
+        labels_list, lflags, gen_flags, has_mask = label_cfg.labels, label_cfg.lflags, label_cfg.gen_flags, label_cfg.has_mask
+        tables = label_cfg.tables  # precomputed by *_label_weight_tables (off the critical path), or None
         ncall = len(specs)
         kmax = max(sp.K for sp in specs)
         with torch.cuda.device(dev):
@@ -497,8 +506,8 @@ def cvppp_loss_section_from_labels(embedding, emds, ema_embedding, labels, label
     if ema_embedding.requires_grad:
         raise NotImplementedError("the EMA operand must be detached (convert_consistency_flip)")
     specs, weights = _section_specs(offsets, nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb)
-    specs[0].label_flags = (_lib.TGT_PADDING | _lib.TGT_MASK_INSIDE, _lib.TGT_PADDING, True)  # gen_affs_ours(padding=True) + its mask
     specs[0].relu = specs[-1].relu = bool(relu_pred)
-    specs[0].weight_tables = None if weight_tables is None else list(weight_tables)
-    loss, pred, losses = _LabelsSection.apply(specs, weights, ema_embedding, [labels] + list(label_downs), embedding, *emds)
+    label_cfg = _LabelCfg([labels] + list(label_downs), _lib.TGT_PADDING | _lib.TGT_MASK_INSIDE, _lib.TGT_PADDING, True,
+                          None if weight_tables is None else list(weight_tables))  # gen_affs_ours(padding=True) + its mask
+    loss, pred, losses = _LabelsSection.apply(specs, weights, ema_embedding, label_cfg, embedding, *emds)
     return loss, pred, _section_parts(losses, weights, self_emb, cross_emb)
