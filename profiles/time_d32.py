@@ -16,6 +16,8 @@ offsets = pkg.multi_offset([1, 3, 5, 9, 11], 4)
 K = len(offsets)
 e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 555)
 E, T, Wt, M = (torch.from_numpy(x).to(dev) for x in (e, t, w, m))
+if os.environ.get("F16", "0") == "1":  # f16 storage of the embedding / its gradient, f32 accumulation
+    E = E.half()
 desc = op.make_desc(op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX), E)
 affs = torch.empty(B, K, H, W, device=dev); G = torch.empty(B, K, H, W, device=dev); lossv = torch.empty(1 + K, device=dev)
 wsb = L.pea_workspace_bytes(ctypes.byref(desc)); work = torch.empty(max(wsb, 4) // 4, device=dev)
@@ -39,4 +41,4 @@ for name, fn in fns.items():
         for _ in range(20): assert fn() == 0
         b.record(); b.synchronize()
         ts.append(a.elapsed_time(b) / 20 * 1e3)
-    print("D=%d %s min %.1f us" % (D, name, min(ts)), flush=True)
+    print("D=%d%s %s min %.1f us" % (D, " f16" if E.dtype == torch.float16 else "", name, min(ts)), flush=True)
