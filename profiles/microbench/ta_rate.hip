@@ -45,6 +45,11 @@ __global__ __launch_bounds__(1024) void k(const float* __restrict__ src, float* 
       const int row = lane >> 5, x = lane & 31;
       const f2 v = *(const f2*)(base + (((step * 2 + row) * 544 + 2 * x) & mask));
       acc += v.x + v.y;
+    } else if (MODE == 8) {  // dwordx2 at an ODD pixel offset (4-byte aligned only): the shifted gathers of a 2-px-per-lane kernel
+      const int row = lane >> 5, x = lane & 31;
+      f2 v;
+      __builtin_memcpy(&v, base + ((((step * 2 + row) * 544 + 2 * x) & mask) + 27), 8);
+      acc += v.x + v.y;
     } else {                 // dwordx4, lane = 8s+q within 32, two rows: 8-lane runs per plane
       const int q = lane & 7, s = (lane >> 3) & 3, row = lane >> 5;
       const f4 v = *(const f4*)(base + s * plane + ((((step * 2 + row) * 8 + q) * 4) & pmask));
@@ -85,5 +90,6 @@ int main() {
   run<4>(src, out, 16, "dwordx4, lane = 16s+q (4 planes, 16-lane runs)");
   run<7>(src, out, 16, "dwordx4, lane = 32r+8s+q (8-lane runs)");
   run<6>(src, out, 8, "dwordx2, 2 rows x 32 lanes");
+  run<8>(src, out, 8, "dwordx2, 2 rows x 32 lanes, odd pixel offset");
   return 0;
 }
