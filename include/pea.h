@@ -131,6 +131,22 @@ int pea_affinity_fwd(const PeaDesc *desc, const void *e, const void *e_other, co
 int pea_affinity_bwd(const PeaDesc *desc, const void *e, const void *e_other, const float *g, const float *dloss,
                      void *de, void *de_other, void *stream);
 
+/* The same two calls with the 1 / norm plane of e between them (new entry points; the two above forward to these with
+ * NULL).  inv_norm [B,Z,Y,X] f32 = 1 / max(|e(p)|_2, eps), NEGATED where |e(p)| < eps (the clamp branch of F.normalize,
+ * whose Jacobian is I / eps): four bytes per pixel that the forward knows anyway (it normalises every pixel it stages)
+ * and that lets the self-loss backward of an axis-aligned in-plane stencil (every offset along y or along x only: the
+ * multi_offset(neighbor=4) tables of scripts_cvppp/utils/affinity_ours.py:4-15) run as the LDS-DMA cross kernel
+ * (csrc/pea_xdma.h): the channels go through LDS two at a time and sum_i g_i ehat(q_i) needs 1 / |e(q_i)| before the
+ * first chunk.  pea_affinity_bwd_ex with inv_norm == NULL, a second operand, f16 storage, D != 16 or any other stencil
+ * takes the kernels of pea_affinity_bwd -- same result either way.  pea_inv_norm computes the plane alone (for callers
+ * that hold e but did not run the forward: the vjp of a foreign criterion). */
+int pea_affinity_fwd_ex(const PeaDesc *desc, const void *e, const void *e_other, const float *target,
+                        const float *weight, const uint8_t *mask, float *affs, float *g_out, float *inv_norm_out,
+                        float *loss_out, void *workspace, size_t workspace_bytes, void *stream);
+int pea_affinity_bwd_ex(const PeaDesc *desc, const void *e, const void *e_other, const float *g, const float *inv_norm,
+                        const float *dloss, void *de, void *de_other, void *stream);
+int pea_inv_norm(const PeaDesc *desc, const void *e, float *inv_norm_out, void *stream);
+
 /* The backward of the full-resolution pair of the training loop in one launch: g is what pea_affinity_fwd wrote for the self
  * loss (e_other = NULL), g_cross what it wrote for the detached-EMA cross loss of the same e (e_other = ema); the stencil
  * and geometry are desc's (lambda and the normaliser are already inside g / g_cross).

@@ -180,7 +180,7 @@ class FusedAffinityMSE(torch.autograd.Function):
             loss_vec = torch.empty(1 + spec.K, dtype=torch.float32, device=e_c.device)
             wsb = L.pea_workspace_bytes(ctypes.byref(d))
             work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=e_c.device)
-            de_unit = g = None
+            de_unit = g = inv = None
             if want_e and not want_o and _fused_enabled():
                 de_unit = torch.empty_like(e_c)
                 rc = L.pea_affinity_fwd_bwd(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(target), _ptr(weight), _ptr(mask),
@@ -192,21 +192,25 @@ class FusedAffinityMSE(torch.autograd.Function):
             if de_unit is None:
                 # g = d loss / d affs is all the backward needs besides the embeddings; skip it when nothing trains
                 g = torch.empty(kshape, dtype=torch.float32, device=e_c.device) if (want_e or want_o) else None
-                _lib.check(L.pea_affinity_fwd(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(target), _ptr(weight), _ptr(mask),
-                                              _ptr(affs), _ptr(g), _ptr(loss_vec), _ptr(work), wsb, _stream()), "pea_affinity_fwd")
+                # 1 / norm of e, 4 bytes per pixel: what the cross backward (self loss, axis-aligned stencil) stages next to e
+                inv = (torch.empty((e_c.shape[0],) + tuple(e_c.shape[2:]), dtype=torch.float32, device=e_c.device)
+                       if (want_e and o_c is None) else None)
+                _lib.check(L.pea_affinity_fwd_ex(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(target), _ptr(weight), _ptr(mask),
+                                                 _ptr(affs), _ptr(g), _ptr(inv), _ptr(loss_vec), _ptr(work), wsb, _stream()),
+                           "pea_affinity_fwd_ex")
         ctx.spec, ctx.desc = spec, d
         ctx.has_other = o_c is not None
         ctx.de_unit = de_unit
         # fused path: keep the operands (references, no copies) so that a SECOND backward over a retained graph
         # can rebuild g the two-launch way after the first one has scaled de_unit in place
-        ctx.save_for_backward(e_c, o_c, g, *((target, weight, mask) if de_unit is not None else (None, None, None)))
+        ctx.save_for_backward(e_c, o_c, g, inv, *((target, weight, mask) if de_unit is not None else (None, None, None)))
         loss, per_offset = loss_vec[0], loss_vec[1:]  # views of a buffer that is not itself returned
         ctx.mark_non_differentiable(affs, per_offset)
         return loss, affs, per_offset
 
     @staticmethod
     def backward(ctx, dloss, _daffs, _dvec):
-        e_c, o_c, g, target, weight, mask = ctx.saved_tensors
+        e_c, o_c, g, inv, target, weight, mask = ctx.saved_tensors
         want_e = ctx.needs_input_grad[0]
         want_o = ctx.has_other and ctx.needs_input_grad[1]
         if not (want_e or want_o) or dloss is None:
@@ -229,8 +233,8 @@ class FusedAffinityMSE(torch.autograd.Function):
                                               None, _ptr(g), _ptr(loss_vec), _ptr(work), wsb, _stream()), "pea_affinity_fwd (rebuild g)")
             de = torch.empty_like(e_c) if want_e else None
             de_o = torch.empty_like(o_c) if want_o else None
-            _lib.check(L.pea_affinity_bwd(ctypes.byref(ctx.desc), _ptr(e_c), _ptr(o_c), _ptr(g), _ptr(dl), _ptr(de),
-                                          _ptr(de_o), _stream()), "pea_affinity_bwd")
+            _lib.check(L.pea_affinity_bwd_ex(ctypes.byref(ctx.desc), _ptr(e_c), _ptr(o_c), _ptr(g), _ptr(inv), _ptr(dl), _ptr(de),
+                                             _ptr(de_o), _stream()), "pea_affinity_bwd_ex")
         return de, de_o, None, None, None, None
 
 

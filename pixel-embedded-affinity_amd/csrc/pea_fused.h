@@ -218,7 +218,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fused_tiled(const KParams P, cons
   if (tiny) proj = 0.f;  // clamp_min branch of F.normalize: d ehat / d e = I / eps
   const float sc = dl * invp;
 #pragma unroll
-  for (int c = 0; c < D_T; ++c) bs_emb<T>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
+  for (int c = 0; c < D_T; ++c) bs_emb<T, true>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
 
   lds_barrier();
   if (threadIdx.x < P.K) {

@@ -222,10 +222,10 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fused_labels(con
 #pragma unroll
     for (int c = 0; c < D_T; ++c) prev[c] = bl_emb<T>(dB, pe, ezo + c * ecs);
 #pragma unroll
-    for (int c = 0; c < D_T; ++c) bs_emb<T>(dB, prev[c] + (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
+    for (int c = 0; c < D_T; ++c) bs_emb<T, true>(dB, prev[c] + (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
   } else {
 #pragma unroll
-    for (int c = 0; c < D_T; ++c) bs_emb<T>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
+    for (int c = 0; c < D_T; ++c) bs_emb<T, true>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
   }
 
   lds_barrier();
@@ -546,10 +546,10 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fused_labels_dua
 #pragma unroll
     for (int c = 0; c < D_T; ++c) prev[c] = bl_emb<T>(dB, pe, ezo + c * ecs);
 #pragma unroll
-    for (int c = 0; c < D_T; ++c) bs_emb<T>(dB, prev[c] + (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
+    for (int c = 0; c < D_T; ++c) bs_emb<T, true>(dB, prev[c] + (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
   } else {
 #pragma unroll
-    for (int c = 0; c < D_T; ++c) bs_emb<T>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
+    for (int c = 0; c < D_T; ++c) bs_emb<T, true>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
   }
 
   lds_barrier();

@@ -28,6 +28,7 @@
 #include "pea_fused_labels.h"
 #include "pea_head.h"
 #include "pea_chunked.h"
+#include "pea_xdma.h"
 
 using namespace pea;
 
@@ -217,11 +218,41 @@ size_t fwd_partials(const KParams& P) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 1 / norm plane (pea_xdma.h): written by the tiled D = 16 forward while it stages; by this kernel otherwise
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+void launch_inv_norm(const KParams& P, const T* e, float* inv, hipStream_t s) {
+  hipLaunchKernelGGL(k_inv_norm<T>, dim3((unsigned)(P.tiles_per_xcd * kXcd)), dim3(kBlock), 0, s, P, e, inv);
+}
+
+// the cross backward (self loss, f32 storage, axis-aligned in-plane stencil): needs the 1 / norm plane
+constexpr int kXdmaTH = 16, kXdmaTW = 32, kXdmaPSU = 51;
+template <int D_T>
+bool try_bwd_xdma(const KParams& P, const float* x, const float* inv, const float* g, const float* dl, float* dx, hipStream_t s) {
+  if (!inv || env_int("PEA_BWD_XDMA", 1) == 0) return false;
+  if (misaligned(x, 16) || misaligned(inv, 16) || misaligned(g, 4) || misaligned(dx, 4)) return false;
+  XParams C;
+  size_t lds;
+  if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds)) return false;
+  const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  if (P.border == PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_bwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSU, false>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, dx);
+  } else {
+    constexpr auto kern = k_bwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSU, true>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, dx);
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward dispatch
 // ------------------------------------------------------------------------------------------------
 template <typename T, int D_T, bool TRAIN, bool SELF, int CI>
 void launch_fwd_cfg(const KParams& P, const TParams& Q, const T* e, const T* eo, const float* t, const float* w,
-                    const uint8_t* m, float* affs, float* gout, float* partials, hipStream_t s) {
+                    const uint8_t* m, float* affs, float* gout, float* partials, float* inv_out, hipStream_t s) {
   constexpr TileCfg c = fwd_cfg<D_T>(CI);
   constexpr int NT = c.TH * c.TW;
   const size_t lds = Lds<D_T, c.PLQ>::kBytes + (TRAIN ? (size_t)(NT / 64) * P.K * sizeof(float) : 0);
@@ -229,11 +260,11 @@ void launch_fwd_cfg(const KParams& P, const TParams& Q, const T* e, const T* eo,
   if (P.border == PEA_BORDER_CIRCULAR) {
     constexpr auto kern = k_fwd_tiled<T, D_T, c.TH, c.TW, c.PLQ, false, TRAIN, SELF>;
     allow_lds<kern>(lds);
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials, inv_out);
   } else {
     constexpr auto kern = k_fwd_tiled<T, D_T, c.TH, c.TW, c.PLQ, true, TRAIN, SELF>;
     allow_lds<kern>(lds);
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials, inv_out);
   }
 }
 
@@ -243,23 +274,23 @@ constexpr TileCfg kFwdVO = {16, 32, 1041};  // 16x32 tile, dot products laid ove
 
 template <typename T, int D_T, bool TRAIN, bool SELF, bool OVL>
 void launch_fwd_v(const KParams& P, const TParams& Q, size_t lds, const T* e, const T* eo, const float* t, const float* w,
-                  const uint8_t* m, float* affs, float* gout, float* partials, hipStream_t s) {
+                  const uint8_t* m, float* affs, float* gout, float* partials, float* inv_out, hipStream_t s) {
   constexpr TileCfg c = fwdv_cfg<D_T>(OVL);
   const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(c.TH * c.TW);
   if (P.border == PEA_BORDER_CIRCULAR) {
     constexpr auto kern = k_fwd_tiled_v<T, D_T, c.TH, c.TW, c.PLQ, OVL, false, TRAIN, SELF>;
     allow_lds<kern>(lds);
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials, inv_out);
   } else {
     constexpr auto kern = k_fwd_tiled_v<T, D_T, c.TH, c.TW, c.PLQ, OVL, true, TRAIN, SELF>;
     allow_lds<kern>(lds);
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials, inv_out);
   }
 }
 
 template <typename T, int D_T, bool TRAIN>
 bool try_fwd_v(const KParams& P, const T* e, const T* eo, const float* t, const float* w, const uint8_t* m, float* affs,
-               float* gout, float* partials, hipStream_t s, int* nparts) {
+               float* gout, float* partials, float* inv_out, hipStream_t s, int* nparts) {
   if (env_int("PEA_FWD_V", 1) == 0) return false;
   if (P.K > kKV || P.X % 4) return false;
   if (misaligned(t, 16) || misaligned(w, 16) || misaligned(affs, 16) || misaligned(gout, 16) || misaligned(m, 4)) return false;
@@ -275,11 +306,11 @@ bool try_fwd_v(const KParams& P, const T* e, const T* eo, const float* t, const 
   if (!plan_tiles(P, c, false, &Q) || Q.n_near > kKV || Q.n_far > kFV) return false;
   const bool self = eo == e;
   if (ovl) {
-    if (self) launch_fwd_v<T, D_T, TRAIN, true, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
-    else launch_fwd_v<T, D_T, TRAIN, false, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
+    if (self) launch_fwd_v<T, D_T, TRAIN, true, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, inv_out, s);
+    else launch_fwd_v<T, D_T, TRAIN, false, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, inv_out, s);
   } else {
-    if (self) launch_fwd_v<T, D_T, TRAIN, true, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
-    else launch_fwd_v<T, D_T, TRAIN, false, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, s);
+    if (self) launch_fwd_v<T, D_T, TRAIN, true, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, inv_out, s);
+    else launch_fwd_v<T, D_T, TRAIN, false, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, inv_out, s);
   }
   *nparts = Q.ntiles;
   return true;
@@ -288,7 +319,7 @@ bool try_fwd_v(const KParams& P, const T* e, const T* eo, const float* t, const 
 // returns true if a tiled kernel was launched (nparts = number of partial rows written)
 template <typename T, int D_T, bool TRAIN>
 bool try_fwd_tiled(const KParams& P, const T* e, const T* eo, const float* t, const float* w, const uint8_t* m, float* affs,
-                   float* gout, float* partials, hipStream_t s, int* nparts) {
+                   float* gout, float* partials, float* inv_out, hipStream_t s, int* nparts) {
   const int ci = env_int("PEA_FWD_CFG", kFwdDefault);
   if (ci < 0 || ci >= kNumFwdCfg) return false;
   TParams Q;
@@ -296,8 +327,8 @@ bool try_fwd_tiled(const KParams& P, const T* e, const T* eo, const float* t, co
   const bool self = (eo == e);
 #define PEA_FWD_CASE(CI)                                                                             \
   case CI:                                                                                           \
-    if (self) launch_fwd_cfg<T, D_T, TRAIN, true, CI>(P, Q, e, eo, t, w, m, affs, gout, partials, s); \
-    else launch_fwd_cfg<T, D_T, TRAIN, false, CI>(P, Q, e, eo, t, w, m, affs, gout, partials, s);     \
+    if (self) launch_fwd_cfg<T, D_T, TRAIN, true, CI>(P, Q, e, eo, t, w, m, affs, gout, partials, inv_out, s); \
+    else launch_fwd_cfg<T, D_T, TRAIN, false, CI>(P, Q, e, eo, t, w, m, affs, gout, partials, inv_out, s);     \
     break;
   switch (ci) { PEA_FWD_CASE(0) PEA_FWD_CASE(1) PEA_FWD_CASE(2) default: return false; }
 #undef PEA_FWD_CASE
@@ -346,21 +377,26 @@ bool try_fwd_chunked(const KParams& P, const T* e, const T* eo, const float* t, 
 
 template <typename T, bool TRAIN>
 int launch_fwd(const KParams& P, const void* e, const void* eo, const float* t, const float* w, const uint8_t* m,
-               float* affs, float* gout, float* partials, hipStream_t s, int* nparts) {
+               float* affs, float* gout, float* partials, float* inv_out, hipStream_t s, int* nparts) {
   const T* ep = (const T*)e;
   const T* op = eo ? (const T*)eo : ep;
+  if (inv_out && (eo != nullptr && eo != e)) inv_out = nullptr;  // self loss only (caller runs k_inv_norm otherwise)
   if (env_int("PEA_FORCE_DIRECT", 0) == 0) {
     bool done = false;
-    if (P.D == 16 && TRAIN) done = try_fwd_v<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
-    if (!done && P.D == 16) done = try_fwd_tiled<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
+    if (P.D == 16 && TRAIN) done = try_fwd_v<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, inv_out, s, nparts);
+    if (!done && P.D == 16) done = try_fwd_tiled<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, inv_out, s, nparts);
+    if (done && P.D == 16) return hip_rc();
+    if (inv_out) launch_inv_norm<T>(P, ep, inv_out, s);  // the kernels below do not write the plane themselves
     // 64 B of LDS per region pixel: two workgroups per CU.  Self loss / inference only: with a second operand the
     // 128-VGPR budget of that occupancy spills (and see pea_chunked.h on spill stores), so EMA calls keep the one-region kernels
     if (P.D == 32 && env_int("PEA_FWD_CHUNKED32", 1) != 0)
       done = try_fwd_chunked<T, 32, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
-    if (!done && P.D == 32 && TRAIN) done = try_fwd_v<T, 32, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
-    if (!done && P.D == 32) done = try_fwd_tiled<T, 32, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
+    if (!done && P.D == 32 && TRAIN) done = try_fwd_v<T, 32, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, nullptr, s, nparts);
+    if (!done && P.D == 32) done = try_fwd_tiled<T, 32, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, nullptr, s, nparts);
     if (P.D == 64) done = try_fwd_chunked<T, 64, 32, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
     if (done) return hip_rc();
+  } else if (inv_out) {
+    launch_inv_norm<T>(P, ep, inv_out, s);
   }
   const size_t lds = TRAIN ? (size_t)P.K * kBlock * sizeof(float) : 0;
   const dim3 g((unsigned)(P.tiles_per_xcd * kXcd)), blk(kBlock);
@@ -683,47 +719,74 @@ int pea_affinity_infer(const PeaDesc* desc, const void* e, const void* e_other, 
   hipStream_t s = (hipStream_t)stream;
   int nparts = 0;
   return desc->dtype == PEA_F16
-             ? launch_fwd<__half, false>(P, e, e_other, nullptr, nullptr, nullptr, affs, nullptr, nullptr, s, &nparts)
-             : launch_fwd<float, false>(P, e, e_other, nullptr, nullptr, nullptr, affs, nullptr, nullptr, s, &nparts);
+             ? launch_fwd<__half, false>(P, e, e_other, nullptr, nullptr, nullptr, affs, nullptr, nullptr, nullptr, s, &nparts)
+             : launch_fwd<float, false>(P, e, e_other, nullptr, nullptr, nullptr, affs, nullptr, nullptr, nullptr, s, &nparts);
 }
 
-int pea_affinity_fwd(const PeaDesc* desc, const void* e, const void* e_other, const float* target,
-                     const float* weight, const uint8_t* mask, float* affs, float* g_out, float* loss_out,
-                     void* workspace, size_t workspace_bytes, void* stream) {
+int pea_affinity_fwd_ex(const PeaDesc* desc, const void* e, const void* e_other, const float* target,
+                        const float* weight, const uint8_t* mask, float* affs, float* g_out, float* inv_norm_out,
+                        float* loss_out, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = validate(desc);
   if (rc) return rc;
   if (!e || !target || !weight || !loss_out) return PEA_E_NULL;
   const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
   if (misaligned(e, es) || misaligned(e_other, es) || misaligned(affs, 4) || misaligned(g_out, 4) ||
-      misaligned(target, 4) || misaligned(weight, 4) || misaligned(loss_out, 4) || misaligned(workspace, 4))
+      misaligned(target, 4) || misaligned(weight, 4) || misaligned(loss_out, 4) || misaligned(workspace, 4) ||
+      misaligned(inv_norm_out, 4))
     return PEA_E_ALIGN;
   const KParams P = make_params(desc);
   if (!workspace || workspace_bytes < fwd_partials(P) * P.K * sizeof(float)) return PEA_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   float* partials = (float*)workspace;
   int nparts = 0;
+  const bool self = !e_other || e_other == e;
   rc = desc->dtype == PEA_F16
-           ? launch_fwd<__half, true>(P, e, e_other, target, weight, mask, affs, g_out, partials, s, &nparts)
-           : launch_fwd<float, true>(P, e, e_other, target, weight, mask, affs, g_out, partials, s, &nparts);
+           ? launch_fwd<__half, true>(P, e, e_other, target, weight, mask, affs, g_out, partials, self ? inv_norm_out : nullptr, s, &nparts)
+           : launch_fwd<float, true>(P, e, e_other, target, weight, mask, affs, g_out, partials, self ? inv_norm_out : nullptr, s, &nparts);
   if (rc) return rc;
+  if (inv_norm_out && !self) {  // second operand: the staging works on e_other, so the plane of e takes its own launch
+    if (desc->dtype == PEA_F16) launch_inv_norm<__half>(P, (const __half*)e, inv_norm_out, s);
+    else launch_inv_norm<float>(P, (const float*)e, inv_norm_out, s);
+  }
   hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P, partials, nparts, loss_out);
   return hip_rc();
 }
 
-int pea_affinity_bwd(const PeaDesc* desc, const void* e, const void* e_other, const float* g, const float* dloss,
-                     void* de, void* de_other, void* stream) {
+int pea_affinity_fwd(const PeaDesc* desc, const void* e, const void* e_other, const float* target,
+                     const float* weight, const uint8_t* mask, float* affs, float* g_out, float* loss_out,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+  return pea_affinity_fwd_ex(desc, e, e_other, target, weight, mask, affs, g_out, nullptr, loss_out, workspace, workspace_bytes, stream);
+}
+
+int pea_inv_norm(const PeaDesc* desc, const void* e, float* inv_norm_out, void* stream) {
+  const int rc = validate(desc);
+  if (rc) return rc;
+  if (!e || !inv_norm_out) return PEA_E_NULL;
+  if (misaligned(e, desc->dtype == PEA_F16 ? 2 : 4) || misaligned(inv_norm_out, 4)) return PEA_E_ALIGN;
+  const KParams P = make_params(desc);
+  if (desc->dtype == PEA_F16) launch_inv_norm<__half>(P, (const __half*)e, inv_norm_out, (hipStream_t)stream);
+  else launch_inv_norm<float>(P, (const float*)e, inv_norm_out, (hipStream_t)stream);
+  return hip_rc();
+}
+
+int pea_affinity_bwd_ex(const PeaDesc* desc, const void* e, const void* e_other, const float* g, const float* inv_norm,
+                        const float* dloss, void* de, void* de_other, void* stream) {
   int rc = validate(desc);
   if (rc) return rc;
   if (!e || !g || (!de && !de_other)) return PEA_E_NULL;
   if (de_other && !e_other) return PEA_E_NULL;
   const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
   if (misaligned(e, es) || misaligned(e_other, es) || misaligned(de, es) || misaligned(de_other, es) ||
-      misaligned(g, 4) || misaligned(dloss, 4))
+      misaligned(g, 4) || misaligned(dloss, 4) || misaligned(inv_norm, 4))
     return PEA_E_ALIGN;
   const KParams P = make_params(desc);
   hipStream_t s = (hipStream_t)stream;
   const bool h = desc->dtype == PEA_F16;
   if (!e_other) {
+    // self loss: the LDS-DMA cross kernel when the 1 / norm plane came along and the stencil is axis-aligned
+    if (!h && P.D == 16 && env_int("PEA_FORCE_DIRECT", 0) == 0 &&
+        try_bwd_xdma<16>(P, (const float*)e, inv_norm, g, dloss, (float*)de, s))
+      return hip_rc();
     return h ? launch_bwd<__half>(P, 3, e, e, e, g, dloss, de, s) : launch_bwd<float>(P, 3, e, e, e, g, dloss, de, s);
   }
   if (de) {
@@ -734,6 +797,11 @@ int pea_affinity_bwd(const PeaDesc* desc, const void* e, const void* e_other, co
   if (!de_other) return PEA_OK;
   return h ? launch_bwd<__half>(P, 2, e_other, nullptr, e, g, dloss, de_other, s)
            : launch_bwd<float>(P, 2, e_other, nullptr, e, g, dloss, de_other, s);
+}
+
+int pea_affinity_bwd(const PeaDesc* desc, const void* e, const void* e_other, const float* g, const float* dloss,
+                     void* de, void* de_other, void* stream) {
+  return pea_affinity_bwd_ex(desc, e, e_other, g, nullptr, dloss, de, de_other, stream);
 }
 
 int pea_affinity_fwd_bwd(const PeaDesc* desc, const void* e, const void* e_other, const float* target,

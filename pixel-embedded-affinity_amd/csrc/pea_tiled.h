@@ -95,10 +95,13 @@ __device__ __forceinline__ float bl_emb(rsrc_t r, unsigned vo, unsigned so) {
   if (sizeof(T) == 4) return bl32(r, vo, so);
   return __half2float(__builtin_bit_cast(__half, __builtin_amdgcn_raw_buffer_load_b16(r, vo, so, 0)));
 }
-template <typename T>
+// NTL: non-temporal.  The gradient planes are written once and not read again by the kernel that writes them; as plain
+// stores they push the embedding / g lines that the neighbouring tiles are about to re-read out of the XCD's 4 MB L2
+// (measured on the cross backward: 140 us with plain stores, 97 us with nt stores, 136 us with sc1 alone).
+template <typename T, bool NTL = false>
 __device__ __forceinline__ void bs_emb(rsrc_t r, float v, unsigned vo, unsigned so) {
-  if (sizeof(T) == 4) bs32(r, v, vo, so);
-  else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, __float2half(v)), r, vo, so, 0);
+  if (sizeof(T) == 4) bs32<NTL>(r, v, vo, so);
+  else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, __float2half(v)), r, vo, so, NTL ? kAuxNT : 0);
 }
 
 // sum over the 64 lanes, result valid in lane 63: 6 DPP adds (no LDS traffic)
@@ -167,10 +170,13 @@ __device__ __forceinline__ int wrap1(int v, int n, bool& ok) {
   return v;
 }
 
-// stage the normalised region of batch item `eb`, plane byte offset `zo`, into LDS
-template <typename T, int D_T, int PLQ, int NT, bool CROP>
-__device__ __forceinline__ void stage_region(const KParams& P, const TParams& Q, rsrc_t eb, unsigned zo, unsigned cs,
-                                             int y0, int x0, char* __restrict__ lds) {
+// stage the normalised region of batch item `eb`, plane byte offset `zo`, into LDS.
+// WINV (training forward, self loss): the lane that stages one of the tile's OWN pixels also writes its signed 1 / norm
+// (negative where |e| < eps: the clamp branch of F.normalize) to the plane the cross backward (pea_xdma.h) reads;
+// every other lane's store carries an out-of-range offset and is dropped by the bounds check.
+template <typename T, int D_T, int PLQ, int NT, bool CROP, bool WINV>
+__device__ __forceinline__ void stage_region_impl(const KParams& P, const TParams& Q, rsrc_t eb, unsigned zo, unsigned cs,
+                                                  int y0, int x0, char* __restrict__ lds, rsrc_t ib, unsigned izo, int th, int tw) {
   typedef Lds<D_T, PLQ> L;
   int idx = threadIdx.x;
   int r = (int)(((float)idx + 0.5f) * Q.inv_rw);
@@ -189,6 +195,11 @@ __device__ __forceinline__ void stage_region(const KParams& P, const TParams& Q,
       ss = fmaf(v[ch], v[ch], ss);
     }
     const float inv = rnorm(ss, Q.inv_eps);
+    if (WINV) {
+      const int tr = r - Q.hy0, tc = c - Q.hx0;
+      const bool mine = (unsigned)tr < (unsigned)th && (unsigned)tc < (unsigned)tw && y0 + tr < P.Y && x0 + tc < P.X;
+      bs32(ib, ss < P.eps * P.eps ? -inv : inv, mine ? (unsigned)(gy * P.X + gx) * 4u : kOOB, izo);
+    }
     char* dst = lds + idx * 16;
 #pragma unroll
     for (int q = 0; q < L::S; ++q) {
@@ -200,6 +211,11 @@ __device__ __forceinline__ void stage_region(const KParams& P, const TParams& Q,
     c += Q.dc;
     if (c >= Q.RW) { c -= Q.RW; r += 1; }
   }
+}
+template <typename T, int D_T, int PLQ, int NT, bool CROP>
+__device__ __forceinline__ void stage_region(const KParams& P, const TParams& Q, rsrc_t eb, unsigned zo, unsigned cs,
+                                             int y0, int x0, char* __restrict__ lds) {
+  stage_region_impl<T, D_T, PLQ, NT, CROP, false>(P, Q, eb, zo, cs, y0, x0, lds, eb, 0u, 0, 0);
 }
 
 // stage_region for the self-loss backward: every lane first stages ITS OWN tile pixel (keeping the raw channels and
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled(const 
                                                          const T* __restrict__ eo, const float* __restrict__ target,
                                                          const float* __restrict__ weight,
                                                          const uint8_t* __restrict__ mask, float* __restrict__ affs,
-                                                         float* __restrict__ gout, float* __restrict__ partials) {
+                                                         float* __restrict__ gout, float* __restrict__ partials, float* __restrict__ inv_out) {
   typedef Lds<D_T, PLQ> L;
   constexpr int NT = TH * TW, NW = NT / 64;
   constexpr int KN = 8;  // near offsets per chunk (chunk 0 is requested before the staging loads)
@@ -359,7 +375,8 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled(const 
   }
 
   // (2) stage the region
-  stage_region<T, D_T, PLQ, NT, CROP>(P, Q, oB, ezo, ecs, y0, x0, lds);
+  if (SELF && inv_out) stage_region_impl<T, D_T, PLQ, NT, CROP, true>(P, Q, oB, ezo, ecs, y0, x0, lds, mkbuf(inv_out + (size_t)b * S), (unsigned)z * YX * 4u, TH, TW);
+  else stage_region<T, D_T, PLQ, NT, CROP>(P, Q, oB, ezo, ecs, y0, x0, lds);
 
   // (3) the first two far neighbour vectors: in flight across the barrier and the near-offset work
   float fvA[D_T], fvB[D_T];
@@ -483,7 +500,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled_v(cons
                                                            const T* __restrict__ eo, const float* __restrict__ target,
                                                            const float* __restrict__ weight,
                                                            const uint8_t* __restrict__ mask, float* __restrict__ affs,
-                                                           float* __restrict__ gout, float* __restrict__ partials) {
+                                                           float* __restrict__ gout, float* __restrict__ partials, float* __restrict__ inv_out) {
   typedef Lds<D_T, PLQ> L;
   constexpr int NT = TH * TW, TP = NT, QP = TP / 4, NSL = QP / 64;
   constexpr int ITEMS = (kKV * QP + NT - 1) / NT;
@@ -560,7 +577,8 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled_v(cons
   }
 
   // ---- (1) stage the region; (2) first two far vectors in flight across the barrier
-  stage_region<T, D_T, PLQ, NT, CROP>(P, Q, oB, ezo, ecs, y0, x0, lds);
+  if (SELF && inv_out) stage_region_impl<T, D_T, PLQ, NT, CROP, true>(P, Q, oB, ezo, ecs, y0, x0, lds, mkbuf(inv_out + (size_t)b * S), (unsigned)z * YX * 4u, TH, TW);
+  else stage_region<T, D_T, PLQ, NT, CROP>(P, Q, oB, ezo, ecs, y0, x0, lds);
   float fvA[D_T], fvB[D_T];
   bool fokA = false, fokB = false;
 #define PEA_FWDV_LOAD_FAR(fv, fok, k)                                                              \
@@ -842,7 +860,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_bwd_tiled(const 
   if (tiny) proj = 0.f;  // clamp_min branch of F.normalize: d ehat / d e = I / eps
   const float sc = dl * invp;
 #pragma unroll
-  for (int c = 0; c < D_T; ++c) bs_emb<T>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
+  for (int c = 0; c < D_T; ++c) bs_emb<T, true>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
 }
 
 // Self-loss backward AND the detached-EMA cross loss' backward of the same tensor in one launch, two LDS phases (the
@@ -1071,7 +1089,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_bwd_tiled_dual(c
   if (tiny) proj = 0.f;  // clamp_min branch of F.normalize: d ehat / d e = I / eps
   const float sc = invp;  // dloss / dloss2 are already in G
 #pragma unroll
-  for (int c = 0; c < D_T; ++c) bs_emb<T>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
+  for (int c = 0; c < D_T; ++c) bs_emb<T, true>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
 }
 
 
