@@ -214,6 +214,7 @@ size_t fwd_partials(const KParams& P) {
   }
   TParams qv;
   if (plan_tiles(P, kFwdV_decl, false, &qv)) n = std::max(n, (size_t)qv.ntiles);  // (the 16x32 shape is in kFwdCfg)
+  n = std::max(n, (size_t)((P.Y + 15) / 16) * ((P.X + 31) / 32) * P.Z * P.B);      // the LDS-DMA forward's 16x32 tiles
   return n;
 }
 
@@ -244,6 +245,32 @@ bool try_bwd_xdma(const KParams& P, const float* x, const float* inv, const floa
     allow_lds<kern>(lds);
     hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, dx);
   }
+  return true;
+}
+
+// the LDS-DMA forward (self loss / inference, D = 16, f32, axis-aligned in-plane stencil, K <= kXP)
+template <bool TRAIN>
+bool try_fwd_xdma(const KParams& P, const float* e, const float* t, const float* w, const uint8_t* m, float* affs, float* gout,
+                  float* partials, float* inv_out, hipStream_t s, int* nparts) {
+  if (env_int("PEA_FWD_XDMA", 1) == 0) return false;
+  if (misaligned(e, 16) || misaligned(t, 16) || misaligned(w, 16) || misaligned(affs, 16) || misaligned(gout, 16) ||
+      misaligned(m, 4) || misaligned(inv_out, 4))
+    return false;
+  if (TRAIN && ((P.tbs | P.wbs | P.mbs) & 3)) return false;
+  XParams C;
+  size_t lds;
+  if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds, true)) return false;
+  const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  if (P.border == PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_fwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, TRAIN>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, e, t, w, m, affs, gout, partials, inv_out);
+  } else {
+    constexpr auto kern = k_fwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, true, TRAIN>;
+    allow_lds<kern>(lds);
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, e, t, w, m, affs, gout, partials, inv_out);
+  }
+  *nparts = C.ntiles;
   return true;
 }
 
@@ -383,7 +410,11 @@ int launch_fwd(const KParams& P, const void* e, const void* eo, const float* t, 
   if (inv_out && (eo != nullptr && eo != e)) inv_out = nullptr;  // self loss only (caller runs k_inv_norm otherwise)
   if (env_int("PEA_FORCE_DIRECT", 0) == 0) {
     bool done = false;
-    if (P.D == 16 && TRAIN) done = try_fwd_v<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, inv_out, s, nparts);
+    if constexpr (sizeof(T) == 4) {
+      if (P.D == 16 && op == ep)
+        done = try_fwd_xdma<TRAIN>(P, (const float*)ep, t, w, m, affs, gout, partials, inv_out, s, nparts);
+    }
+    if (!done && P.D == 16 && TRAIN) done = try_fwd_v<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, inv_out, s, nparts);
     if (!done && P.D == 16) done = try_fwd_tiled<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, inv_out, s, nparts);
     if (done && P.D == 16) return hip_rc();
     if (inv_out) launch_inv_norm<T>(P, ep, inv_out, s);  // the kernels below do not write the plane themselves

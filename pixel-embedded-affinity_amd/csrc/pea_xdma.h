@@ -18,9 +18,10 @@
 // gathers.  Vector-memory instructions per pixel: 34 x dwordx4 DMA + 20 g loads + 16 stores (k_bwd_tiled: 139 dword).
 //
 // LDS geometry (dword index inside a plane):  VF[r][c] = r * TW + c  (r = 0 is image row y0 - hy0);  H strips after it,
-// HB + ly * SW + coord with SW = 32 or 64: the RIGHT strip at coord [0, SW/2), the LEFT strip at [SW/2, SW), so that a
-// neighbour column c = lx + d outside the tile sits at coord (c & 31) resp. (c & (SW-1)): bank (c mod 32) -- the same
-// bank it would have inside the tile, i.e. a wave whose lanes split between VF and a strip still reads 32 distinct banks.
+// HB + ly * SW + coord with SW = 32 or 64: the RIGHT strip at coord [0, split), the LEFT strip at [split, SW) (a one-sided
+// stencil keeps one of them: split = 0 or SW), so that a neighbour column c = lx + d outside the tile sits at coord
+// (c & 31) resp. (c & (SW-1)): bank (c mod 32) -- the same bank it would have inside the tile, i.e. a wave whose lanes
+// split between VF and a strip still reads 32 distinct banks.
 #pragma once
 #include "pea_tiled.h"
 
@@ -32,15 +33,20 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 struct XParams {
   int hy0, hy1;   // halo rows above / below the tile in VF
-  int SW;         // strip row length: 32 (reach <= 16) or 64
-  int QV, QA;     // quads (4 x-adjacent pixels) in VF; in VF + strips
-  int QW;         // quads per wave = ceil(QA / waves), <= 128
+  int SW;         // strip row length in LDS: 32 or 64 pixels
+  int split;      // strip coordinates < split hold columns x0 + TW + coord (right of the tile), the others x0 - SW + coord
+  int QV, QA;     // quads (4 x-adjacent pixels) in VF; in VF + strips.  Blocks of 64 quads go round the waves.
   int tiles_y, tiles_x, tiles_per_plane, ntiles, tiles_per_xcd;
   int npx, npy;
   int xd[kXP], yd[kXP];    // pixel displacement of the neighbour along x / y  (0 for unused pairs)
   int xm[kXP];             // strip coordinate mask of the x pair: d < 0 ? SW - 1 : 31
   int xgi[kXP], ygi[kXP];  // g channel
   int xgo[kXP], ygo[kXP];  // role A: 0 (g at p); role B: -o (g at p - o)
+  // forward (role A only, offsets in their own order): K <= kXP
+  int fd[kXP];             // displacement along the offset's axis
+  int fax[kXP];            // 1: along x, 0: along y
+  int fm[kXP];             // strip coordinate mask (x offsets)
+  float fgs[kXP];          // 2 * lambda_i / N_i
 };
 
 // inv[b, z, y, x] = 1 / max(|e|, eps), NEGATED where |e| < eps (the clamp branch of F.normalize: d ehat / d e = I / eps)
@@ -64,7 +70,8 @@ __global__ __launch_bounds__(256) void k_inv_norm(const KParams P, const T* __re
 // self-loss backward (both roles, nb == x); f32 storage; X % 4 == 0 and 16-byte aligned planes (host-checked)
 // LDS: six planes of PS = PSU * 256 bytes: buffer b in {0,1,2}, channel j of the chunk at (2b + j) * PS; the 1 / norm
 // plane starts out in plane 4 (buffer 2 is first filled after the coefficients are done).
-template <int D_T, int TH, int TW, int PSU, bool CROP, int AUXS = 0>
+// AUXS: cache policy of the gradient stores (non-temporal: they must not push the halo lines out of the L2, pea_tiled.h bs_emb)
+template <int D_T, int TH, int TW, int PSU, bool CROP, int AUXS = kAuxNT>
 __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const XParams C, const float* __restrict__ xt,
                                                          const float* __restrict__ invp, const float* __restrict__ gin,
                                                          const float* __restrict__ dloss, float* __restrict__ dx) {
@@ -94,13 +101,12 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   const unsigned po4 = (unsigned)(py * P.X + px) * 4u;
   const unsigned pe = live ? po4 : kOOB;
 
-  // ---- the two quads this lane moves per plane (wave w owns quads [w * QW, (w+1) * QW)): global byte offset
+  // ---- the (up to) two quads this lane moves per plane: blocks of 64 quads go round the waves (block s * NW + wave)
   unsigned vo[2];
   bool act[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int qw = s * 64 + lane;
-    const int q = wave * C.QW + qw;
+    const int q = (s * (NT / 64) + wave) * 64 + lane;
     int gy, gx;
     if (q < C.QV) {
       gy = y0 - C.hy0 + (q >> 3);
@@ -110,15 +116,15 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       const int sh = C.SW == 64 ? 4 : 3;  // quads per strip row: 16 / 8
       const int cc = 4 * (k & ((1 << sh) - 1));
       gy = y0 + (k >> sh);
-      gx = cc < (C.SW >> 1) ? x0 + TW + cc : x0 - C.SW + cc;  // right strip first, then the left one
+      gx = cc < C.split ? x0 + TW + cc : x0 - C.SW + cc;
     }
-    act[s] = qw < C.QW && q < C.QA;
+    act[s] = q < C.QA;
     bool oky, okx;
     gy = wrap1<CROP>(gy, P.Y, oky);
     gx = wrap1<CROP>(gx, P.X, okx);
     vo[s] = (oky && okx) ? (unsigned)(gy * P.X + gx) * 4u : kOOB;
   }
-  const int wbase = wave * C.QW * 16;  // this wave's byte offset inside a plane
+  const int wbase = wave * 1024;  // this wave's first block inside a plane; its second one is NW KiB further
   // DMA instructions this wave issues per chunk (a slot without a live lane is skipped): what `vmcnt` has to count
   const int npc = 2 * ((__builtin_amdgcn_ballot_w64(act[0]) != 0) + (__builtin_amdgcn_ballot_w64(act[1]) != 0));
   // wait until only the youngest chunk's DMA may still be in flight, then the workgroup barrier
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
 #define PEA_XDMA(rsrc, plane_byte, so)                                                                              \
   {                                                                                                                 \
     if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, 0);        \
-    if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase + 1024), 16, vo[1], so, 0, 0); \
+    if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase + (NT / 64) * 1024), 16, vo[1], so, 0, 0); \
   }
   PEA_XDMA(iB, 4 * PS, ezo)
   PEA_XDMA(xB, 0, ezo)
@@ -240,17 +246,258 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// forward (self loss / inference), same staging: role A only, so the cross is one-sided (CVPPP: 27 rows up, one strip).
+// The channels arrive RAW, two per chunk; every lane accumulates, per offset, the raw dot product with its own pixel
+// and the neighbour's sum of squares (packed: the two channels of the chunk side by side), and normalises at the end:
+// <ehat(p), ehat(q)> = <e(p), e(q)> / (|e(p)| |e(q)|).  The lane's own 1 / norm goes to the plane the backward stages.
+// Epilogue as k_fwd_tiled_v: the K dot products are parked in LDS as [offset][tile pixel] (over the dead ring) and walked
+// four x-adjacent pixels per lane, so target / weight / affs / g are dwordx4 and the four masks one dword.
+// Needs K <= kXP, X % 4 == 0, 16-byte aligned planes.
+// ------------------------------------------------------------------------------------------------------------------
+template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN>
+__global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const XParams C, const float* __restrict__ e,
+                                                         const float* __restrict__ target, const float* __restrict__ weight,
+                                                         const uint8_t* __restrict__ mask, float* __restrict__ affs,
+                                                         float* __restrict__ gout, float* __restrict__ partials,
+                                                         float* __restrict__ inv_out) {
+  constexpr int NT = TH * TW, PS = PSU * 256, NP = D_T / 2, TP = NT, QP = TP / 4, NSL = QP / 64;
+  constexpr int ITEMS = (kXP * QP + NT - 1) / NT;
+  static_assert(TW == 32 && D_T % 2 == 0 && QP % 64 == 0, "lane mapping / channel pairs");
+  static_assert(kXP * TP * 4 + kXP * NSL * 4 <= 6 * PS, "the parked dot products fit the ring");
+  extern __shared__ f4 lds4[];
+  char* lds = (char*)lds4;
+  float* sA = (float*)lds;                          // [K][TP] dot products, laid over the ring once it is dead
+  float* s_part = (float*)(lds + kXP * TP * 4);     // [K][NSL]
+  const int bid = blockIdx.x;
+  const int tile = (bid % kXcd) * C.tiles_per_xcd + bid / kXcd;
+  if (tile >= C.ntiles) return;
+  const int plane = tile / C.tiles_per_plane;
+  const int rem = tile - plane * C.tiles_per_plane;
+  const int ty = rem / C.tiles_x;
+  const int y0 = ty * TH, x0 = (rem - ty * C.tiles_x) * TW;
+  const int b = plane / P.Z, z = plane - b * P.Z;
+  const size_t S = (size_t)P.S;
+  const unsigned YX = (unsigned)(P.Y * P.X);
+  const rsrc_t xB = mkbuf(e + (size_t)b * D_T * S);
+  const rsrc_t aB = mkbuf(affs ? affs + (size_t)b * P.K * S : nullptr), gB = mkbuf(gout ? gout + (size_t)b * P.K * S : nullptr);
+  const rsrc_t tB = mkbuf(TRAIN ? target + (size_t)b * P.tbs : nullptr), wB = mkbuf(TRAIN ? weight + (size_t)b * P.wbs : nullptr);
+  const rsrc_t mB = mkbuf(mask ? mask + (size_t)b * P.mbs : nullptr);
+  const rsrc_t iB = mkbuf(inv_out ? inv_out + (size_t)b * S : nullptr);
+  const unsigned ecs = (unsigned)P.S * 4u, ezo = (unsigned)z * YX * 4u;
+  const bool has_a = affs != nullptr, has_g = gout != nullptr, has_m = mask != nullptr;
+  const bool relu = P.flags & PEA_FLAG_RELU_AFFS;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+
+  // ---- (0) the epilogue's operands: item = (offset, quad of 4 x-adjacent tile pixels); requested first
+  bool ion[ITEMS];
+  unsigned ivo[ITEMS];
+  int iqd[ITEMS], igy[ITEMS], igx[ITEMS], isl[ITEMS];
+  f4 t4[ITEMS], w4[ITEMS];
+  unsigned m4[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int tt = it * NT + (int)threadIdx.x;
+    const int sl = __builtin_amdgcn_readfirstlane(tt / QP);
+    ion[it] = sl < P.K;
+    isl[it] = min(sl, P.K - 1);
+    const int qd = tt - (tt / QP) * QP;
+    iqd[it] = qd;
+    const int l4 = qd * 4;
+    igy[it] = y0 + l4 / TW;
+    igx[it] = x0 + l4 % TW;
+    const bool lv = ion[it] && igy[it] < P.Y && igx[it] < P.X;  // X % 4 == 0: a quad is inside or outside as a whole
+    ivo[it] = lv ? (unsigned)(igy[it] * P.X + igx[it]) * 4u : kOOB;
+    if (TRAIN) {
+      const unsigned so = ezo + (unsigned)isl[it] * ecs;
+      t4[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(tB, ivo[it], so, kAuxNT));
+      w4[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wB, ivo[it], so, kAuxNT));
+      m4[it] = has_m ? __builtin_amdgcn_raw_buffer_load_b32(mB, lv ? ivo[it] >> 2 : kOOB, (ezo >> 2) + (unsigned)isl[it] * (unsigned)P.S, kAuxNT)
+                     : 0x01010101u;
+    }
+  }
+
+  const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
+  const int py = y0 + ly, px = x0 + lx;
+  const bool live = py < P.Y && px < P.X;
+  const unsigned pe = live ? (unsigned)(py * P.X + px) * 4u : kOOB;
+
+  // ---- the (up to) two quads this lane moves per plane
+  unsigned vo[2];
+  bool act[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int q = (s * (NT / 64) + wave) * 64 + lane;
+    int gy, gx;
+    if (q < C.QV) {
+      gy = y0 - C.hy0 + (q >> 3);
+      gx = x0 + 4 * (q & 7);
+    } else {
+      const int k = q - C.QV;
+      const int sh = C.SW == 64 ? 4 : 3;
+      const int cc = 4 * (k & ((1 << sh) - 1));
+      gy = y0 + (k >> sh);
+      gx = cc < C.split ? x0 + TW + cc : x0 - C.SW + cc;
+    }
+    act[s] = q < C.QA;
+    bool oky, okx;
+    gy = wrap1<CROP>(gy, P.Y, oky);
+    gx = wrap1<CROP>(gx, P.X, okx);
+    vo[s] = (oky && okx) ? (unsigned)(gy * P.X + gx) * 4u : kOOB;
+  }
+  const int wbase = wave * 1024;
+  const int npc = 2 * ((__builtin_amdgcn_ballot_w64(act[0]) != 0) + (__builtin_amdgcn_ballot_w64(act[1]) != 0));
+#define PEA_XDMA(plane_byte, so)                                                                                    \
+  {                                                                                                                 \
+    if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, 0);        \
+    if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (plane_byte) + wbase + (NT / 64) * 1024), 16, vo[1], so, 0, 0); \
+  }
+#define PEA_XWAIT1()                                                                             \
+  {                                                                                              \
+    if (npc == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
+    else if (npc == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                \
+  }
+  PEA_XDMA(0, ezo)
+  PEA_XDMA(PS, ezo + ecs)
+  if (NP > 1) {
+    PEA_XDMA(2 * PS, ezo + 2u * ecs)
+    PEA_XDMA(3 * PS, ezo + 3u * ecs)
+  }
+
+  // ---- LDS slot of every offset's neighbour
+  int an[kXP];
+  const int vown = ((C.hy0 + ly) * TW + lx) * 4;
+  const int hrow = (C.QV * 4 + ly * C.SW) * 4;
+#pragma unroll
+  for (int k = 0; k < kXP; ++k) {
+    const int d = C.fd[k], c = lx + d;
+    const int a_x = (unsigned)c < (unsigned)TW ? vown + d * 4 : hrow + (c & C.fm[k]) * 4;
+    an[k] = C.fax[k] ? a_x : vown + d * TW * 4;  // unused offsets: d = 0, the own slot
+  }
+  if (NP > 1) PEA_XWAIT1()
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (NP > 2) {
+    PEA_XDMA(4 * PS, ezo + 4u * ecs)
+    PEA_XDMA(5 * PS, ezo + 5u * ecs)
+  }
+
+  f2 dot[kXP], ssq[kXP], oss = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < kXP; ++k) { dot[k] = (f2){0.f, 0.f}; ssq[k] = (f2){0.f, 0.f}; }
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int bo = (ps % 3) * 2 * PS;
+    f2 o;
+    o.x = *(const float*)(lds + bo + vown);
+    o.y = *(const float*)(lds + bo + PS + vown);
+    oss = __builtin_elementwise_fma(o, o, oss);
+#pragma unroll
+    for (int k = 0; k < kXP; ++k) {
+      f2 v;
+      v.x = *(const float*)(lds + bo + an[k]);
+      v.y = *(const float*)(lds + bo + PS + an[k]);
+      dot[k] = __builtin_elementwise_fma(o, v, dot[k]);
+      ssq[k] = __builtin_elementwise_fma(v, v, ssq[k]);
+      if (k % 5 == 4) asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int k = 0; k < kXP; ++k) asm volatile("" : "+v"(dot[k]), "+v"(ssq[k]));  // the chunk's sums exist before its barrier
+    asm volatile("" : "+v"(oss));
+    if (ps + 1 < NP) {
+      if (ps + 2 < NP) PEA_XWAIT1()
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (ps + 3 < NP) {
+        PEA_XDMA(bo, ezo + (unsigned)(2 * ps + 6) * ecs)
+        PEA_XDMA(bo + PS, ezo + (unsigned)(2 * ps + 7) * ecs)
+      }
+    }
+  }
+#undef PEA_XDMA
+#undef PEA_XWAIT1
+
+  // ---- normalise; the lane's own 1 / norm for the backward
+  const float osum = oss.x + oss.y;
+  const float inv_eps = 1.0f / P.eps;
+  const float inv_own = rnorm(osum, inv_eps);
+  if (inv_out) bs32(iB, osum < P.eps * P.eps ? -inv_own : inv_own, pe, ezo);
+  lds_barrier();  // every lane is done with the ring: sA goes over it
+#pragma unroll
+  for (int k = 0; k < kXP; ++k) {
+    if (k < P.K) {  // uniform
+      float a = (dot[k].x + dot[k].y) * inv_own * rnorm(ssq[k].x + ssq[k].y, inv_eps);
+      if (CROP) {
+        const int q = (C.fax[k] ? px : py) + C.fd[k];
+        a = (unsigned)q < (unsigned)(C.fax[k] ? P.X : P.Y) ? a : 0.f;
+      }
+      sA[k * TP + (int)threadIdx.x] = a;
+    }
+  }
+  lds_barrier();
+
+  // ---- epilogue: 4 x-adjacent pixels of one offset per lane, dwordx4 everywhere
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    if (!ion[it]) continue;  // wave-uniform
+    const int sl = isl[it];
+    const f4 a4 = *(const f4*)(sA + sl * TP + iqd[it] * 4);
+    const unsigned so = ezo + (unsigned)sl * ecs;
+    if (has_a) {
+      f4 o = a4;
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      bs128<true>(aB, o, ivo[it], so);
+    }
+    if (TRAIN) {
+      float acc = 0.f;
+      f4 g4;
+      const float gs = C.fgs[sl];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float m = (float)((m4[it] >> (8 * j)) & 0xffu);
+        const float r = a4[j] * m - t4[it][j] * m;
+        float wr = w4[it][j] * r;
+        if (CROP) {  // a cropped-away neighbour carries no loss term (its a is already 0)
+          const int q = (C.fax[sl] ? igx[it] + j : igy[it]) + C.fd[sl];
+          wr = (unsigned)q < (unsigned)(C.fax[sl] ? P.X : P.Y) ? wr : 0.f;
+        }
+        g4[j] = gs * wr * m;
+        acc = fmaf(wr, r, acc);
+      }
+      if (has_g) bs128<false>(gB, g4, ivo[it], so);
+      const float red = wave_sum63(acc);
+      if ((threadIdx.x & 63) == 63) s_part[sl * NSL + (iqd[it] >> 6)] = red;
+    }
+  }
+  if (TRAIN) {
+    lds_barrier();
+    if ((int)threadIdx.x < P.K) {
+      float v = 0.f;
+#pragma unroll
+      for (int s = 0; s < NSL; ++s) v += s_part[threadIdx.x * NSL + s];
+      partials[(size_t)threadIdx.x * C.ntiles + tile] = v;
+    }
+  }
+}
+
 // host: the plan.  false = not an axis-aligned in-plane stencil that fits (the caller falls back to k_bwd_tiled)
-inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, size_t* lds_bytes) {
+// fwd = true: role A only (one-sided halos, offsets in their own order for the forward kernel)
+inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, size_t* lds_bytes, bool fwd = false) {
   if (P.border == PEA_BORDER_REPLICATE) return false;
   if ((long long)P.Y * P.X >= (1LL << 28)) return false;                           // plane byte offsets + displacement < 2^31
   if ((long long)(P.D > P.K ? P.D : P.K) * P.S * 4 > 0xFFFFFFFFLL) return false;   // 32-bit buffer soffset
   if (P.X % 4 || P.S % 4) return false;                                            // quads never straddle a row end
   XParams C = {};
   int hx = 0, hy = 0;
+  if (P.K > kXP) return false;
+  int up = 0, down = 0, left = 0, right = 0;
   for (int i = 0; i < P.K; ++i) {
     const int oz = P.off[i][0], oy = P.off[i][1], ox = P.off[i][2];
     if (oz != 0 || (oy != 0) == (ox != 0)) return false;  // exactly one in-plane component
+    up = oy < -up ? -oy : up; down = oy > down ? oy : down; left = ox < -left ? -ox : left; right = ox > right ? ox : right;
+    C.fd[i] = ox != 0 ? ox : oy;
+    C.fax[i] = ox != 0;
+    C.fgs[i] = P.gscale[i];
+    if (fwd) continue;
     if (ox != 0) {
       if (C.npx + 2 > kXP) return false;
       hx = ox < 0 ? (hx > -ox ? hx : -ox) : (hx > ox ? hx : ox);
@@ -263,18 +510,20 @@ inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, s
       C.yd[C.npy] = -oy; C.ygi[C.npy] = i; C.ygo[C.npy] = -oy; ++C.npy;
     }
   }
+  if (fwd) { hx = left > right ? left : right; C.hy0 = up; C.hy1 = down; }
+  else { C.hy0 = C.hy1 = hy; left = right = hx; }
   if (hx > TW) return false;  // a neighbour column is inside the tile or in the strip next to it
-  C.hy0 = C.hy1 = hy;
-  C.SW = hx <= 16 ? 32 : 64;
+  if (left > 0 && right > 0) { C.SW = hx <= 16 ? 32 : 64; C.split = C.SW / 2; }
+  else { C.SW = 32; C.split = right > 0 ? 32 : 0; }  // one strip (or none: still one row of 32 per tile row)
   for (int k = 0; k < kXP; ++k) C.xm[k] = C.xd[k] < 0 ? C.SW - 1 : 31;
+  for (int k = 0; k < kXP; ++k) C.fm[k] = C.fd[k] < 0 ? C.SW - 1 : 31;
   C.QV = (C.hy0 + TH + C.hy1) * TW / 4;
   C.QA = C.QV + TH * C.SW / 4;
   const int nw = TH * TW / 64;
-  C.QW = (C.QA + nw - 1) / nw;
-  if (C.QW > 128) return false;                      // two quads per lane and plane
-  if (C.QW * nw * 16 > psu * 256) return false;      // the plane holds every wave's share
+  if (C.QA > 2 * nw * 64) return false;              // two quads per lane and plane
+  if (C.QA * 16 > psu * 256) return false;           // the plane holds the region
   // the kernels wrap with one conditional add
-  if (P.Y < TH + C.hy1 || P.Y < C.hy0 || P.X < TW + C.SW / 2 || P.X < C.SW / 2) return false;
+  if (P.Y < TH + C.hy1 || P.Y < C.hy0 || P.X < TW + C.SW || P.X < C.SW) return false;
   C.tiles_y = (P.Y + TH - 1) / TH;
   C.tiles_x = (P.X + TW - 1) / TW;
   C.tiles_per_plane = C.tiles_y * C.tiles_x;
