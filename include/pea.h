@@ -146,6 +146,9 @@ int pea_affinity_fwd_ex(const PeaDesc *desc, const void *e, const void *e_other,
 int pea_affinity_bwd_ex(const PeaDesc *desc, const void *e, const void *e_other, const float *g, const float *inv_norm,
                         const float *dloss, void *de, void *de_other, void *stream);
 int pea_inv_norm(const PeaDesc *desc, const void *e, float *inv_norm_out, void *stream);
+/* Host-only: 1 when the LDS-DMA cross kernels cover the descriptor (self loss, 16-byte aligned tensors assumed) for the
+ * forward (backward == 0) or the backward (backward != 0, given the 1 / norm plane), else 0 (the tiled / direct kernels run). */
+int pea_cross_supported(const PeaDesc *desc, int backward);
 
 /* The backward of the full-resolution pair of the training loop in one launch: g is what pea_affinity_fwd wrote for the self
  * loss (e_other = NULL), g_cross what it wrote for the detached-EMA cross loss of the same e (e_other = ema); the stencil

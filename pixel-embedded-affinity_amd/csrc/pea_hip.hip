@@ -205,6 +205,9 @@ void allow_lds(size_t bytes) {
   }
 }
 
+// workspace = [K][fwd_partials] f32 loss partials
+size_t ws_bytes(size_t nparts_max, int K) { return nparts_max * K * sizeof(float); }
+
 size_t fwd_partials(const KParams& P) {
   // worst case over the paths pea_affinity_fwd may take
   size_t n = (size_t)P.tiles;
@@ -217,6 +220,8 @@ size_t fwd_partials(const KParams& P) {
   n = std::max(n, (size_t)((P.Y + 15) / 16) * ((P.X + 31) / 32) * P.Z * P.B);      // the LDS-DMA forward's 16x32 tiles
   return n;
 }
+
+void launch_loss_finalize(const KParams& P, float* partials, int nparts, float* loss_out, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // 1 / norm plane (pea_xdma.h): written by the tiled D = 16 forward while it stages; by this kernel otherwise
@@ -411,7 +416,9 @@ int launch_fwd(const KParams& P, const void* e, const void* eo, const float* t, 
   if (env_int("PEA_FORCE_DIRECT", 0) == 0) {
     bool done = false;
     if constexpr (sizeof(T) == 4) {
-      if (P.D == 16 && op == ep)
+      // (inference keeps k_fwd_tiled: 60 us against 68 us at B=8 x 544^2 -- without the epilogue streams the one-sided
+      //  box of the tiled kernel moves fewer bytes than six ring planes do)
+      if (TRAIN && P.D == 16 && op == ep)
         done = try_fwd_xdma<TRAIN>(P, (const float*)ep, t, w, m, affs, gout, partials, inv_out, s, nparts);
     }
     if (!done && P.D == 16 && TRAIN) done = try_fwd_v<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, inv_out, s, nparts);
@@ -714,6 +721,12 @@ __global__ __launch_bounds__(256) void k_scale_multi(const ScaleMulti M, const f
   }
 }
 
+// One workgroup: a second reduction launch costs more than it saves (measured: 16-workgroup slice sums + a final kernel
+// took 8 + 5 us against 10 us for this one; any launch is >= 4.5 us here and one CU pulls ~20 GB/s)
+void launch_loss_finalize(const KParams& P, float* partials, int nparts, float* loss_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P, (const float*)partials, nparts, loss_out);
+}
+
 }  // namespace
 
 extern "C" {
@@ -737,7 +750,7 @@ int pea_desc_validate(const PeaDesc* desc) { return validate(desc); }
 size_t pea_workspace_bytes(const PeaDesc* desc) {
   if (validate(desc)) return 0;
   const KParams P = make_params(desc);
-  return fwd_partials(P) * P.K * sizeof(float);
+  return ws_bytes(fwd_partials(P), P.K);
 }
 
 int pea_affinity_infer(const PeaDesc* desc, const void* e, const void* e_other, float* affs, void* stream) {
@@ -766,7 +779,7 @@ int pea_affinity_fwd_ex(const PeaDesc* desc, const void* e, const void* e_other,
       misaligned(inv_norm_out, 4))
     return PEA_E_ALIGN;
   const KParams P = make_params(desc);
-  if (!workspace || workspace_bytes < fwd_partials(P) * P.K * sizeof(float)) return PEA_E_WORKSPACE;
+  if (!workspace || workspace_bytes < ws_bytes(fwd_partials(P), P.K)) return PEA_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   float* partials = (float*)workspace;
   int nparts = 0;
@@ -779,7 +792,7 @@ int pea_affinity_fwd_ex(const PeaDesc* desc, const void* e, const void* e_other,
     if (desc->dtype == PEA_F16) launch_inv_norm<__half>(P, (const __half*)e, inv_norm_out, s);
     else launch_inv_norm<float>(P, (const float*)e, inv_norm_out, s);
   }
-  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P, partials, nparts, loss_out);
+  launch_loss_finalize(P, partials, nparts, loss_out, s);
   return hip_rc();
 }
 
@@ -787,6 +800,16 @@ int pea_affinity_fwd(const PeaDesc* desc, const void* e, const void* e_other, co
                      const float* weight, const uint8_t* mask, float* affs, float* g_out, float* loss_out,
                      void* workspace, size_t workspace_bytes, void* stream) {
   return pea_affinity_fwd_ex(desc, e, e_other, target, weight, mask, affs, g_out, nullptr, loss_out, workspace, workspace_bytes, stream);
+}
+
+int pea_cross_supported(const PeaDesc* desc, int backward) {
+  if (validate(desc)) return 0;
+  const KParams P = make_params(desc);
+  if (desc->dtype != PEA_F32 || P.D != 16 || env_int("PEA_FORCE_DIRECT", 0) != 0) return 0;
+  if (env_int(backward ? "PEA_BWD_XDMA" : "PEA_FWD_XDMA", 1) == 0) return 0;
+  XParams C;
+  size_t lds;
+  return plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds, backward == 0) ? 1 : 0;
 }
 
 int pea_inv_norm(const PeaDesc* desc, const void* e, float* inv_norm_out, void* stream) {
@@ -846,7 +869,7 @@ int pea_affinity_fwd_bwd(const PeaDesc* desc, const void* e, const void* e_other
       misaligned(weight, 4) || misaligned(loss_out, 4) || misaligned(dloss, 4) || misaligned(workspace, 4))
     return PEA_E_ALIGN;
   const KParams P = make_params(desc);
-  if (!workspace || workspace_bytes < fwd_partials(P) * P.K * sizeof(float)) return PEA_E_WORKSPACE;
+  if (!workspace || workspace_bytes < ws_bytes(fwd_partials(P), P.K)) return PEA_E_WORKSPACE;
   if (P.D != 16 || env_int("PEA_FORCE_DIRECT", 0) != 0) return PEA_E_UNSUPPORTED;  // caller: pea_affinity_fwd + pea_affinity_bwd
   hipStream_t s = (hipStream_t)stream;
   float* partials = (float*)workspace;
@@ -864,7 +887,7 @@ int pea_affinity_fwd_bwd(const PeaDesc* desc, const void* e, const void* e_other
   if (!done) return PEA_E_UNSUPPORTED;
   rc = hip_rc();
   if (rc) return rc;
-  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P, partials, nparts, loss_out);
+  launch_loss_finalize(P, partials, nparts, loss_out, s);
   return hip_rc();
 }
 
@@ -994,7 +1017,7 @@ int pea_affinity_fwd_bwd_labels(const PeaDesc* desc, const void* e, const void* 
     return PEA_E_ALIGN;
   if (flags & ~(PEA_TGT_PADDING | PEA_TGT_BOTH_FOREGROUND | PEA_TGT_MASK_INSIDE | PEA_TGT_ACCUMULATE)) return PEA_E_DESC;
   const KParams P = make_params(desc);
-  if (!workspace || workspace_bytes < fwd_partials(P) * P.K * sizeof(float)) return PEA_E_WORKSPACE;
+  if (!workspace || workspace_bytes < ws_bytes(fwd_partials(P), P.K)) return PEA_E_WORKSPACE;
   if ((P.D != 16 && P.D != 32) || env_int("PEA_FORCE_DIRECT", 0) != 0) return PEA_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* partials = (float*)workspace;
@@ -1015,7 +1038,7 @@ int pea_affinity_fwd_bwd_labels(const PeaDesc* desc, const void* e, const void* 
   if (!done) return PEA_E_UNSUPPORTED;
   rc = hip_rc();
   if (rc) return rc;
-  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P, partials, nparts, loss_out);
+  launch_loss_finalize(P, partials, nparts, loss_out, s);
   return hip_rc();
 }
 
@@ -1040,11 +1063,11 @@ int pea_affinity_fwd_bwd_labels_dual(const PeaDesc* desc, const PeaDesc* desc_cr
     return PEA_E_ALIGN;
   if (flags & ~(PEA_TGT_PADDING | PEA_TGT_BOTH_FOREGROUND | PEA_TGT_MASK_INSIDE)) return PEA_E_DESC;
   const KParams P = make_params(desc), P2 = make_params(desc_cross);
-  const size_t np = fwd_partials(P) * P.K;
-  if (!workspace || workspace_bytes < 2 * np * sizeof(float)) return PEA_E_WORKSPACE;
+  const size_t wsb = ws_bytes(fwd_partials(P), P.K);  // each loss has its own [partials | slice sums] block
+  if (!workspace || workspace_bytes < 2 * wsb) return PEA_E_WORKSPACE;
   if ((P.D != 16 && P.D != 32) || env_int("PEA_FORCE_DIRECT", 0) != 0 || env_int("PEA_LABELS_DUAL", 1) == 0) return PEA_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  float *partials = (float*)workspace, *partials2 = partials + np;
+  float *partials = (float*)workspace, *partials2 = (float*)((char*)workspace + wsb);
   int nparts = 0;
   bool done;
 #define PEA_LD(T_, D_) try_fused_labels_dual<T_, D_>(P, P2, (const T_*)e, (const T_*)ema, labels, wtab, flags, affs, partials, partials2, \
@@ -1055,8 +1078,8 @@ int pea_affinity_fwd_bwd_labels_dual(const PeaDesc* desc, const PeaDesc* desc_cr
   if (!done) return PEA_E_UNSUPPORTED;
   rc = hip_rc();
   if (rc) return rc;
-  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P, partials, nparts, loss_out);
-  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P2, partials2, nparts, loss_cross_out);
+  launch_loss_finalize(P, partials, nparts, loss_out, s);
+  launch_loss_finalize(P2, partials2, nparts, loss_cross_out, s);
   return hip_rc();
 }
 

@@ -278,6 +278,11 @@ if __name__ == "__main__":
         case_head("ghead_2d_c64_d32", 62, B=1, C=64, D=32, spatial=(9, 31))
         case_head("ghead_3d_c28_d16", 63, B=1, C=28, D=16, spatial=(3, 10, 13))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cross":  # only the fixtures sized for the LDS-DMA cross kernels (pea_xdma.h)
+        torch.manual_seed(0)
+        case_2d("g2d_x_k10", 71, B=1, D=16, H=50, W=100, shifts=[1, 3, 5, 9, 27], nb=4, zero_px=True)
+        case_2d("g2d_x_k8", 72, B=2, D=16, H=37, W=72, shifts=[1, 3, 5, 9, 11], nb=4, K=8)
+        sys.exit(0)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     # 2D, shipped CVPPP stencil (shifts 1,3,5,9,27 x neighbor 4 -> K=10), ragged sizes
@@ -291,6 +296,10 @@ if __name__ == "__main__":
     case_2d("g2d_cos_mode", 5, B=1, D=16, H=24, W=40, shifts=[1, 3, 5], nb=4, mode="cos", scale=3.0)
     case_2d("g2d_d64", 6, B=1, D=64, H=16, W=64, shifts=[1, 3, 5, 9], nb=4)
     case_2d("g2d_d5_generic", 7, B=1, D=5, H=19, W=23, shifts=[1, 2], nb=8)
+    # shapes that reach the LDS-DMA cross kernels (D = 16, X % 4 == 0, X >= 32 + strip): the shipped stencil with ragged
+    # tiles and zero-norm pixels; the deep-supervision prefix offsets[:8] with the narrow (32-pixel) strip row
+    case_2d("g2d_x_k10", 71, B=1, D=16, H=50, W=100, shifts=[1, 3, 5, 9, 27], nb=4, zero_px=True)
+    case_2d("g2d_x_k8", 72, B=2, D=16, H=37, W=72, shifts=[1, 3, 5, 9, 11], nb=4, K=8)
     # EMA cross loss: detached second operand (shipped, if_ema_flip) and the non-detached variant
     case_2d_ema("g2d_ema_detach", 11, B=2, D=16, H=40, W=56, shifts=[1, 3, 5, 9, 27], nb=4, affs0_weight=2, detach=True)
     case_2d_ema("g2d_ema_both", 12, B=1, D=16, H=32, W=40, shifts=[1, 3, 9], nb=8, affs0_weight=1, detach=False)

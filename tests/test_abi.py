@@ -24,7 +24,7 @@ def lib(pkg):
 def test_header_declares_the_expected_entry_points():
     assert declared_symbols() == sorted(["pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes",
                                          "pea_affinity_infer", "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_ex", "pea_affinity_bwd_ex",
-                                         "pea_inv_norm", "pea_affinity_bwd_dual",
+                                         "pea_inv_norm", "pea_cross_supported", "pea_affinity_bwd_dual",
                                          "pea_affinity_fwd_bwd", "pea_scale_inplace", "pea_scale_inplace_multi", "pea_fill_border_relu",
                                          "pea_targets_workspace_bytes", "pea_gen_targets",
                                          "pea_stitch_add", "pea_stitch_finalize", "pea_label_weights",
@@ -119,3 +119,33 @@ def test_no_kernel_spills_vector_registers(pkg, lib, tmp_path):
                 spilled.append(name)
     assert kernels > 50, "code object metadata not found"
     assert not spilled, "kernels with VGPR spills: %s" % spilled
+
+
+def test_cross_kernels_cover_the_shipped_2d_shapes(pkg, lib):
+    """host-only dispatch query: the LDS-DMA cross kernels (csrc/pea_xdma.h) take the axis-aligned multi_offset(neighbor=4)
+    stencils at CVPPP / BBBC039V1 sizes; diagonal stencils, z offsets, f16, D != 16 and narrow images take the tiled kernels"""
+    def desc(D, H, W, offs, dtype=0, border=0, B=8):
+        d = pkg._lib.PeaDesc()
+        d.abi, d.ndim, d.B, d.D, d.K = 1, 2, B, D, len(offs)
+        d.dims[:] = [1, H, W]
+        d.border, d.dtype, d.norm, d.eps = border, dtype, 0, 1e-12
+        for i, o in enumerate(offs):
+            d.offsets[i][:] = [0] * (3 - len(o)) + list(o)
+            d.lam[i] = 1.0
+        return d
+    cv = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    q = lambda d, b: lib.pea_cross_supported(ctypes.byref(d), b)
+    for bwd in (0, 1):
+        assert q(desc(16, 544, 544, cv), bwd) == 1
+        assert q(desc(16, 272, 272, cv[:8]), bwd) == 1           # the deep-supervision scales (main.py:284-286)
+        assert q(desc(16, 136, 136, cv[:6]), bwd) == 1
+        assert q(desc(16, 704, 704, pkg.multi_offset([1, 3, 5, 9, 11], 4)), bwd) == 1
+        assert q(desc(16, 50, 100, cv, B=1), bwd) == 1            # golden g2d_x_k10
+        assert q(desc(16, 37, 72, cv[:8], B=2), bwd) == 1         # golden g2d_x_k8
+        assert q(desc(16, 544, 544, cv, border=1), bwd) == 1      # CROP_ZERO
+        assert q(desc(16, 544, 544, pkg.multi_offset([1, 3, 9], 8)), bwd) == 0   # diagonal offsets
+        assert q(desc(32, 544, 544, cv), bwd) == 0
+        assert q(desc(16, 544, 544, cv, dtype=1), bwd) == 0       # f16 storage
+        assert q(desc(16, 544, 542, cv), bwd) == 0                # X % 4 != 0
+        assert q(desc(16, 40, 56, cv, B=2), bwd) == 0             # narrower than a tile plus its strips
+    assert q(desc(16, 34, 34, cv[:2]), 0) == 0

@@ -1,0 +1,150 @@
+"""GPU (-m gpu): the LDS-DMA cross kernels (csrc/pea_xdma.h: k_fwd_xdma, k_bwd_xdma, k_inv_norm) against the CPU oracle,
+against the tiled kernels they replace, and through the new C-ABI entry points (pea_affinity_fwd_ex / pea_affinity_bwd_ex /
+pea_inv_norm).  The reference goldens sized for them (g2d_x_k10, g2d_x_k8) run in test_gpu_parity.py.
+
+Tolerances as in test_gpu_parity.py: affs abs 1e-5, loss rel 1e-5, grads rel-to-max 1e-4."""
+import ctypes
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import __graft_entry__ as ge
+
+pytestmark = pytest.mark.gpu
+AFFS_ATOL, LOSS_RTOL, GRAD_RTOL = 1e-5, 1e-5, 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def synth():
+    ge.load_package()
+    return importlib.import_module(ge.PKG_NAME + ".utils.synth")
+
+
+def cu(a, dev):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def relmax(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _inputs(synth, B, D, dims, K, seed, zero_px=False):
+    S = int(np.prod(dims))
+    e = synth.synth_embedding((B, D, S), 100 + seed).reshape([B, D] + dims)
+    if zero_px:
+        e[0, :, 0, 3, 5] = 0.0
+        e[-1, :, 0, dims[1] - 1, dims[2] - 1] = 1e-14
+    idx = np.arange(B * K * S, dtype=np.uint64)
+    t = (synth.hash_uniform(idx, 200 + seed) < 0.6).astype(np.float32).reshape([B, K] + dims)
+    w = (0.5 + synth.hash_uniform(idx, 300 + seed)).astype(np.float32).reshape([B, K] + dims)
+    m = (synth.hash_uniform(idx, 400 + seed) < 0.9).astype(np.uint8).reshape([B, K] + dims)
+    return e, t, w, m
+
+
+CASES = [
+    # (B, Y, X, shifts, K, border, norm, mask, relu, dloss)          border 0 CIRCULAR / 1 CROP_ZERO; norm 0 BX / 1 CROPPED / 2 FULL
+    (2, 50, 100, [1, 3, 5, 9, 27], 10, 0, 0, True, False, 1.0),       # shipped stencil, ragged tiles in y and x, 64-pixel strip rows
+    (1, 43, 96, [1, 3, 5, 9, 27], 10, 0, 0, False, True, 0.5),        # the smallest image the +-27 cross accepts; relu; no mask
+    (3, 64, 128, [1, 3, 5, 9, 27], 10, 1, 1, True, False, 2.0),       # CROP_ZERO + cropped normaliser (the 3D path's border in 2D)
+    (2, 37, 72, [1, 3, 5, 9, 11], 8, 0, 0, True, False, 1.0),         # reach 9: 32-pixel strip rows
+    (2, 48, 64, [1, 3, 5, 9, 11], 10, 0, 2, True, False, 0.25),       # reach 11, minimum width, PEA_NORM_FULL
+    (1, 80, 160, [2, 4, 16], 6, 1, 2, False, False, 1.0),             # even shifts, reach 16 (the widest 32-pixel strip row)
+    (2, 33, 68, [1], 2, 0, 0, True, False, 1.0),                      # K = 2
+    (1, 96, 200, [1, 3, 5, 9, 27], 9, 0, 0, True, False, 1.0),        # odd K: x reaches 27, y only 9 (asymmetric cross)
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_cross_kernels_vs_oracle(pkg, dev, orc, synth, case):
+    B, Y, X, shifts, K, border, norm, use_mask, relu, dloss = CASES[case]
+    D, dims = 16, [1, Y, X]
+    offs = [[0] + o for o in pkg.multi_offset(shifts, 4)][:K]
+    lam = [1.0 + 0.25 * (i % 3) for i in range(K)]
+    e, t, w, m = _inputs(synth, B, D, dims, K, 7 * case, zero_px=(case == 0))
+    op, L = pkg.affinity_op, pkg._lib.lib()
+    spec = op.AffinitySpec(3, offs, lam, border, norm, relu=relu)
+    et = cu(e, dev).requires_grad_(True)
+    d_hip = op.make_desc(spec, et.detach())
+    assert L.pea_cross_supported(ctypes.byref(d_hip), 0) == 1 and L.pea_cross_supported(ctypes.byref(d_hip), 1) == 1
+    loss, affs, parts = op.FusedAffinityMSE.apply(et, None, cu(t, dev), cu(w, dev), cu(m, dev) if use_mask else None, spec)
+    (loss * dloss).backward()
+    d = orc.make_desc(B, D, dims, offs, lam, border, norm, flags=orc.FLAG_RELU if relu else 0, ndim=3)
+    o_affs, o_loss = orc.c_fwd(d, e, None, t, w, m if use_mask else None)
+    o_grad, _ = orc.c_bwd(d, e, None, t, w, m if use_mask else None, dloss=dloss)
+    assert np.abs(affs.cpu().numpy().reshape(o_affs.shape) - o_affs).max() < AFFS_ATOL
+    assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * max(abs(o_loss[0]), 1e-6)
+    np.testing.assert_allclose(parts.cpu().numpy(), o_loss[1:], rtol=LOSS_RTOL, atol=1e-9)
+    assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL
+    inf = op.affinity_infer(et.detach(), None, spec)
+    assert np.abs(inf.cpu().numpy().reshape(o_affs.shape) - o_affs).max() < AFFS_ATOL
+
+
+def test_cross_and_tiled_kernels_agree_and_are_reproducible(pkg, dev, synth, monkeypatch):
+    """the same call through the cross kernels and (PEA_FWD_XDMA=0 PEA_BWD_XDMA=0) through the tiled kernels; twice each"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    B, D, H, W = 3, 16, 112, 160
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 61)
+
+    def run():
+        et = cu(e, dev).requires_grad_(True)
+        loss, affs, parts = pkg.embedding_loss(et, cu(t, dev), cu(w, dev), cu(m, dev), pkg.WeightedMSE(), offsets)
+        (loss * 1.5).backward()
+        return loss.item(), affs.cpu().numpy(), et.grad.cpu().numpy(), np.array(list(parts))
+
+    monkeypatch.delenv("PEA_FWD_XDMA", raising=False)
+    monkeypatch.delenv("PEA_BWD_XDMA", raising=False)
+    l1, a1, g1, p1 = run()
+    l1b, a1b, g1b, p1b = run()
+    assert l1 == l1b and np.array_equal(a1, a1b) and np.array_equal(g1, g1b) and np.array_equal(p1, p1b)  # no atomics anywhere
+    monkeypatch.setenv("PEA_FWD_XDMA", "0")
+    monkeypatch.setenv("PEA_BWD_XDMA", "0")
+    l0, a0, g0, p0 = run()
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    assert np.abs(a1 - a0).max() < 2e-6
+    np.testing.assert_allclose(p1, p0, rtol=1e-6)
+    assert relmax(g1, g0) < 1e-5
+
+
+def test_inv_norm_plane_and_ex_entry_points(pkg, dev, orc, synth):
+    """pea_inv_norm against numpy (sign = the clamp branch of F.normalize); the plane pea_affinity_fwd_ex writes; and
+    pea_affinity_bwd_ex with and without it (cross kernel / tiled kernel) against the oracle, through the C ABI directly"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    B, D, H, W = 2, 16, 64, 128
+    K = len(offsets)
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 77)
+    e[0, :, 5, 7] = 0.0
+    e[1, :, 63, 127] = 3e-14
+    op, L = pkg.affinity_op, pkg._lib.lib()
+    E, T, Wt, M = cu(e, dev), cu(t, dev), cu(w, dev), cu(m, dev)
+    desc = op.make_desc(op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX), E)
+    P = lambda x: ctypes.c_void_p(x.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    inv0 = torch.empty(B, H, W, device=dev)
+    assert L.pea_inv_norm(ctypes.byref(desc), P(E), P(inv0), st) == 0
+    nrm = np.sqrt((e.astype(np.float64) ** 2).sum(1))
+    ref = np.where(nrm < 1e-12, -1e12, 1.0 / np.maximum(nrm, 1e-12))
+    np.testing.assert_allclose(inv0.cpu().numpy(), ref, rtol=3e-7)
+    assert (inv0.cpu().numpy() < 0).sum() == 2
+    affs, g, inv1 = torch.empty(B, K, H, W, device=dev), torch.empty(B, K, H, W, device=dev), torch.full((B, H, W), 7.0, device=dev)
+    lossv = torch.empty(1 + K, device=dev)
+    wsb = L.pea_workspace_bytes(ctypes.byref(desc))
+    work = torch.empty(max(wsb, 4) // 4, device=dev)
+    assert L.pea_affinity_fwd_ex(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), P(g), P(inv1), P(lossv), P(work), wsb, st) == 0
+    np.testing.assert_allclose(inv1.cpu().numpy(), ref, rtol=3e-7)
+    d = orc.desc_2d(e, offsets)
+    o_grad, _ = orc.c_bwd(d, e, None, t, w, m, dloss=0.75)
+    dl = torch.full((), 0.75, device=dev)
+    de_x, de_t = torch.empty_like(E), torch.empty_like(E)
+    assert L.pea_affinity_bwd_ex(ctypes.byref(desc), P(E), None, P(g), P(inv1), P(dl), P(de_x), None, st) == 0
+    assert L.pea_affinity_bwd_ex(ctypes.byref(desc), P(E), None, P(g), None, P(dl), P(de_t), None, st) == 0
+    assert relmax(de_x.cpu().numpy(), o_grad) < GRAD_RTOL and relmax(de_t.cpu().numpy(), o_grad) < GRAD_RTOL
+    # the zero-norm pixels take the clamp branch: d ehat / d e = I / eps, no projection
+    assert relmax(de_x.cpu().numpy()[0, :, 5, 7], o_grad[0, :, 5, 7]) < GRAD_RTOL
