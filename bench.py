@@ -32,10 +32,131 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SHIFTS, NEIGHBOR = [1, 3, 5, 9, 27], 4
 B_PER_GPU, D, H, W = 8, 16, 544, 544
 
+# --config: the headline workload (c2 = BASELINE.json configs[1], the default and the only one the driver runs) and the other
+# single-GPU shapes of BASELINE.json / SURVEY.md section 8d, each through the same step / roofline / cpu_baseline code
+CONFIGS = {
+    "c2": dict(what="BASELINE configs[1]: CVPPP A1 embedding_loss fwd+bwd", ndim=2, B=8, D=16, dims=(544, 544), shifts=[1, 3, 5, 9, 27], K=10, f16=False),
+    "c3": dict(what="BASELINE configs[2]: BBBC039V1 embedding_loss fwd+bwd (per-GPU share of B=32 over 4 GPUs)", ndim=2, B=8, D=32, dims=(704, 704),
+               shifts=[1, 3, 5, 9, 11], K=10, f16=False),
+    "c4": dict(what="BASELINE configs[3]: AC3/AC4 embedding_loss_norm5 fwd+bwd, one 24x1024x1024 sub-volume per GPU, the reference's 12 axis offsets",
+               ndim=3, B=1, D=16, dims=(24, 1024, 1024), stencil="norm5", K=12, f16=False),
+    "c4n26": dict(what="BASELINE configs[3]: AC3/AC4 sub-volume 24x1024x1024, synthetic 26-neighbourhood (CROP_ZERO, cropped normaliser)",
+                  ndim=3, B=1, D=16, dims=(24, 1024, 1024), stencil="n26", K=26, f16=False),
+    "c5": dict(what="BASELINE configs[4]: D=64 embedding_loss fwd+bwd, f16 storage / f32 accumulate, offsets[:8]", ndim=2, B=8, D=64, dims=(544, 544),
+               shifts=[1, 3, 5, 9, 27], K=8, f16=True),
+}
 
-def algorithmic_bytes_per_px(D, K):
-    """SURVEY.md section 8d (fp32, 2D with u8 mask): fwd 4D+13K, bwd 8D+9K, fwd+bwd 12D+22K."""
-    return {"fwd": 4 * D + 13 * K, "bwd": 8 * D + 9 * K, "step": 12 * D + 22 * K}
+
+def algorithmic_bytes_per_px(D, K, es=4, mask=True):
+    """fwd es*D + (4+4+[1]+4)K, bwd 2*es*D + (4+4+[1])K; es = bytes per embedding element (4, or 2 for f16
+    storage).  2D f32 with the u8 mask: fwd 4D+13K, bwd 8D+9K, fwd+bwd 12D+22K; 3D (no mask): 12D+20K."""
+    km = 1 if mask else 0
+    fwd, bwd = es * D + (12 + km) * K, 2 * es * D + (8 + km) * K
+    return {"fwd": fwd, "bwd": bwd, "step": fwd + bwd}
+
+
+def other_config(args, pkg, dev, world, rank, dist, fence):
+    """--config c3 | c4 | c4n26 | c5: same step timing, roofline (from the entry points' in-step HIP-event durations) and a
+    bounded cpu_baseline; inputs are drawn on the GPU (torch.Generator, seed 555 + rank): N(0,1) embeddings,
+    Bernoulli(0.6) targets, U(0.5,1.5) weights, Bernoulli(0.9) masks (2D)."""
+    c = CONFIGS[args.config]
+    B, Dm, dims, K = (args.batch if args.batch != B_PER_GPU else c["B"]), c["D"], list(c["dims"]), c["K"]
+    g = torch.Generator(device=dev).manual_seed(555 + rank)
+    E = torch.randn([B, Dm] + dims, generator=g, device=dev)
+    if c["f16"]:
+        E = E.half()
+    E.requires_grad_(True)
+    T = (torch.rand([B, K] + dims, generator=g, device=dev) < 0.6).float()
+    Wt = torch.rand([B, K] + dims, generator=g, device=dev) + 0.5
+    M = (torch.rand([B, K] + dims, generator=g, device=dev) < 0.9).to(torch.uint8) if c["ndim"] == 2 else None
+    crit = pkg.WeightedMSE()
+    L, op = pkg._lib.lib(), pkg.affinity_op
+    if c["ndim"] == 2:
+        offsets = pkg.multi_offset(c["shifts"], NEIGHBOR)[:K]
+        spec = op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX)
+    else:
+        if c["stencil"] == "norm5":
+            offsets = pkg.utils.affinity_ours.axis_offsets_3d(pkg.utils.affinity_ours.NORM5_SHIFTS)
+        else:
+            offsets = [[dz, dy, dx] for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dz, dy, dx) != (0, 0, 0)]
+        spec = op.AffinitySpec(3, offsets, None, pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
+
+    def step():
+        E.grad = None
+        loss, affs, _ = op.FusedAffinityMSE.apply(E, None, T, Wt, M, spec)
+        loss.backward()
+
+    for _ in range(max(args.warmup, 3)):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    npx = B * int(np.prod(dims))
+    value = world * npx * args.steps / dt / 1e6
+    if rank != 0:
+        return None
+    Ed = E.detach()
+    desc = op.make_desc(spec, Ed)
+    affs, G = torch.empty([B, K] + dims, device=dev), torch.empty([B, K] + dims, device=dev)
+    lossv, INV, dE, one = torch.empty(1 + K, device=dev), torch.empty([B] + dims, device=dev), torch.empty_like(Ed), torch.ones((), device=dev)
+    wsb = L.pea_workspace_bytes(ctypes.byref(desc))
+    work = torch.empty(max(wsb, 4) // 4, device=dev)
+    P = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fwd = lambda: L.pea_affinity_fwd_ex(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(affs), P(G), P(INV), P(lossv), P(work), wsb, st)
+    bwd = lambda: L.pea_affinity_bwd_ex(ctypes.byref(desc), P(Ed), None, P(G), P(INV), P(one), P(dE), None, st)
+    in_step_times_ms(fwd, bwd, 3)
+    kf, kb = in_step_times_ms(fwd, bwd, max(10, min(args.steps, 50)))
+    ab = algorithmic_bytes_per_px(Dm, K, 2 if c["f16"] else 4, mask=M is not None)
+    dom = "bwd" if kb >= kf else "fwd"
+    achieved = ab[dom] * npx / (max(kf, kb) * 1e-3) / 1e9
+    step_gbs = ab["step"] * npx / ((kf + kb) * 1e-3) / 1e9
+    out = {
+        "metric": "affinity-map Mpixels/sec (fwd+bwd)", "value": round(value, 2), "unit": "Mpx/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 storage / f32 arithmetic" if c["f16"] else "f32",
+        "data": "synthetic",
+        "config": {"workload": "%s: B=%d per GPU x D=%d x %s, K=%d offsets" % (c["what"], B, Dm, "x".join(str(v) for v in dims), K),
+                   "images_per_gpu": B, "embedding_dim": Dm, "dims": dims, "offsets": K, "sharding": "batch across ranks, no data-path collective"},
+        "kernel_ms": {"fwd": round(kf, 5), "bwd": round(kb, 5)},
+        "cross_kernels": {"fwd": int(L.pea_cross_supported(ctypes.byref(desc), 0)), "bwd": int(L.pea_cross_supported(ctypes.byref(desc), 1))},
+        "roofline": {"bound": "hbm", "kernel": "pea_affinity_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_px": ab[dom], "px_per_launch": npx,
+                     "ms": round(max(kf, kb), 5), "fwd_plus_bwd_GBs": round(step_gbs, 1), "fwd_plus_bwd_frac": round(step_gbs / HBM_PEAK_GBS, 4)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        # bounded sample: one image (2D) / one 24 x 256 x 256 block of the sub-volume (3D), same op sequence on the host cores
+        orc = ge.load_oracle()
+        cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        torch.set_num_threads(cores)
+        if c["ndim"] == 2:
+            ec, tc, wc, mc = (x[:1].float().cpu() if x.dtype != torch.uint8 else x[:1].cpu() for x in (Ed, T, Wt, M))
+            fn = lambda x: orc.torch_embedding_loss(x, tc, wc, mc, offsets)[0]
+            sample = "1 image of the batch"
+        else:
+            sl = (slice(0, 1), slice(None), slice(None), slice(0, 256), slice(0, 256))
+            ec, tc, wc = (x[sl].float().cpu().contiguous() for x in (Ed, T[:, :12], Wt[:, :12]))
+            fn = lambda x: orc.torch_embedding_loss_3d(x, tc, wc, pkg.utils.affinity_ours.NORM5_SHIFTS)[0]
+            sample = "a 24x256x256 block of the sub-volume, the norm5 stencil (K=12)"
+        def one():
+            x = ec.clone().requires_grad_(True)
+            fn(x).backward()
+        t0 = time.perf_counter(); one(); first = time.perf_counter() - t0
+        iters = int(max(1, min(5, 20.0 // max(first, 1e-3) - 1)))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            one()
+        dtc = (time.perf_counter() - t0) / iters
+        out["cpu_baseline"] = {"value": round(ec[0, 0].numel() / dtc / 1e6, 4), "unit": "Mpx/s", "cores": cores, "kind": "port",
+                               "sample": "%d timed fwd+bwd iterations of %s, oracle/pea_oracle.py torch restatement, %.2f s/iter" % (iters, sample, dtc)}
+    return out
 
 
 def event_time_ms(fn, iters):
@@ -126,6 +247,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="images per GPU")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="c2 = the headline workload (default); c3 / c4 / c4n26 / c5: see CONFIGS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-section", action="store_true",
                     help="skip the multi-scale loss-section timings (profiling runs: per-kernel averages then cover the full-size launches only)")
@@ -156,6 +278,21 @@ def main():
 
     pkg = ge.load_package()
     synth = __import__("importlib").import_module(ge.PKG_NAME + ".utils.synth")
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.config != "c2":
+        out = other_config(args, pkg, dev, world, rank, dist, fence)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        if out is not None:
+            print(json.dumps(out), flush=True)
+        return
+
     offsets = pkg.multi_offset(SHIFTS, NEIGHBOR)
     K, B = len(offsets), args.batch
     # each rank owns its own images (different seeds): independent units, no exchange
@@ -169,12 +306,6 @@ def main():
         loss, affs, _ = pkg.embedding_loss(E, T, Wt, M, crit, offsets)
         loss.backward()
         return loss
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
 
     # Settle first (untimed, before the W warm-up steps): a GPU that has just been handed over idles at its lowest clocks
     # and the first few hundred launches also pay the allocator's and the library's first-touch costs; a 20-step timing

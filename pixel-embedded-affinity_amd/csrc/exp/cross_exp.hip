@@ -19,7 +19,7 @@ extern "C" int pea_x_bwd(const PeaDesc* d, const void* e, const float* inv, cons
   const KParams P = mk(d);
   XParams Xp; size_t lds;
   if (!plan_xdma(P, 16, 32, 51, &Xp, &lds)) return -3;
-#define RUN(AUX) { constexpr auto k = k_bwd_xdma<16, 16, 32, 51, false, AUX>; allow<k>(lds); \
+#define RUN(AUX) { constexpr auto k = k_bwd_xdma<16, 16, 32, 51, false, kXP, AUX>; allow<k>(lds); \
   hipLaunchKernelGGL(k, dim3(Xp.tiles_per_xcd * kXcd), dim3(512), lds, (hipStream_t)stream, P, Xp, (const float*)e, inv, g, dl, (float*)de); }
   if (cfg == 2) RUN(0) else if (cfg == 3) RUN(2) else if (cfg == 4) RUN(16) else if (cfg == 5) RUN(18) else if (cfg == 6) RUN(1) else return -3;
   return (int)hipGetLastError();

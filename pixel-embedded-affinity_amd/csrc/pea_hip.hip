@@ -142,7 +142,11 @@ constexpr int kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup ma
 bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, TParams* Q) {
   if (P.border == PEA_BORDER_REPLICATE) return false;  // direct kernels only (row a-15: an unused variant of the reference)
   if ((long long)P.Y * P.X >= (1LL << 29)) return false;                     // plane byte offsets stay below 2^31 (kOOB)
-  if ((long long)std::max(P.D, P.K) * P.S * 4 > 0xFFFFFFFFLL) return false;  // buffer soffset is 32-bit
+  // A raw buffer access is in range iff voffset < num_records - soffset (gfx9 range check: the scalar offset COUNTS), and the
+  // kernels select the channel / offset plane with soffset under num_records = 2^31: the [D or K, Z, Y, X] block of one batch
+  // item must stay below 2 GiB, or planes past it read zeros and drop their stores without any error (found by the
+  // full-size K = 26 test: 26 x 24 x 1024^2 x 4 B = 2.6 GB).  Larger blocks take the direct kernels (64-bit pointers).
+  if ((long long)std::max(P.D, P.K) * P.S * 4 >= (1LL << 31)) return false;
   const int NT = c.TH * c.TW;
   int radii[PEA_MAX_K], nr = 0;
   for (int i = 0; i < P.K; ++i)
@@ -240,13 +244,15 @@ bool try_bwd_xdma(const KParams& P, const float* x, const float* inv, const floa
   XParams C;
   size_t lds;
   if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds)) return false;
+  constexpr int XP = D_T > 32 ? 8 : kXP;  // pairs per axis the instantiation keeps in registers
+  if (C.npx > XP || C.npy > XP) return false;
   const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
   if (P.border == PEA_BORDER_CIRCULAR) {
-    constexpr auto kern = k_bwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSU, false>;
+    constexpr auto kern = k_bwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSU, false, XP>;
     allow_lds<kern>(lds);
     hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, dx);
   } else {
-    constexpr auto kern = k_bwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSU, true>;
+    constexpr auto kern = k_bwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSU, true, XP>;
     allow_lds<kern>(lds);
     hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, dx);
   }
@@ -254,7 +260,7 @@ bool try_bwd_xdma(const KParams& P, const float* x, const float* inv, const floa
 }
 
 // the LDS-DMA forward (self loss / inference, D = 16, f32, axis-aligned in-plane stencil, K <= kXP)
-template <bool TRAIN>
+template <int D_T, bool TRAIN>
 bool try_fwd_xdma(const KParams& P, const float* e, const float* t, const float* w, const uint8_t* m, float* affs, float* gout,
                   float* partials, float* inv_out, hipStream_t s, int* nparts) {
   if (env_int("PEA_FWD_XDMA", 1) == 0) return false;
@@ -267,11 +273,11 @@ bool try_fwd_xdma(const KParams& P, const float* e, const float* t, const float*
   if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds, true)) return false;
   const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
   if (P.border == PEA_BORDER_CIRCULAR) {
-    constexpr auto kern = k_fwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, TRAIN>;
+    constexpr auto kern = k_fwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSU, false, TRAIN>;
     allow_lds<kern>(lds);
     hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, e, t, w, m, affs, gout, partials, inv_out);
   } else {
-    constexpr auto kern = k_fwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, true, TRAIN>;
+    constexpr auto kern = k_fwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSU, true, TRAIN>;
     allow_lds<kern>(lds);
     hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, e, t, w, m, affs, gout, partials, inv_out);
   }
@@ -418,8 +424,12 @@ int launch_fwd(const KParams& P, const void* e, const void* eo, const float* t, 
     if constexpr (sizeof(T) == 4) {
       // (inference keeps k_fwd_tiled: 60 us against 68 us at B=8 x 544^2 -- without the epilogue streams the one-sided
       //  box of the tiled kernel moves fewer bytes than six ring planes do)
-      if (TRAIN && P.D == 16 && op == ep)
-        done = try_fwd_xdma<TRAIN>(P, (const float*)ep, t, w, m, affs, gout, partials, inv_out, s, nparts);
+      if (TRAIN && op == ep) {
+        if (P.D == 16) done = try_fwd_xdma<16, TRAIN>(P, (const float*)ep, t, w, m, affs, gout, partials, inv_out, s, nparts);
+        else if (P.D == 32) done = try_fwd_xdma<32, TRAIN>(P, (const float*)ep, t, w, m, affs, gout, partials, inv_out, s, nparts);
+        else if (P.D == 64) done = try_fwd_xdma<64, TRAIN>(P, (const float*)ep, t, w, m, affs, gout, partials, inv_out, s, nparts);
+        if (done) return hip_rc();
+      }
     }
     if (!done && P.D == 16 && TRAIN) done = try_fwd_v<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, inv_out, s, nparts);
     if (!done && P.D == 16) done = try_fwd_tiled<T, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, inv_out, s, nparts);
@@ -805,11 +815,12 @@ int pea_affinity_fwd(const PeaDesc* desc, const void* e, const void* e_other, co
 int pea_cross_supported(const PeaDesc* desc, int backward) {
   if (validate(desc)) return 0;
   const KParams P = make_params(desc);
-  if (desc->dtype != PEA_F32 || P.D != 16 || env_int("PEA_FORCE_DIRECT", 0) != 0) return 0;
+  if (desc->dtype != PEA_F32 || (P.D != 16 && P.D != 32 && P.D != 64) || env_int("PEA_FORCE_DIRECT", 0) != 0) return 0;
   if (env_int(backward ? "PEA_BWD_XDMA" : "PEA_FWD_XDMA", 1) == 0) return 0;
   XParams C;
   size_t lds;
-  return plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds, backward == 0) ? 1 : 0;
+  if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds, backward == 0)) return 0;
+  return (backward && P.D > 32 && (C.npx > 8 || C.npy > 8)) ? 0 : 1;
 }
 
 int pea_inv_norm(const PeaDesc* desc, const void* e, float* inv_norm_out, void* stream) {
@@ -838,9 +849,13 @@ int pea_affinity_bwd_ex(const PeaDesc* desc, const void* e, const void* e_other,
   const bool h = desc->dtype == PEA_F16;
   if (!e_other) {
     // self loss: the LDS-DMA cross kernel when the 1 / norm plane came along and the stencil is axis-aligned
-    if (!h && P.D == 16 && env_int("PEA_FORCE_DIRECT", 0) == 0 &&
-        try_bwd_xdma<16>(P, (const float*)e, inv_norm, g, dloss, (float*)de, s))
-      return hip_rc();
+    if (!h && env_int("PEA_FORCE_DIRECT", 0) == 0) {
+      bool done = false;
+      if (P.D == 16) done = try_bwd_xdma<16>(P, (const float*)e, inv_norm, g, dloss, (float*)de, s);
+      else if (P.D == 32) done = try_bwd_xdma<32>(P, (const float*)e, inv_norm, g, dloss, (float*)de, s);
+      else if (P.D == 64) done = try_bwd_xdma<64>(P, (const float*)e, inv_norm, g, dloss, (float*)de, s);
+      if (done) return hip_rc();
+    }
     return h ? launch_bwd<__half>(P, 3, e, e, e, g, dloss, de, s) : launch_bwd<float>(P, 3, e, e, e, g, dloss, de, s);
   }
   if (de) {

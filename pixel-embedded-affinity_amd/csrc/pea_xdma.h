@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void k_inv_norm(const KParams P, const T* __re
 // LDS: six planes of PS = PSU * 256 bytes: buffer b in {0,1,2}, channel j of the chunk at (2b + j) * PS; the 1 / norm
 // plane starts out in plane 4 (buffer 2 is first filled after the coefficients are done).
 // AUXS: cache policy of the gradient stores (non-temporal: they must not push the halo lines out of the L2, pea_tiled.h bs_emb)
-template <int D_T, int TH, int TW, int PSU, bool CROP, int AUXS = kAuxNT>
+// XP: (offset, role) pairs per axis held in registers (<= kXP; the D = 64 instantiation takes 8 to stay inside 128 VGPRs)
+template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, int AUXS = kAuxNT>
 __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const XParams C, const float* __restrict__ xt,
                                                          const float* __restrict__ invp, const float* __restrict__ gin,
                                                          const float* __restrict__ dloss, float* __restrict__ dx) {
@@ -146,12 +147,12 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   // ---- g of every pair (role A at p, role B at p - o) and the LDS slot of every neighbour
   // dead lanes: an offset that stays out of range when a small displacement is added
   const unsigned pg = live ? po4 : 0xC0000000u;
-  float cx[kXP], cy[kXP];
-  int ax[kXP], ay[kXP];
+  float cx[XP], cy[XP];
+  int ax[XP], ay[XP];
   const int vown = ((C.hy0 + ly) * TW + lx) * 4;
   const int hrow = (C.QV * 4 + ly * C.SW) * 4;
 #pragma unroll
-  for (int k = 0; k < kXP; ++k) {
+  for (int k = 0; k < XP; ++k) {
     const int go = C.xgo[k];                       // uniform
     const int t = px + go;
     const bool out = (unsigned)t >= (unsigned)P.X;  // either side
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
     ax[k] = (unsigned)c < (unsigned)TW ? vown + d * 4 : hrow + (c & C.xm[k]) * 4;
   }
 #pragma unroll
-  for (int k = 0; k < kXP; ++k) {
+  for (int k = 0; k < XP; ++k) {
     const int go = C.ygo[k];
     const int t = py + go;
     const bool out = (unsigned)t >= (unsigned)P.Y;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   const float invo = *(const float*)(lds + 4 * PS + vown);
   const float inv_own = fabsf(invo);
 #pragma unroll
-  for (int k = 0; k < kXP; ++k) {
+  for (int k = 0; k < XP; ++k) {
     cx[k] *= fabsf(*(const float*)(lds + 4 * PS + ax[k]));
     cy[k] *= fabsf(*(const float*)(lds + 4 * PS + ay[k]));
     // computed HERE: volatile asm statements keep their order; the scheduler otherwise sinks the whole arithmetic
@@ -193,18 +194,26 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
     PEA_XDMA(xB, 5 * PS, ezo + 5u * ecs)
   }
 
-  f2 G[NP], eh[NP];
+  // D_T <= 16: the lane keeps its own normalised pixel (eh) for the projection at the end; wider embeddings have no
+  // registers for it (G alone is D_T of them): <ehat, G> is accumulated chunk by chunk and the own pixel is read again
+  // from global memory (an L2 hit: its tile was just staged) for the final (G - ehat <ehat, G>) / n
+  constexpr bool KEEP = D_T <= 16;
+  f2 G[NP], eh[KEEP ? NP : 1];
+  float proj = 0.f;
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
     const int bo = (ps % 3) * 2 * PS;
     f2 o;
     o.x = *(const float*)(lds + bo + vown);
     o.y = *(const float*)(lds + bo + PS + vown);
-    eh[ps] = o * inv_own;
-    asm volatile("" : "+v"(eh[ps]));
+    o = o * inv_own;
+    if (KEEP) {
+      eh[ps] = o;
+      asm volatile("" : "+v"(eh[ps]));
+    }
     f2 acc = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < kXP; ++k) {
+    for (int k = 0; k < XP; ++k) {
       f2 v;
       v.x = *(const float*)(lds + bo + ax[k]);
       v.y = *(const float*)(lds + bo + PS + ax[k]);
@@ -212,12 +221,16 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       if (k % 5 == 4) asm volatile("" ::: "memory");  // bound the ds_read hoisting
     }
 #pragma unroll
-    for (int k = 0; k < kXP; ++k) {
+    for (int k = 0; k < XP; ++k) {
       f2 v;
       v.x = *(const float*)(lds + bo + ay[k]);
       v.y = *(const float*)(lds + bo + PS + ay[k]);
       acc = __builtin_elementwise_fma((f2){cy[k], cy[k]}, v, acc);
       if (k % 5 == 4) asm volatile("" ::: "memory");
+    }
+    if (!KEEP) {
+      proj = fmaf(o.x, acc.x, fmaf(o.y, acc.y, proj));
+      asm volatile("" : "+v"(proj));
     }
     asm volatile("" : "+v"(acc));  // the chunk's sums exist before its barrier
     G[ps] = acc;
@@ -234,15 +247,20 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
 #undef PEA_XDMA
 #undef PEA_XWAIT1
 
-  float proj = 0.f;
+  if (KEEP) {
 #pragma unroll
-  for (int ps = 0; ps < NP; ++ps) proj = fmaf(eh[ps].x, G[ps].x, fmaf(eh[ps].y, G[ps].y, proj));
+    for (int ps = 0; ps < NP; ++ps) proj = fmaf(eh[ps].x, G[ps].x, fmaf(eh[ps].y, G[ps].y, proj));
+  }
   if (invo < 0.f) proj = 0.f;  // clamp branch of F.normalize
   const float sc = dl * inv_own;
+  const float pn = proj * inv_own;  // !KEEP: ehat * proj = e * (inv_own * proj)
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (G[ps].x - eh[ps].x * proj) * sc), dB, pe, ezo + (unsigned)(2 * ps) * ecs, AUXS);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (G[ps].y - eh[ps].y * proj) * sc), dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs, AUXS);
+    float ex, ey;
+    if (KEEP) { ex = eh[ps].x * proj; ey = eh[ps].y * proj; }
+    else { ex = bl32(xB, pe, ezo + (unsigned)(2 * ps) * ecs) * pn; ey = bl32(xB, pe, ezo + (unsigned)(2 * ps + 1) * ecs) * pn; }
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (G[ps].x - ex) * sc), dB, pe, ezo + (unsigned)(2 * ps) * ecs, AUXS);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (G[ps].y - ey) * sc), dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs, AUXS);
   }
 }
 
@@ -484,7 +502,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
 inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, size_t* lds_bytes, bool fwd = false) {
   if (P.border == PEA_BORDER_REPLICATE) return false;
   if ((long long)P.Y * P.X >= (1LL << 28)) return false;                           // plane byte offsets + displacement < 2^31
-  if ((long long)(P.D > P.K ? P.D : P.K) * P.S * 4 > 0xFFFFFFFFLL) return false;   // 32-bit buffer soffset
+  if ((long long)(P.D > P.K ? P.D : P.K) * P.S * 4 >= (1LL << 31)) return false;   // soffset counts in the range check (plan_tiles)
   if (P.X % 4 || P.S % 4) return false;                                            // quads never straddle a row end
   XParams C = {};
   int hx = 0, hy = 0;

@@ -144,8 +144,11 @@ def test_cross_kernels_cover_the_shipped_2d_shapes(pkg, lib):
         assert q(desc(16, 37, 72, cv[:8], B=2), bwd) == 1         # golden g2d_x_k8
         assert q(desc(16, 544, 544, cv, border=1), bwd) == 1      # CROP_ZERO
         assert q(desc(16, 544, 544, pkg.multi_offset([1, 3, 9], 8)), bwd) == 0   # diagonal offsets
-        assert q(desc(32, 544, 544, cv), bwd) == 0
+        assert q(desc(32, 704, 704, pkg.multi_offset([1, 3, 5, 9, 11], 4)), bwd) == 1   # BASELINE configs[2]
+        assert q(desc(64, 544, 544, cv[:8]), bwd) == 1                                  # configs[4] in f32
+        assert q(desc(8, 544, 544, cv), bwd) == 0                                       # D not in {16, 32, 64}
         assert q(desc(16, 544, 544, cv, dtype=1), bwd) == 0       # f16 storage
         assert q(desc(16, 544, 542, cv), bwd) == 0                # X % 4 != 0
         assert q(desc(16, 40, 56, cv, B=2), bwd) == 0             # narrower than a tile plus its strips
     assert q(desc(16, 34, 34, cv[:2]), 0) == 0
+    assert q(desc(64, 544, 544, cv), 0) == 1 and q(desc(64, 544, 544, cv), 1) == 0    # D = 64 backward: at most 8 pairs per axis

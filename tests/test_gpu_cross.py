@@ -59,13 +59,16 @@ CASES = [
     (1, 80, 160, [2, 4, 16], 6, 1, 2, False, False, 1.0),             # even shifts, reach 16 (the widest 32-pixel strip row)
     (2, 33, 68, [1], 2, 0, 0, True, False, 1.0),                      # K = 2
     (1, 96, 200, [1, 3, 5, 9, 27], 9, 0, 0, True, False, 1.0),        # odd K: x reaches 27, y only 9 (asymmetric cross)
+    (2, 48, 96, [1, 3, 5, 9, 11], 10, 0, 0, True, False, 0.5, 32),    # D = 32 (BBBC039V1 stencil): 16 chunks, own pixel re-read at the end
+    (1, 50, 100, [1, 3, 5, 9, 27], 8, 0, 0, True, True, 1.0, 64),     # D = 64, offsets[:8]
+    (1, 64, 128, [1, 3, 5, 9, 27], 8, 1, 1, False, False, 2.0, 32),   # D = 32, CROP_ZERO
 ]
 
 
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_cross_kernels_vs_oracle(pkg, dev, orc, synth, case):
-    B, Y, X, shifts, K, border, norm, use_mask, relu, dloss = CASES[case]
-    D, dims = 16, [1, Y, X]
+    B, Y, X, shifts, K, border, norm, use_mask, relu, dloss = CASES[case][:10]
+    D, dims = (CASES[case][10] if len(CASES[case]) > 10 else 16), [1, Y, X]
     offs = [[0] + o for o in pkg.multi_offset(shifts, 4)][:K]
     lam = [1.0 + 0.25 * (i % 3) for i in range(K)]
     e, t, w, m = _inputs(synth, B, D, dims, K, 7 * case, zero_px=(case == 0))

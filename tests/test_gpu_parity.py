@@ -181,7 +181,8 @@ def test_baseline_config_b8_properties(pkg, dev, synth):
     inf = pkg.embedding2affs(E[:1], offsets)
     inf_r = pkg.embedding2affs(torch.roll(E[:1], shifts=(13, -29), dims=(2, 3)), offsets)
     assert torch.equal(torch.roll(inf, shifts=(13, -29), dims=(2, 3)), inf_r)
-    assert torch.equal(inf, a1[:1])
+    # inference runs k_fwd_tiled (normalise, then dot), training k_fwd_xdma (raw dot, then the two norms): same map to rounding
+    assert float((inf - a1[:1]).abs().max()) < 2e-6
     # |a| <= 1 (cosine) and the zero offset would be exactly ~1
     assert float(a1.abs().max()) <= 1.0 + 1e-5
 
