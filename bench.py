@@ -55,6 +55,49 @@ def algorithmic_bytes_per_px(D, K, es=4, mask=True):
     return {"fwd": fwd, "bwd": bwd, "step": fwd + bwd}
 
 
+def train_leg(pkg, dev, world, rank, dist, shared, fence, b=2, steps=8, warm=3):
+    """BASELINE.json's second metric: train imgs/s of a full step at this N -- the ResidualUNet2D_deep backbone (plain PyTorch-ROCm,
+    4.7 M parameters, model/unet2d_residual.py) forward + EMA forward + the labels-in loss section on the HIP kernels + backward +
+    Adam, one rank per GPU under DistributedDataParallel over RCCL (bucketed gradient all-reduce overlapped with the backward;
+    per-rank BatchNorm, as the reference's DataParallel has it).  b images of 544x544 per GPU (cvppp.yaml batch_size 2), weak scaling,
+    synthetic images and instance labels.  Time = max over ranks of `steps` steps between barriers."""
+    import importlib
+    mod = importlib.import_module(ge.PKG_NAME + ".model.unet2d_residual")
+    ts = importlib.import_module(ge.PKG_NAME + ".harness.train_step")
+    synth = importlib.import_module(ge.PKG_NAME + ".utils.synth")
+    torch.manual_seed(555)
+    net = mod.ResidualUNet2D_deep(in_channels=3, out_channels=2, nfeatures=[16, 32, 64, 128, 256], emd=16).to(dev)
+    model = net
+    if dist is not None:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        # the mask head takes no part in the shipped loss (mask_weight / ct_weight 0): its parameters never get a gradient
+        DDP._set_params_and_buffers_to_ignore_for_model(net, [n for n, _ in net.named_parameters() if n.startswith("binary_seg.")]
+                                                        + [n for n, _ in net.named_buffers() if n.startswith("binary_seg.")])
+        model = DDP(net, device_ids=None if shared else [dev.index], broadcast_buffers=False, gradient_as_bucket_view=True)
+    stepper = ts.CvpppTrainStep(model, ts.make_optimizer(net))
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    x = torch.randn(b, 3, H, W, generator=g, device=dev)
+    x_ema = x + 0.1 * torch.randn(b, 3, H, W, generator=g, device=dev)
+    labels = torch.from_numpy(synth.synth_labels(b, (1, H, W), 555 + rank)[:, 0].copy()).to(dev).to(torch.int32)
+    for _ in range(warm):
+        stepper.step(x, x_ema, labels)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = stepper.step(x, x_ema, labels)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return {"train_imgs_per_s": round(world * b * steps / dt, 2), "train_step_ms": round(dt / steps * 1e3, 3),
+            "train_config": {"model": "ResidualUNet2D_deep [16,32,64,128,256] emd 16 (PyTorch-ROCm) + HIP heads + labels-in loss section",
+                             "images_per_gpu": b, "steps": steps, "optimizer": "Adam(amsgrad)",
+                             "parallelism": ("ddp%d over RCCL" % world) if (dist is not None and not shared) else ("ddp%d over gloo (shared device)" % world if dist is not None else "single GPU"),
+                             "loss": float(loss.item())}}
+
+
 def other_config(args, pkg, dev, world, rank, dist, fence):
     """--config c3 | c4 | c4n26 | c5: same step timing, roofline (from the entry points' in-step HIP-event durations) and a
     bounded cpu_baseline; inputs are drawn on the GPU (torch.Generator, seed 555 + rank): N(0,1) embeddings,
@@ -248,6 +291,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="images per GPU")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="c2 = the headline workload (default); c3 / c4 / c4n26 / c5: see CONFIGS")
+    ap.add_argument("--no-train", action="store_true", help="skip the train imgs/s leg (backbone + DDP)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-section", action="store_true",
                     help="skip the multi-scale loss-section timings (profiling runs: per-kernel averages then cover the full-size launches only)")
@@ -335,6 +379,7 @@ def main():
         dt = float(tmax.item())
     px_per_step = world * B * H * W
     value = px_per_step * args.steps / dt / 1e6
+    train = None if args.no_train else train_leg(pkg, dev, world, rank, dist, shared, fence)
 
     out = None
     if rank == 0:
@@ -446,6 +491,7 @@ def main():
             # pixels are counted on the padded tensor the op processes (544^2 per CVPPP image); the same rate in
             # images and in pixels of the un-padded 530x500 image
             "settle_steps": settle,
+            **(train or {}),
             "images_per_s_op_only": round(value * 1e6 / (H * W), 1),
             "value_530x500_equiv": round(value * (530 * 500) / (H * W), 2),
             "kernel_ms": {k: round(v, 5) for k, v in kt.items()},

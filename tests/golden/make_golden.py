@@ -232,6 +232,19 @@ def case_head(name, seed, B, C, D, spatial, bias=True):
          db=(conv.bias.grad.numpy() if conv.bias is not None else np.zeros(0, np.float32)))
 
 
+def case_model(name, seed, shape, nfeatures, emd):
+    """the reference's ResidualUNet2D_deep (scripts_cvppp/model/unet2d_residual.py:279-353) with small widths: its state_dict
+    (the layout checkpoints are saved in), a seeded input and the six outputs in training mode (BatchNorm on batch statistics)"""
+    refmodel = load("ref_unet2d", "scripts_cvppp/model/unet2d_residual.py")
+    torch.manual_seed(seed)
+    net = refmodel.ResidualUNet2D_deep(in_channels=3, out_channels=2, nfeatures=nfeatures, emd=emd)
+    x = torch.randn(*shape)
+    outs = net(x)
+    sd = {"sd/" + k: v.detach().numpy() for k, v in net.state_dict().items()}
+    save(name, x=x.numpy(), nfeatures=np.array(nfeatures), emd=np.int32(emd), keys=np.array(list(net.state_dict().keys())),
+         **{"out%d" % i: o.detach().numpy() for i, o in enumerate(outs)}, **sd)
+
+
 def case_full_summary(name, seed, B, D, H, W):
     """One full-size CVPPP case (B x 16 x 544 x 544, K=10): too big to store, so inputs are a closed-form
     function of the index (no RNG) and only summary statistics + samples of the outputs are kept."""
@@ -278,6 +291,10 @@ if __name__ == "__main__":
         case_head("ghead_2d_c64_d32", 62, B=1, C=64, D=32, spatial=(9, 31))
         case_head("ghead_3d_c28_d16", 63, B=1, C=28, D=16, spatial=(3, 10, 13))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "model":  # only the backbone layout fixtures
+        case_model("gmodel_resunet2d", 81, (2, 3, 48, 64), [4, 8, 12, 16, 20], 16)
+        case_model("gmodel_resunet2d_odd", 82, (1, 3, 40, 40), [4, 6, 8, 10, 12], 16)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cross":  # only the fixtures sized for the LDS-DMA cross kernels (pea_xdma.h)
         torch.manual_seed(0)
         case_2d("g2d_x_k10", 71, B=1, D=16, H=50, W=100, shifts=[1, 3, 5, 9, 27], nb=4, zero_px=True)
@@ -321,3 +338,5 @@ if __name__ == "__main__":
     case_head("ghead_2d_c32_d16", 61, B=2, C=32, D=16, spatial=(19, 23))
     case_head("ghead_2d_c64_d32", 62, B=1, C=64, D=32, spatial=(9, 31))
     case_head("ghead_3d_c28_d16", 63, B=1, C=28, D=16, spatial=(3, 10, 13))
+    case_model("gmodel_resunet2d", 81, (2, 3, 48, 64), [4, 8, 12, 16, 20], 16)
+    case_model("gmodel_resunet2d_odd", 82, (1, 3, 40, 40), [4, 6, 8, 10, 12], 16)

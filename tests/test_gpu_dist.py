@@ -1,0 +1,136 @@
+"""GPU (-m gpu): the multi-GPU path with the HIP kernels as the per-rank op.  Two fresh child processes share the one device of
+the test box (control plane over gloo: a second RCCL rank needs a second GPU); each runs embedding_loss forward + backward on
+ITS shard of the batch through libpea_hip.so, a shared 'backbone' parameter's gradient and the logged losses are averaged over
+ranks the DDP way (utils/shard.py), and rank 0 compares with the same HIP op on the full batch: the sharding identity of
+SURVEY.md section 8e.  Also: one DDP training step of the real backbone (harness/train_step.py) on 2 ranks keeps the replicas'
+parameters identical and equals the single-process step on the concatenated batch."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import __graft_entry__ as ge
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = ge.load_package()
+        synth = importlib.import_module(ge.PKG_NAME + ".utils.synth")
+        sh = importlib.import_module(ge.PKG_NAME + ".utils.shard")
+        dev = torch.device("cuda:0")
+        offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+        B, D, H, W = 4, 16, 64, 128  # wide enough for the cross kernels
+        e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 31)
+        crit = pkg.WeightedMSE()
+
+        def run(lo, hi):
+            # one shared "backbone" parameter: embedding = x + theta * v (theta * x alone would not do: the loss is invariant
+            # to the scale of the embedding, its gradient w.r.t. a global scale is exactly 0)
+            theta = torch.tensor(0.7, device=dev, requires_grad=True)
+            x = torch.from_numpy(e[lo:hi]).to(dev)
+            v = torch.roll(x, shifts=(3, 5), dims=(1, 3))
+            loss, affs, parts = pkg.embedding_loss(x + theta * v, *(torch.from_numpy(a[lo:hi]).to(dev) for a in (t, w, m)), crit, offsets)
+            loss.backward()
+            return theta.grad.detach().cpu().double().reshape(1), torch.cat([loss.detach().reshape(1), parts.tensor]).cpu().double()
+
+        lo, hi = sh.shard_range(B, rank, world)
+        dtheta, logged = run(lo, hi)
+        sh.allreduce_mean_([dtheta, logged])
+        if rank == 0:
+            dtheta_full, logged_full = run(0, B)
+            out.put(("op", logged.numpy(), logged_full.numpy(), float(dtheta), float(dtheta_full)))
+
+        # ---- one DDP step of the real backbone on the shards vs the same step on the full batch in one process
+        mod = importlib.import_module(ge.PKG_NAME + ".model.unet2d_residual")
+        ts = importlib.import_module(ge.PKG_NAME + ".harness.train_step")
+        from torch.nn.parallel import DistributedDataParallel as DDP
+
+        def build():
+            torch.manual_seed(7)
+            net = mod.ResidualUNet2D_deep(nfeatures=[4, 8, 8, 16, 16], emd=16).to(dev)
+            for mm in net.modules():  # BatchNorm on batch statistics differs between a shard and the full batch: freeze it
+                if isinstance(mm, torch.nn.BatchNorm2d):
+                    mm.eval()
+            return net
+
+        Hs, Ws = 96, 128
+        gen = torch.Generator().manual_seed(11)
+        xs = torch.randn(B, 3, Hs, Ws, generator=gen)
+        xe = xs + 0.1 * torch.randn(B, 3, Hs, Ws, generator=gen)
+        lab = torch.from_numpy(synth.synth_labels(B, (1, Hs, Ws), 5)[:, 0].copy()).to(torch.int32)
+
+        class Frozen(ts.CvpppTrainStep):
+            def step(self, *a, **k):  # keep BatchNorm in eval mode (model.train() would switch it back)
+                train = self.model.train
+                self.model.train = lambda *aa, **kk: self.model
+                try:
+                    return super().step(*a, **k)
+                finally:
+                    self.model.train = train
+
+        net = build()
+        DDP._set_params_and_buffers_to_ignore_for_model(net, [n for n, _ in net.named_parameters() if n.startswith("binary_seg.")])
+        ddp = DDP(net, broadcast_buffers=False)
+        st = Frozen(ddp, torch.optim.SGD(net.parameters(), lr=0.1), shifts=(1, 2, 3, 5, 9), neighbor=4)
+        st.step(xs[lo:hi].to(dev), xe[lo:hi].to(dev), lab[lo:hi].to(dev))
+        torch.cuda.synchronize()
+        mine = torch.cat([p.detach().flatten() for n, p in net.named_parameters() if not n.startswith("binary_seg.")]).cpu()
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        if rank == 0:
+            ref = build()
+            sr = Frozen(ref, torch.optim.SGD(ref.parameters(), lr=0.1), shifts=(1, 2, 3, 5, 9), neighbor=4)
+            sr.step(xs.to(dev), xe.to(dev), lab.to(dev))
+            full = torch.cat([p.detach().flatten() for n, p in ref.named_parameters() if not n.startswith("binary_seg.")]).cpu()
+            out.put(("ddp", float((both[0] - both[1]).abs().max()), float((mine - full).abs().max()), float(full.abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_hip_kernels_sharding_identity_and_ddp_step():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    import queue
+    import time
+    t0 = time.time()
+    while len(res) < 2 and time.time() - t0 < 200:
+        try:
+            r = out.get(timeout=2)
+            res[r[0]] = r[1:]
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break  # a rank died: do not sit out the timeout on the GPU box
+    assert len(res) == 2, "a rank failed: exit codes %s" % [p.exitcode for p in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    logged, logged_full, dtheta, dtheta_full = res["op"]
+    np.testing.assert_allclose(logged, logged_full, rtol=2e-6)
+    assert abs(dtheta - dtheta_full) <= 2e-5 * abs(dtheta_full)
+    replica_gap, ddp_vs_full, scale = res["ddp"]
+    assert replica_gap == 0.0                   # the all-reduced gradients are identical on both ranks
+    assert ddp_vs_full <= 2e-5 * max(scale, 1)  # and equal the full-batch step (local normalisers average to the global one)
