@@ -18,7 +18,6 @@
  *                          scripts_ac3ac4/loss/loss_embedding_mse.py:169-194 embedding_loss_norm5
  *                          scripts_ac3ac4/loss/loss_embedding_mse.py:30-51,263-289 ema_..._norm1/5
  *                          with loss/loss.py:106-124 WeightedMSE (same in all three script trees) fused in
- *   pea_affinity_fwd_bwd <- pea_affinity_fwd and pea_affinity_bwd of the same call in one launch (default criterion)
  *   pea_affinity_bwd    <- the torch.autograd backward of the functions above (also the vjp for foreign criteria)
  *                          (the reference has no explicit backward; loss.backward() at
  *                          scripts_cvppp/main.py:311, scripts_ac3ac4/main.py:232)
@@ -158,22 +157,9 @@ int pea_cross_supported(const PeaDesc *desc, int backward);
 int pea_affinity_bwd_dual(const PeaDesc *desc, const void *e, const void *ema, const float *g, const float *g_cross,
                           const float *dloss, const float *dloss_cross, void *de, void *stream);
 
-/* Training step in ONE launch (the fused WeightedMSE path): the outputs of pea_affinity_fwd -- affs (nullable) and
- * loss_out[1 + K] -- and de = dloss * d loss / d e (same dtype / layout as e) without the g round trip through HBM.
- * Replaces, for the default criterion, the pair embedding_loss(...) + loss.backward()
- * (scripts_cvppp/main.py:284-293,311; scripts_ac3ac4/main.py:219-232).  e_other: NULL (self loss) or the DETACHED
- * second operand (ema_embedding_loss after convert_consistency_flip, scripts_cvppp/data/data_consistency.py:36);
- * a second operand that needs its own gradient takes pea_affinity_fwd + pea_affinity_bwd.  dloss: device scalar or
- * NULL (= 1; scale later with pea_scale_inplace).  Returns PEA_E_UNSUPPORTED when no fused kernel covers the
- * descriptor (D != 16, stencil too wide for the LDS tile): call pea_affinity_fwd + pea_affinity_bwd instead.
- * workspace: as pea_affinity_fwd. */
-int pea_affinity_fwd_bwd(const PeaDesc *desc, const void *e, const void *e_other, const float *target,
-                         const float *weight, const uint8_t *mask, float *affs, float *loss_out, const float *dloss,
-                         void *de, void *workspace, size_t workspace_bytes, void *stream);
-
 /* buf[0..n) *= scale[0] in place (dtype PEA_F32 / PEA_F16; f32 buffers 16-byte aligned).  `scale` is a DEVICE scalar
  * (autograd's grad_output): the kernel reads it and returns without touching buf when it is exactly 1, which is
- * what a plain loss.backward() hands to the gradient pea_affinity_fwd_bwd produced for dloss = 1. */
+ * what a plain loss.backward() hands to the gradient pea_affinity_fwd_bwd_labels produced for dloss = 1. */
 int pea_scale_inplace(void *buf, int dtype, size_t n, const float *scale, void *stream);
 /* the same for up to 8 buffers (host arrays of device pointers / element counts) in one launch: the gradients of one loss
  * section share their grad_output */
@@ -206,7 +192,9 @@ int pea_gen_targets(const PeaDesc *desc, const int32_t *labels, unsigned flags, 
 /* ---- the training step from labels: no target / weight / mask tensors at all (SURVEY.md section 8f, f2 fused) ----
  * pea_label_weights: wtab [B,K,2] f32 = { weight of target-1 pixels, weight of target-0 pixels } per (image, channel), i.e.
  * weight_binary_ratio(lb_affs[i]) (scripts_cvppp/data/data_segmentation.py:205-228) as two scalars; integer counts in
- * `workspace` (pea_targets_workspace_bytes).  pea_affinity_fwd_bwd_labels: pea_affinity_fwd_bwd with
+ * `workspace` (pea_targets_workspace_bytes).  pea_affinity_fwd_bwd_labels: the outputs of pea_affinity_fwd (affs, nullable, and
+ * loss_out[1 + K]) AND de = dloss * d loss / d e in ONE launch -- no g round trip through HBM; e_other = NULL (self loss) or
+ * the DETACHED second operand; dloss = device scalar or NULL (= 1: scale later with pea_scale_inplace) -- with
  *   target_i(q) = [label(q) == label(q + o_i)] (flags as pea_gen_targets), mask_i(q) = [q + o_i inside] with
  *   PEA_TGT_MASK_INSIDE else 1, weight_i(q) = target ? wtab[b][i][0] : wtab[b][i][1]
  * evaluated inside the kernel: results equal (to rounding) to pea_gen_targets + pea_affinity_fwd + pea_affinity_bwd.

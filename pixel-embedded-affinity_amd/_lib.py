@@ -24,7 +24,7 @@ FLAG_RELU_AFFS = 1
 TGT_PADDING, TGT_BOTH_FOREGROUND, TGT_MASK_INSIDE, TGT_ACCUMULATE = 1, 2, 4, 8
 
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",
-           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_ex", "pea_affinity_bwd_ex", "pea_inv_norm", "pea_cross_supported", "pea_affinity_bwd_dual", "pea_affinity_fwd_bwd", "pea_scale_inplace", "pea_scale_inplace_multi", "pea_fill_border_relu", "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd",
+           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_ex", "pea_affinity_bwd_ex", "pea_inv_norm", "pea_cross_supported", "pea_affinity_bwd_dual", "pea_scale_inplace", "pea_scale_inplace_multi", "pea_fill_border_relu", "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd",
            "pea_targets_workspace_bytes", "pea_gen_targets", "pea_stitch_add", "pea_stitch_finalize",
            "pea_label_weights", "pea_affinity_fwd_bwd_labels", "pea_affinity_fwd_bwd_labels_dual")
 
@@ -108,8 +108,6 @@ def lib():
     L.pea_inv_norm.argtypes = [dp, vp, vp, vp]
     L.pea_affinity_bwd_dual.restype = ctypes.c_int
     L.pea_affinity_bwd_dual.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp]
-    L.pea_affinity_fwd_bwd.restype = ctypes.c_int
-    L.pea_affinity_fwd_bwd.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.pea_scale_inplace.restype = ctypes.c_int
     L.pea_scale_inplace.argtypes = [vp, ctypes.c_int, ctypes.c_size_t, vp, vp]
     L.pea_targets_workspace_bytes.restype = ctypes.c_size_t

@@ -136,20 +136,12 @@ def affinity_infer(e, e_other, spec):
     return affs
 
 
-def _fused_enabled():
-    return os.environ.get("PEA_FUSED", "0") == "1"
-
-
 class FusedAffinityMSE(torch.autograd.Function):
-    """loss, affs, per_offset_losses = f(e, e_other, target, weight, mask).
-
-    Default: one forward launch (saving g = d loss / d affs) and one backward launch.
-    With PEA_FUSED=1, when e needs a gradient (and e_other does not), the forward is ONE launch of
-    pea_affinity_fwd_bwd that also produces d loss / d e for grad_output = 1; backward() multiplies it by the actual
-    grad_output in place (pea_scale_inplace returns without touching it when that is exactly 1, the loss.backward()
-    case).  Measured at the CVPPP bench shape the one launch takes as long as the two (295 vs 294 us: both are bound
-    by the issue rate of one-dword vector-memory instructions, and sampling target / weight / mask at p and p - o
-    costs what the g round trip saved), so it is opt-in: it moves 35 % fewer HBM bytes and needs no g buffer."""
+    """loss, affs, per_offset_losses = f(e, e_other, target, weight, mask): the WeightedMSE criterion fused into the affinity
+    forward.  One forward launch (saving g = d loss / d affs and, for the self loss, the 1 / norm plane of e) and one backward
+    launch.  (Round 1 also had an opt-in one-launch step on this tensor path, PEA_FUSED=1; it sampled target / weight / mask at
+    p and at p - o with one-dword loads, only ever tied the two launches and is gone -- the one-launch step that pays is the
+    labels-in one, LabelsAffinityMSE below.)"""
 
     @staticmethod
     def forward(ctx, e, e_other, target, weight, mask, spec):
@@ -180,37 +172,24 @@ class FusedAffinityMSE(torch.autograd.Function):
             loss_vec = torch.empty(1 + spec.K, dtype=torch.float32, device=e_c.device)
             wsb = L.pea_workspace_bytes(ctypes.byref(d))
             work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=e_c.device)
-            de_unit = g = inv = None
-            if want_e and not want_o and _fused_enabled():
-                de_unit = torch.empty_like(e_c)
-                rc = L.pea_affinity_fwd_bwd(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(target), _ptr(weight), _ptr(mask),
-                                            _ptr(affs), _ptr(loss_vec), None, _ptr(de_unit), _ptr(work), wsb, _stream())
-                if rc == _lib.E_UNSUPPORTED:
-                    de_unit = None
-                else:
-                    _lib.check(rc, "pea_affinity_fwd_bwd")
-            if de_unit is None:
-                # g = d loss / d affs is all the backward needs besides the embeddings; skip it when nothing trains
-                g = torch.empty(kshape, dtype=torch.float32, device=e_c.device) if (want_e or want_o) else None
-                # 1 / norm of e, 4 bytes per pixel: what the cross backward (self loss, axis-aligned stencil) stages next to e
-                inv = (torch.empty((e_c.shape[0],) + tuple(e_c.shape[2:]), dtype=torch.float32, device=e_c.device)
-                       if (want_e and o_c is None) else None)
-                _lib.check(L.pea_affinity_fwd_ex(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(target), _ptr(weight), _ptr(mask),
-                                                 _ptr(affs), _ptr(g), _ptr(inv), _ptr(loss_vec), _ptr(work), wsb, _stream()),
-                           "pea_affinity_fwd_ex")
+            # g = d loss / d affs is all the backward needs besides the embeddings; skip it when nothing trains
+            g = torch.empty(kshape, dtype=torch.float32, device=e_c.device) if (want_e or want_o) else None
+            # 1 / norm of e, 4 bytes per pixel: what the cross backward (self loss, axis-aligned stencil) stages next to e
+            inv = (torch.empty((e_c.shape[0],) + tuple(e_c.shape[2:]), dtype=torch.float32, device=e_c.device)
+                   if (want_e and o_c is None) else None)
+            _lib.check(L.pea_affinity_fwd_ex(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(target), _ptr(weight), _ptr(mask),
+                                             _ptr(affs), _ptr(g), _ptr(inv), _ptr(loss_vec), _ptr(work), wsb, _stream()),
+                       "pea_affinity_fwd_ex")
         ctx.spec, ctx.desc = spec, d
         ctx.has_other = o_c is not None
-        ctx.de_unit = de_unit
-        # fused path: keep the operands (references, no copies) so that a SECOND backward over a retained graph
-        # can rebuild g the two-launch way after the first one has scaled de_unit in place
-        ctx.save_for_backward(e_c, o_c, g, inv, *((target, weight, mask) if de_unit is not None else (None, None, None)))
+        ctx.save_for_backward(e_c, o_c, g, inv)
         loss, per_offset = loss_vec[0], loss_vec[1:]  # views of a buffer that is not itself returned
         ctx.mark_non_differentiable(affs, per_offset)
         return loss, affs, per_offset
 
     @staticmethod
     def backward(ctx, dloss, _daffs, _dvec):
-        e_c, o_c, g, inv, target, weight, mask = ctx.saved_tensors
+        e_c, o_c, g, inv = ctx.saved_tensors
         want_e = ctx.needs_input_grad[0]
         want_o = ctx.has_other and ctx.needs_input_grad[1]
         if not (want_e or want_o) or dloss is None:
@@ -220,17 +199,6 @@ class FusedAffinityMSE(torch.autograd.Function):
         with torch.cuda.device(e_c.device):
             L = _lib.lib()
             dl = dloss.to(device=e_c.device, dtype=torch.float32).contiguous()
-            if ctx.de_unit is not None:
-                de, ctx.de_unit = ctx.de_unit, None
-                _lib.check(L.pea_scale_inplace(_ptr(de), ctx.desc.dtype, de.numel(), _ptr(dl), _stream()), "pea_scale_inplace")
-                return de, None, None, None, None, None
-            if g is None:  # second backward of a fused forward (retain_graph): rebuild g
-                g = torch.empty(_affs_shape(e_c, ctx.spec.K), dtype=torch.float32, device=e_c.device)
-                loss_vec = torch.empty(1 + ctx.spec.K, dtype=torch.float32, device=e_c.device)
-                wsb = L.pea_workspace_bytes(ctypes.byref(ctx.desc))
-                work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=e_c.device)
-                _lib.check(L.pea_affinity_fwd(ctypes.byref(ctx.desc), _ptr(e_c), _ptr(o_c), _ptr(target), _ptr(weight), _ptr(mask),
-                                              None, _ptr(g), _ptr(loss_vec), _ptr(work), wsb, _stream()), "pea_affinity_fwd (rebuild g)")
             de = torch.empty_like(e_c) if want_e else None
             de_o = torch.empty_like(o_c) if want_o else None
             _lib.check(L.pea_affinity_bwd_ex(ctypes.byref(ctx.desc), _ptr(e_c), _ptr(o_c), _ptr(g), _ptr(inv), _ptr(dl), _ptr(de),

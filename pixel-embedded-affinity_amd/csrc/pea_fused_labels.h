@@ -2,9 +2,9 @@
 // launch, with target / mask / weight never materialised ("removes target / weight /
 // mask reads from the op entirely if fused").
 //
-// k_fused_tiled (pea_fused.h) has to sample target, weight and mask at p and at p - o: 60 one-dword loads per pixel and
-// 300 MB of HBM over-fetch at the bench shape, which is why it only ties the two-launch path.  From an int32 label
-// image the same quantities are
+// A one-launch step on the TENSOR path (round 1's k_fused_tiled, since removed) has to sample target, weight and mask at p and
+// at p - o: 60 one-dword loads per pixel and 300 MB of HBM over-fetch at the bench shape; it only ever tied the two-launch
+// path and loses to it now (273 us against 107 + 97 us).  From an int32 label image the same quantities are
 //     t_i(q) = [label(q) == label(q + o_i)]          (and both > 0 with PEA_TGT_BOTH_FOREGROUND; neighbour outside the
 //     m_i(q) = [q + o_i inside the image]             image: t = PEA_TGT_PADDING ? 1 : 0, exactly pea_gen_targets)
 //     w_i(q) = t_i(q) ? wpos[b][i] : wneg[b][i]      (class balance: two scalars per (image, channel), pea_label_weights)

@@ -23,7 +23,6 @@
 
 #include "pea_direct.h"
 #include "pea_tiled.h"
-#include "pea_fused.h"
 #include "pea_targets.h"
 #include "pea_fused_labels.h"
 #include "pea_head.h"
@@ -124,17 +123,15 @@ int device_cus() {
 // ------------------------------------------------------------------------------------------------
 struct TileCfg { int TH, TW, PLQ; };  // workgroup = TH*TW lanes (one per pixel); PLQ = LDS plane stride in pixels
 // compiled-in shapes; index chosen by PEA_FWD_CFG / PEA_BWD_CFG (defaults = the measured best, CVPPP stencil)
-constexpr TileCfg kFwdV_decl = {32, 32, 1697};
-constexpr TileCfg kFwdCfg[] = {{16, 32, 1041}, {32, 32, 1697}, {8, 64, 1249}};
-constexpr TileCfg kBwdCfg[] = {{32, 32, 2505}, {16, 32, 1713}};
-constexpr int kNumFwdCfg = sizeof(kFwdCfg) / sizeof(kFwdCfg[0]), kNumBwdCfg = sizeof(kBwdCfg) / sizeof(kBwdCfg[0]);
+// compiled-in tile shapes (the measured best of the round-1 sweep at the CVPPP stencil; the losing shapes are gone)
+constexpr TileCfg kFwdCfg[] = {{16, 32, 1041}};
+constexpr TileCfg kBwdCfg[] = {{32, 32, 2505}};
 // D = 32: 128 B of LDS per region pixel, so one shape: 16x32 tiles, 1041 region pixels (133 KB, one workgroup of 8 waves per CU)
 constexpr TileCfg kCfg32 = {16, 32, 1041};
 template <int D_T> constexpr TileCfg fwd_cfg(int ci) { return D_T == 32 ? kCfg32 : kFwdCfg[ci]; }
 constexpr TileCfg kCfg32B = {16, 32, 1093};  // backward: two-sided halo of 5 (26 x 42 region pixels, 140 KB)
 template <int D_T> constexpr TileCfg bwd_cfg(int ci) { return D_T == 32 ? kCfg32B : kBwdCfg[ci]; }
-template <int D_T> constexpr TileCfg fwdv_cfg(bool ovl) { return D_T == 32 ? kCfg32 : (ovl ? TileCfg{16, 32, 1041} : TileCfg{32, 32, 1697}); }
-constexpr int kFwdDefault = 0, kBwdDefault = 0;
+template <int D_T> constexpr TileCfg fwdv_cfg() { return D_T == 32 ? kCfg32 : TileCfg{16, 32, 1041}; }
 constexpr int kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may take all of it
 
 // Choose the "near" offsets (served from LDS): the largest in-plane radius whose halo'd region still fits the
@@ -152,10 +149,8 @@ bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, TParams* Q) {
   for (int i = 0; i < P.K; ++i)
     if (P.off[i][0] == 0) radii[nr++] = std::max(abs(P.off[i][1]), abs(P.off[i][2]));
   std::sort(radii, radii + nr);
-  const int rcap = env_int("PEA_NEAR_R", 1 << 30);
   for (int k = nr - 1; k >= 0; --k) {
     const int rc = radii[k];
-    if (rc > rcap) continue;
     TParams q = {};
     unsigned near_mask = 0;
     for (int i = 0; i < P.K; ++i) {
@@ -193,7 +188,7 @@ bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, TParams* Q) {
     }
     q.zrun = 0;
     for (int k = 0; k < q.n_far; ++k)
-      if (q.far[k].d != 0 && P.Z > 1 && env_int("PEA_ZFAST", 1) != 0) q.zrun = P.Z;
+      if (q.far[k].d != 0 && P.Z > 1) q.zrun = P.Z;
     *Q = q;
     return true;
   }
@@ -219,8 +214,6 @@ size_t fwd_partials(const KParams& P) {
     TParams q;
     if (plan_tiles(P, c, false, &q)) n = std::max(n, (size_t)q.ntiles);
   }
-  TParams qv;
-  if (plan_tiles(P, kFwdV_decl, false, &qv)) n = std::max(n, (size_t)qv.ntiles);  // (the 16x32 shape is in kFwdCfg)
   n = std::max(n, (size_t)((P.Y + 15) / 16) * ((P.X + 31) / 32) * P.Z * P.B);      // the LDS-DMA forward's 16x32 tiles
   return n;
 }
@@ -306,21 +299,19 @@ void launch_fwd_cfg(const KParams& P, const TParams& Q, const T* e, const T* eo,
   }
 }
 
-// forward with the LDS-transposed, dwordx4 epilogue (k_fwd_tiled_v): the default when its preconditions hold
-constexpr TileCfg kFwdV = kFwdV_decl;       // 32x32 tile, dot products next to the region: 1 workgroup of 16 waves per CU
-constexpr TileCfg kFwdVO = {16, 32, 1041};  // 16x32 tile, dot products laid over the region: 2 workgroups of 8 waves per CU
-
-template <typename T, int D_T, bool TRAIN, bool SELF, bool OVL>
+// forward with the LDS-transposed, dwordx4 epilogue (k_fwd_tiled_v): 16x32 tiles, the dot products laid over the dead region,
+// two workgroups of 8 waves per CU.  The training forward wherever the LDS-DMA kernel (k_fwd_xdma) does not apply.
+template <typename T, int D_T, bool TRAIN, bool SELF>
 void launch_fwd_v(const KParams& P, const TParams& Q, size_t lds, const T* e, const T* eo, const float* t, const float* w,
                   const uint8_t* m, float* affs, float* gout, float* partials, float* inv_out, hipStream_t s) {
-  constexpr TileCfg c = fwdv_cfg<D_T>(OVL);
+  constexpr TileCfg c = fwdv_cfg<D_T>();
   const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(c.TH * c.TW);
   if (P.border == PEA_BORDER_CIRCULAR) {
-    constexpr auto kern = k_fwd_tiled_v<T, D_T, c.TH, c.TW, c.PLQ, OVL, false, TRAIN, SELF>;
+    constexpr auto kern = k_fwd_tiled_v<T, D_T, c.TH, c.TW, c.PLQ, true, false, TRAIN, SELF>;
     allow_lds<kern>(lds);
     hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials, inv_out);
   } else {
-    constexpr auto kern = k_fwd_tiled_v<T, D_T, c.TH, c.TW, c.PLQ, OVL, true, TRAIN, SELF>;
+    constexpr auto kern = k_fwd_tiled_v<T, D_T, c.TH, c.TW, c.PLQ, true, true, TRAIN, SELF>;
     allow_lds<kern>(lds);
     hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, e, eo, t, w, m, affs, gout, partials, inv_out);
   }
@@ -329,27 +320,19 @@ void launch_fwd_v(const KParams& P, const TParams& Q, size_t lds, const T* e, co
 template <typename T, int D_T, bool TRAIN>
 bool try_fwd_v(const KParams& P, const T* e, const T* eo, const float* t, const float* w, const uint8_t* m, float* affs,
                float* gout, float* partials, float* inv_out, hipStream_t s, int* nparts) {
-  if (env_int("PEA_FWD_V", 1) == 0) return false;
   if (P.K > kKV || P.X % 4) return false;
   if (misaligned(t, 16) || misaligned(w, 16) || misaligned(affs, 16) || misaligned(gout, 16) || misaligned(m, 4)) return false;
   if ((P.tbs | P.wbs | P.mbs | (long long)P.S) & 3) return false;
-  const bool ovl = D_T == 32 || env_int("PEA_FWD_OVL", 1) != 0;
-  const TileCfg c = fwdv_cfg<D_T>(ovl);
+  const TileCfg c = fwdv_cfg<D_T>();
   const size_t tp = (size_t)c.TH * c.TW;
   const size_t region = Lds<D_T, 1>::kBytes * (size_t)c.PLQ, dots = (size_t)P.K * tp * 4, parts = (size_t)P.K * (tp / 256) * 4;
-  if (ovl && dots > region) return false;
-  const size_t lds = ovl ? region + parts : region + dots + parts;
+  if (dots > region) return false;
+  const size_t lds = region + parts;
   if (lds > (size_t)kLdsMax) return false;
   TParams Q;
   if (!plan_tiles(P, c, false, &Q) || Q.n_near > kKV || Q.n_far > kFV) return false;
-  const bool self = eo == e;
-  if (ovl) {
-    if (self) launch_fwd_v<T, D_T, TRAIN, true, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, inv_out, s);
-    else launch_fwd_v<T, D_T, TRAIN, false, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, inv_out, s);
-  } else {
-    if (self) launch_fwd_v<T, D_T, TRAIN, true, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, inv_out, s);
-    else launch_fwd_v<T, D_T, TRAIN, false, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, inv_out, s);
-  }
+  if (eo == e) launch_fwd_v<T, D_T, TRAIN, true>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, inv_out, s);
+  else launch_fwd_v<T, D_T, TRAIN, false>(P, Q, lds, e, eo, t, w, m, affs, gout, partials, inv_out, s);
   *nparts = Q.ntiles;
   return true;
 }
@@ -358,18 +341,10 @@ bool try_fwd_v(const KParams& P, const T* e, const T* eo, const float* t, const 
 template <typename T, int D_T, bool TRAIN>
 bool try_fwd_tiled(const KParams& P, const T* e, const T* eo, const float* t, const float* w, const uint8_t* m, float* affs,
                    float* gout, float* partials, float* inv_out, hipStream_t s, int* nparts) {
-  const int ci = env_int("PEA_FWD_CFG", kFwdDefault);
-  if (ci < 0 || ci >= kNumFwdCfg) return false;
   TParams Q;
-  if (!plan_tiles(P, fwd_cfg<D_T>(ci), false, &Q)) return false;
-  const bool self = (eo == e);
-#define PEA_FWD_CASE(CI)                                                                             \
-  case CI:                                                                                           \
-    if (self) launch_fwd_cfg<T, D_T, TRAIN, true, CI>(P, Q, e, eo, t, w, m, affs, gout, partials, inv_out, s); \
-    else launch_fwd_cfg<T, D_T, TRAIN, false, CI>(P, Q, e, eo, t, w, m, affs, gout, partials, inv_out, s);     \
-    break;
-  switch (ci) { PEA_FWD_CASE(0) PEA_FWD_CASE(1) PEA_FWD_CASE(2) default: return false; }
-#undef PEA_FWD_CASE
+  if (!plan_tiles(P, fwd_cfg<D_T>(0), false, &Q)) return false;
+  if (eo == e) launch_fwd_cfg<T, D_T, TRAIN, true, 0>(P, Q, e, eo, t, w, m, affs, gout, partials, inv_out, s);
+  else launch_fwd_cfg<T, D_T, TRAIN, false, 0>(P, Q, e, eo, t, w, m, affs, gout, partials, inv_out, s);
   *nparts = Q.ntiles;
   return true;
 }
@@ -396,7 +371,7 @@ void launch_fwd_chunked(const KParams& P, const TParams& Q, size_t lds, const T*
 template <typename T, int D_T, int DC, bool TRAIN>
 bool try_fwd_chunked(const KParams& P, const T* e, const T* eo, const float* t, const float* w, const uint8_t* m, float* affs,
                      float* gout, float* partials, hipStream_t s, int* nparts) {
-  if (P.D != D_T || env_int("PEA_FWD_CHUNKED", 1) == 0) return false;
+  if (P.D != D_T) return false;
   constexpr TileCfg c = kCfg32;
   TParams Q;
   if (!plan_tiles(P, c, false, &Q) || Q.n_near > kChN || Q.n_far > kChF) return false;
@@ -437,7 +412,7 @@ int launch_fwd(const KParams& P, const void* e, const void* eo, const float* t, 
     if (inv_out) launch_inv_norm<T>(P, ep, inv_out, s);  // the kernels below do not write the plane themselves
     // 64 B of LDS per region pixel: two workgroups per CU.  Self loss / inference only: with a second operand the
     // 128-VGPR budget of that occupancy spills (and see pea_chunked.h on spill stores), so EMA calls keep the one-region kernels
-    if (P.D == 32 && env_int("PEA_FWD_CHUNKED32", 1) != 0)
+    if (P.D == 32)
       done = try_fwd_chunked<T, 32, 16, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, s, nparts);
     if (!done && P.D == 32 && TRAIN) done = try_fwd_v<T, 32, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, nullptr, s, nparts);
     if (!done && P.D == 32) done = try_fwd_tiled<T, 32, TRAIN>(P, ep, op, t, w, m, affs, gout, partials, nullptr, s, nparts);
@@ -480,15 +455,10 @@ void launch_bwd_cfg(const KParams& P, const TParams& Q, const T* x, const T* nb,
 
 template <typename T, int D_T, bool RA, bool RB>
 bool try_bwd_tiled(const KParams& P, const T* x, const T* nb, const float* g, const float* dl, T* dx, hipStream_t s) {
-  const int ci = env_int("PEA_BWD_CFG", kBwdDefault);
-  if (ci < 0 || ci >= kNumBwdCfg) return false;
   TParams Q;
   // role A alone (a detached second operand's cross loss) reaches only p + o: a one-sided halo; role B needs p - o
-  if (!plan_tiles(P, bwd_cfg<D_T>(ci), !(RA && !RB), &Q)) return false;
-#define PEA_BWD_CASE(CI) \
-  case CI: launch_bwd_cfg<T, D_T, RA, RB, CI>(P, Q, x, nb, g, dl, dx, s); break;
-  switch (ci) { PEA_BWD_CASE(0) PEA_BWD_CASE(1) default: return false; }
-#undef PEA_BWD_CASE
+  if (!plan_tiles(P, bwd_cfg<D_T>(0), !(RA && !RB), &Q)) return false;
+  launch_bwd_cfg<T, D_T, RA, RB, 0>(P, Q, x, nb, g, dl, dx, s);
   return true;
 }
 
@@ -525,30 +495,8 @@ int launch_bwd(const KParams& P, int roles, const void* x, const void* nbA, cons
 
 
 // ------------------------------------------------------------------------------------------------
-// fused forward + backward dispatch (pea_fused.h): same tile plan as the tiled backward
+// training step from labels (pea_fused_labels.h): same tile plan as the tiled backward
 // ------------------------------------------------------------------------------------------------
-template <typename T, int D_T, bool RB>
-bool try_fused(const KParams& P, const T* x, const T* nb, const float* t, const float* w, const uint8_t* m, float* affs,
-               float* partials, const float* dl, T* dx, hipStream_t s, int* nparts) {
-  constexpr TileCfg c = kBwdCfg[0];
-  TParams Q;
-  if (!plan_tiles(P, c, RB, &Q)) return false;
-  const size_t lds = Lds<D_T, c.PLQ>::kBytes + (size_t)(c.TH * c.TW / 64) * P.K * sizeof(float);
-  if (lds > (size_t)kLdsMax) return false;
-  const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(c.TH * c.TW);
-  if (P.border == PEA_BORDER_CIRCULAR) {
-    constexpr auto kern = k_fused_tiled<T, D_T, c.TH, c.TW, c.PLQ, false, RB>;
-    allow_lds<kern>(lds);
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, x, nb, t, w, m, affs, partials, dl, dx);
-  } else {
-    constexpr auto kern = k_fused_tiled<T, D_T, c.TH, c.TW, c.PLQ, true, RB>;
-    allow_lds<kern>(lds);
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, Q, x, nb, t, w, m, affs, partials, dl, dx);
-  }
-  *nparts = Q.ntiles;
-  return true;
-}
-
 template <typename T, int D_T, bool RB>
 bool try_fused_labels(const KParams& P, const T* x, const T* nb, const int32_t* labels, const float* wtab, unsigned lflags,
                       float* affs, float* partials, const float* dl, T* dx, hipStream_t s, int* nparts) {
@@ -871,39 +819,6 @@ int pea_affinity_bwd_ex(const PeaDesc* desc, const void* e, const void* e_other,
 int pea_affinity_bwd(const PeaDesc* desc, const void* e, const void* e_other, const float* g, const float* dloss,
                      void* de, void* de_other, void* stream) {
   return pea_affinity_bwd_ex(desc, e, e_other, g, nullptr, dloss, de, de_other, stream);
-}
-
-int pea_affinity_fwd_bwd(const PeaDesc* desc, const void* e, const void* e_other, const float* target,
-                         const float* weight, const uint8_t* mask, float* affs, float* loss_out, const float* dloss,
-                         void* de, void* workspace, size_t workspace_bytes, void* stream) {
-  int rc = validate(desc);
-  if (rc) return rc;
-  if (!e || !target || !weight || !loss_out || !de) return PEA_E_NULL;
-  const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
-  if (misaligned(e, es) || misaligned(e_other, es) || misaligned(de, es) || misaligned(affs, 4) || misaligned(target, 4) ||
-      misaligned(weight, 4) || misaligned(loss_out, 4) || misaligned(dloss, 4) || misaligned(workspace, 4))
-    return PEA_E_ALIGN;
-  const KParams P = make_params(desc);
-  if (!workspace || workspace_bytes < ws_bytes(fwd_partials(P), P.K)) return PEA_E_WORKSPACE;
-  if (P.D != 16 || env_int("PEA_FORCE_DIRECT", 0) != 0) return PEA_E_UNSUPPORTED;  // caller: pea_affinity_fwd + pea_affinity_bwd
-  hipStream_t s = (hipStream_t)stream;
-  float* partials = (float*)workspace;
-  int nparts = 0;
-  bool done;
-  if (desc->dtype == PEA_F16) {
-    const __half *x = (const __half*)e, *nb = (const __half*)e_other;
-    done = nb ? try_fused<__half, 16, false>(P, x, nb, target, weight, mask, affs, partials, dloss, (__half*)de, s, &nparts)
-              : try_fused<__half, 16, true>(P, x, x, target, weight, mask, affs, partials, dloss, (__half*)de, s, &nparts);
-  } else {
-    const float *x = (const float*)e, *nb = (const float*)e_other;
-    done = nb ? try_fused<float, 16, false>(P, x, nb, target, weight, mask, affs, partials, dloss, (float*)de, s, &nparts)
-              : try_fused<float, 16, true>(P, x, x, target, weight, mask, affs, partials, dloss, (float*)de, s, &nparts);
-  }
-  if (!done) return PEA_E_UNSUPPORTED;
-  rc = hip_rc();
-  if (rc) return rc;
-  launch_loss_finalize(P, partials, nparts, loss_out, s);
-  return hip_rc();
 }
 
 int pea_scale_inplace(void* buf, int dtype, size_t n, const float* scale, void* stream) {

@@ -44,7 +44,6 @@ fns = {
     "gentgt": lambda: L.pea_gen_targets(ctypes.byref(desc), P(LAB), 1, P(T), P(M), P(Wt), P(CNT), CNTB, st),
     "labw": lambda: L.pea_label_weights(ctypes.byref(desc), P(LAB), 5, P(WTAB), P(CNT), CNTB, st),
     "labels": lambda: L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(E), None, P(LAB), P(WTAB), 5, P(affs), P(lossv), None, P(dE), P(work), wsb, st),
-    "fused": lambda: L.pea_affinity_fwd_bwd(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), P(lossv), None, P(dE), P(work), wsb, st),
     "fwd": lambda: L.pea_affinity_fwd(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), P(G), P(lossv), P(work), wsb, st),
     "bwd": lambda: L.pea_affinity_bwd(ctypes.byref(desc), P(E), None, P(G), P(one), P(dE), None, st),
     "inf": lambda: L.pea_affinity_infer(ctypes.byref(desc), P(E), None, P(affs), st),

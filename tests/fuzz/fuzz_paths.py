@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised agreement sweep over the alternative paths to the same numbers:
   (a) the labels-in step (embedding_loss_from_labels / ema_...) against gen_targets + the tensor path,
-  (b) the one-launch step (PEA_FUSED=1) against forward + backward,
+  (b) the LDS-DMA cross kernels against the tiled kernels (PEA_FWD_XDMA / PEA_BWD_XDMA = 0) on the tensor path,
   (c) the embedding head against torch's GPU convolution (every supported channel pair, ragged pixel counts),
   (d) the six-loss section as one autograd node and from labels against its call-by-call composition.
 usage: fuzz_paths.py [cases] [seed]; exits non-zero on a disagreement."""
@@ -67,19 +67,19 @@ for it in range(ncase):
     dg = rel(res[1][2], res[0][2])
     note("labels", da < 1e-5 and dl < 1e-5 and dg < tol_g, ctx, affs=da, loss=dl, grad=dg)
 
-    # ---- (b) one launch against two (self loss or detached EMA)
+    # ---- (b) cross kernels (where the dispatch takes them: f32, axis-aligned, wide enough) against the tiled kernels
     res = []
-    for fused in ("0", "1"):
-        os.environ["PEA_FUSED"] = fused
+    for xdma in ("0", "1"):
+        os.environ["PEA_FWD_XDMA"] = os.environ["PEA_BWD_XDMA"] = xdma
         et = e.clone().requires_grad_(True)
         out = pkg.ema_embedding_loss(et, ema, t, w, m, crit, offsets) if ema is not None else pkg.embedding_loss(et, t, w, m, crit, offsets)
         (out[0] * 0.5).backward()
         res.append((out[0].item(), out[1], et.grad))
-    os.environ["PEA_FUSED"] = "0"
+    os.environ.pop("PEA_FWD_XDMA"); os.environ.pop("PEA_BWD_XDMA")
     da = float((res[0][1] - res[1][1]).abs().max())
     dl = abs(res[0][0] - res[1][0]) / max(abs(res[0][0]), 1e-9)
     dg = rel(res[1][2], res[0][2])
-    note("fused", da < 1e-5 and dl < 1e-5 and dg < tol_g, ctx, affs=da, loss=dl, grad=dg)
+    note("cross", da < 1e-5 and dl < 1e-5 and dg < tol_g, ctx, affs=da, loss=dl, grad=dg)
 
     # ---- (c) head against torch's convolution
     D_h = int(rng.choice([16, 32]))

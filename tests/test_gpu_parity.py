@@ -388,59 +388,16 @@ def test_tiled_and_direct_kernels_agree(pkg, dev, synth, monkeypatch):
     assert relmax(g1, g0) < 1e-5
 
 
-@pytest.mark.parametrize("case", ["2d_self", "2d_ema", "3d_norm5", "2d_f16"])
-def test_fused_launch_agrees_with_two_launches(pkg, dev, orc, synth, monkeypatch, case):
-    """pea_affinity_fwd_bwd (one launch, PEA_FUSED=1) against the default pea_affinity_fwd +
-    pea_affinity_bwd: loss, per-offset losses, affs and the gradient, with grad_output != 1"""
-    crit = pkg.WeightedMSE()
-
-    def run():
-        if case == "3d_norm5":
-            B, D, Z, Y, X = 2, 16, 5, 72, 76
-            e, t, w = synth.synth_inputs_3d(B, D, Z, Y, X, orc.norm_offsets([1, 1, 1, 2, 3, 3, 3, 9, 9, 4, 27, 27]), 41)
-            et = cu(e, dev).requires_grad_(True)
-            loss, affs = pkg.embedding_loss_norm5(et, cu(t, dev), cu(w, dev), crit, affs0_weight=2)
-            parts = None
-        else:
-            offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
-            B, D, H, W = 3, 16, 80, 136
-            e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 43)
-            if case == "2d_f16":
-                et = torch.from_numpy(e.astype(np.float16)).to(dev).requires_grad_(True)
-            else:
-                et = cu(e, dev).requires_grad_(True)
-            if case == "2d_ema":
-                ema = cu(np.roll(e, 5, axis=1).copy(), dev)
-                loss, affs = pkg.ema_embedding_loss(et, ema, cu(t, dev), cu(w, dev), cu(m, dev), crit, offsets, affs0_weight=3)
-                parts = None
-            else:
-                loss, affs, parts = pkg.embedding_loss(et, cu(t, dev), cu(w, dev), cu(m, dev), crit, offsets)
-        (loss * 0.75).backward()
-        return loss.item(), affs.cpu().numpy(), et.grad.float().cpu().numpy(), (None if parts is None else list(parts))
-
-    monkeypatch.delenv("PEA_FUSED", raising=False)
-    l0, a0, g0, p0 = run()
-    monkeypatch.setenv("PEA_FUSED", "1")
-    l1, a1, g1, p1 = run()
-    assert abs(l1 - l0) <= 2e-6 * abs(l0)
-    assert np.abs(a1 - a0).max() < 2e-6
-    assert relmax(g1, g0) < (2e-3 if case == "2d_f16" else 1e-5)
-    if p0 is not None:
-        np.testing.assert_allclose(p1, p0, rtol=2e-6)
-
-
-def test_fused_second_backward_over_retained_graph(pkg, dev, synth, monkeypatch):
-    """the fused forward hands its gradient buffer to the first backward; a second backward over a retained graph
-    rebuilds g the two-launch way and must give the same gradient again (scaled by the new grad_output)"""
-    monkeypatch.setenv("PEA_FUSED", "1")
-    offsets = pkg.multi_offset([1, 3, 9], 4)
-    e, t, w, m = synth.synth_inputs_2d(2, 16, 64, 96, offsets, 47)
+def test_second_backward_over_retained_graph(pkg, dev, synth):
+    """a second backward over a retained graph reuses the saved g (and 1 / norm plane): twice the grad_output, twice the gradient"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    e, t, w, m = synth.synth_inputs_2d(2, 16, 64, 128, offsets, 47)
     et = cu(e, dev).requires_grad_(True)
-    loss, _, _ = pkg.embedding_loss(et, cu(t, dev), cu(w, dev), cu(m, dev), pkg.WeightedMSE(), offsets)
+    loss, affs, _ = pkg.embedding_loss(et, cu(t, dev), cu(w, dev), cu(m, dev), pkg.WeightedMSE(), offsets)
     (g1,) = torch.autograd.grad(loss, et, retain_graph=True)
     g1 = g1.clone()
     (g2,) = torch.autograd.grad(loss * 2.0, et)
-    assert relmax(g2.cpu().numpy(), 2.0 * g1.cpu().numpy()) < 1e-5
+    assert relmax(g2.cpu().numpy(), 2.0 * g1.cpu().numpy()) < 1e-6
 
 
 @pytest.mark.parametrize("ema", [False, True])
