@@ -9,6 +9,7 @@ Reference behaviour mirrored (file:line in the reference tree):
   * embedding_loss_norm1/5, ema_*, inf_*                        scripts_ac3ac4/loss/loss_embedding_mse.py:7-289
   * WeightedMSE normaliser                                      scripts_cvppp/loss/loss.py:112-119
 """
+import collections.abc
 import ctypes
 import os
 
@@ -240,35 +241,65 @@ class AffinityMap(torch.autograd.Function):
         return de, de_o, None
 
 
-class LossList(list):
+class LossList(collections.abc.Sequence):
     """The reference's `all_loss` (a list of K Python floats filled by K `.item()` syncs,
-    scripts_cvppp/loss/loss_embedding_mse.py:41) without the syncs: a list whose floats are fetched
-    from the device tensor on first access."""
+    scripts_cvppp/loss/loss_embedding_mse.py:41) without the syncs: a read-only sequence whose floats are fetched from the
+    device tensor on first access (one copy).  A Sequence, not a list subclass: C-level list operations would read the empty
+    underlying storage of a lazily filled list (`all_loss + [x]`, `==`, copy, pickle); here every one of them goes through
+    __getitem__ / __len__, and + / == against lists are defined to behave like the list the reference returns."""
 
     def __init__(self, dev_tensor):
-        super(LossList, self).__init__()
         self.tensor = dev_tensor
-        self._filled = False
+        self._vals = None
 
     def _fill(self):
-        if not self._filled:
-            self._filled = True
-            super(LossList, self).extend(self.tensor.tolist())
+        if self._vals is None:
+            self._vals = self.tensor.tolist()
+        return self._vals
 
     def __len__(self):
         return self.tensor.numel()
 
     def __getitem__(self, i):
-        self._fill()
-        return super(LossList, self).__getitem__(i)
+        return self._fill()[i]
 
     def __iter__(self):
-        self._fill()
-        return super(LossList, self).__iter__()
+        return iter(self._fill())
 
     def __repr__(self):
-        self._fill()
-        return super(LossList, self).__repr__()
+        return repr(self._fill())
+
+    def __eq__(self, other):
+        return list(self) == list(other) if isinstance(other, (list, tuple, LossList)) else NotImplemented
+
+    def __add__(self, other):
+        return list(self) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self)
+
+    def __reduce__(self):
+        return (list, (self._fill(),))  # copies / pickles as the plain list of floats
+
+
+def labels_offsets_in_range(spec, e):
+    """False when an offset reaches past the image (|o| >= dim): torch.roll folds such an offset modulo the dimension, which is
+    what the tensor path's descriptor does, but the reference's gen_affs_ours (scripts_cvppp/utils/affinity_ours.py:17-39)
+    shifts the LABEL image by the true offset -- every neighbour is then outside, mask 0, loss 0.  The labels-in kernels
+    derive target / mask from the descriptor's (folded) offset, so they must not be used there: the *_from_labels wrappers
+    fall back to gen_targets (true offsets) + the tensor path."""
+    dims = _spatial(e, spec.ndim)
+    return all(abs(o[a]) < dims[a] for o in spec.offsets for a in range(3))
+
+
+def _labels_int32(labels):
+    """segmentation ids as the kernels take them (int32).  Wider ids are range-checked first: a silent cast would turn an id
+    >= 2^31 negative (background for BOTH_FOREGROUND) and make ids that agree modulo 2^32 compare equal."""
+    if labels.dtype in (torch.int64, torch.uint64) and labels.numel():
+        lo, hi = int(labels.min()), int(labels.max())
+        if lo < -2 ** 31 or hi >= 2 ** 31:
+            raise ValueError("label ids must fit int32 (got %d .. %d): relabel the segmentation first" % (lo, hi))
+    return labels.to(torch.int32).contiguous()
 
 
 class LabelsStepUnsupported(NotImplementedError):
@@ -294,7 +325,10 @@ class LabelsAffinityMSE(torch.autograd.Function):
         _require_gpu(labels, "labels")
         if labels.dtype.is_floating_point or tuple(labels.shape) != (e_c.shape[0],) + tuple(e_c.shape[2:]):
             raise ValueError("labels must be an integer tensor of shape %s" % ((e_c.shape[0],) + tuple(e_c.shape[2:]),))
-        lab = labels.to(torch.int32).contiguous()
+        lab = _labels_int32(labels)
+        if not labels_offsets_in_range(spec, e_c):
+            raise LabelsStepUnsupported("an offset is as long as the image: the labels-in kernels would fold it (torch.roll) where "
+                                        "gen_affs_ours masks it out; use gen_targets + the tensor API")
         kshape = _affs_shape(e_c, spec.K)
         with torch.cuda.device(e_c.device):
             d = make_desc(spec, e_c)

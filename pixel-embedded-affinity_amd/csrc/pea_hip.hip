@@ -104,18 +104,14 @@ int env_int(const char* name, int dflt) {
 
 bool misaligned(const void* p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
 
+// CUs of the CURRENT device (asked every time: the reference runs replicas under nn.DataParallel threads, one device each, so a
+// process-wide cache of the first device's answer would be wrong for the others, and a static would not be thread-safe)
 int device_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      n = v;
-    else
-      n = 256;
-    (void)hipGetLastError();
-  }
-  return n;
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+    return v;
+  (void)hipGetLastError();
+  return 256;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -195,13 +191,13 @@ bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, TParams* Q) {
   return false;
 }
 
+// Raise the kernel's dynamic-LDS limit above the 64 KB default.  Asked for on every launch that needs it: the attribute is
+// kept per device, so a cached "already raised" flag of the first device would leave the launch on a second device of the
+// same process failing; the call is a host-side table update (no state of ours, thread-safe).  A failure surfaces through
+// hip_rc() after the launch.
 template <auto KERNEL>
 void allow_lds(size_t bytes) {
-  static size_t cur = 64 * 1024;
-  if (bytes > cur) {
-    (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    cur = bytes;
-  }
+  if (bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 // workspace = [K][fwd_partials] f32 loss partials

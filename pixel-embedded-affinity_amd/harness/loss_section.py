@@ -138,7 +138,7 @@ class _TensorSection(torch.autograd.Function):
             fork.join()
             losses = rows[:, 0]
             total = (losses * wdev).sum()
-        ctx.grads = grads
+        ctx.grads, ctx.n_embs = grads, len(embs)
         ctx.mark_non_differentiable(pred, losses)
         return total, pred, losses
 
@@ -146,9 +146,12 @@ class _TensorSection(torch.autograd.Function):
 
 
 def _section_backward(ctx, dtotal):
-    n = len(ctx.grads) if ctx.grads else 0
-    if dtotal is None or not ctx.grads:
+    n = ctx.n_embs
+    if dtotal is None:
         return (None, None, None, None) + (None,) * n
+    if ctx.grads is None:
+        raise RuntimeError("the loss section hands its gradient buffers to the first backward; for a second backward over a "
+                           "retained graph use cvppp_loss_section_composed (one autograd node per loss)")
     grads, ctx.grads = ctx.grads, None
     L = _lib.lib()
     dev = grads[0].device
@@ -377,7 +380,7 @@ class _LabelsSection(torch.autograd.Function):
 
             def prep(j):
                 e_c = op._embedding_arg(embs[j], "embedding")
-                lab = labels_list[j].to(torch.int32).contiguous()
+                lab = op._labels_int32(labels_list[j])
                 d = op.make_desc(specs[j], e_c)
                 cb = L.pea_targets_workspace_bytes(ctypes.byref(d))
                 counts = torch.empty(max(cb, 4) // 4, dtype=torch.int32, device=dev)
@@ -447,7 +450,7 @@ class _LabelsSection(torch.autograd.Function):
             fork.join()
             losses = rows[:, 0]
             total = (losses * wdev).sum()
-        ctx.grads = grads
+        ctx.grads, ctx.n_embs = grads, len(embs)
         ctx.mark_non_differentiable(pred, losses)
         return total, pred, losses
 
@@ -479,7 +482,7 @@ def cvppp_label_weight_tables(labels, label_downs, offsets, nb_half, dis_mode='o
     tables = []
     for j, lab in enumerate([labels] + list(label_downs)):
         op._require_gpu(lab, "labels")
-        lab = lab.to(torch.int32).contiguous()
+        lab = op._labels_int32(lab)
         like = torch.empty((lab.shape[0], 16) + tuple(lab.shape[1:]), device="meta")  # geometry only
         d = op.make_desc(specs[j], like)
         with torch.cuda.device(lab.device):

@@ -11,7 +11,7 @@ import ctypes
 import torch
 
 from .. import _lib
-from ..affinity_op import AffinitySpec, make_desc
+from ..affinity_op import _labels_int32, AffinitySpec, make_desc
 
 
 def gen_targets(labels, offsets, padding=True, both_foreground=False, want_mask=True, want_weight=True):
@@ -24,7 +24,7 @@ def gen_targets(labels, offsets, padding=True, both_foreground=False, want_mask=
     if labels.dim() not in (3, 4):
         raise ValueError("labels must be [B,H,W] or [B,Z,Y,X], got %s" % (tuple(labels.shape),))
     ndim = labels.dim() - 1
-    lab = labels.to(torch.int32).contiguous()
+    lab = _labels_int32(labels)
     spec = AffinitySpec(ndim, offsets, None, _lib.BORDER_CROP_ZERO, _lib.NORM_FULL)
     # make_desc reads B / D / spatial dims off an embedding-shaped tensor: a meta tensor carries just the shape
     shape_probe = torch.empty((lab.shape[0], 1) + tuple(lab.shape[1:]), dtype=torch.float32, device="meta")

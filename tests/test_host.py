@@ -106,5 +106,33 @@ def test_descriptor_building(pkg):
 
 def test_loss_list_is_lazy(pkg):
     ll = pkg.affinity_op.LossList(torch.tensor([0.5, 0.25, 0.125]))
-    assert len(ll) == 3 and not ll._filled
+    assert len(ll) == 3 and ll._vals is None
     assert ll[1] == 0.25 and list(ll) == [0.5, 0.25, 0.125]
+
+
+def test_loss_list_behaves_like_the_reference_list(pkg):
+    """all_loss is a list of K floats in the reference (loss_embedding_mse.py:41); the lazy stand-in must survive what callers do
+    with such a list: len, indexing, iteration, == / + against lists, copy, pickle"""
+    import copy
+    import pickle
+    import torch
+    ll = pkg.affinity_op.LossList(torch.tensor([0.5, 1.5, 2.0]))
+    assert len(ll) == 3 and ll[1] == 1.5 and list(ll) == [0.5, 1.5, 2.0] and sum(ll) == 4.0
+    assert ll == [0.5, 1.5, 2.0] and ll + [7.0] == [0.5, 1.5, 2.0, 7.0] and [7.0] + ll == [7.0, 0.5, 1.5, 2.0]
+    assert copy.copy(ll) == [0.5, 1.5, 2.0] and pickle.loads(pickle.dumps(ll)) == [0.5, 1.5, 2.0]
+    assert repr(ll) == "[0.5, 1.5, 2.0]" and 1.5 in ll
+
+
+def test_label_ids_are_range_checked_before_the_int32_cast(pkg):
+    import torch
+    ok = pkg.affinity_op._labels_int32(torch.tensor([[0, 5, 2 ** 31 - 1]], dtype=torch.int64))
+    assert ok.dtype == torch.int32 and ok.tolist() == [[0, 5, 2 ** 31 - 1]]
+    with pytest.raises(ValueError, match="fit int32"):
+        pkg.affinity_op._labels_int32(torch.tensor([[0, 2 ** 31]], dtype=torch.int64))
+
+
+def test_labels_in_path_refuses_offsets_as_long_as_the_image(pkg):
+    import torch
+    spec = pkg.AffinitySpec(2, [[-1, 0], [0, -40]], None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX)
+    assert not pkg.affinity_op.labels_offsets_in_range(spec, torch.zeros(1, 16, 64, 34))
+    assert pkg.affinity_op.labels_offsets_in_range(spec, torch.zeros(1, 16, 64, 48))
