@@ -226,25 +226,39 @@ void launch_inv_norm(const KParams& P, const T* e, float* inv, hipStream_t s) {
 
 // the cross backward (self loss, f32 storage, axis-aligned in-plane stencil): needs the 1 / norm plane
 constexpr int kXdmaTH = 16, kXdmaTW = 32, kXdmaPSU = 51;
+constexpr int kXdmaPSU3 = 52;  // 3D instantiations: whole 64-quad blocks (13 KB planes), 6 x 13312 B = 78 KB, still two workgroups per CU
 template <int D_T>
 bool try_bwd_xdma(const KParams& P, const float* x, const float* inv, const float* g, const float* dl, float* dx, hipStream_t s) {
   if (!inv || env_int("PEA_BWD_XDMA", 1) == 0) return false;
   if (misaligned(x, 16) || misaligned(inv, 16) || misaligned(g, 4) || misaligned(dx, 4)) return false;
   XParams C;
   size_t lds;
-  if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds)) return false;
-  constexpr int XP = D_T > 32 ? 8 : kXP;  // pairs per axis the instantiation keeps in registers
-  if (C.npx > XP || C.npy > XP) return false;
-  const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
-  if (P.border == PEA_BORDER_CIRCULAR) {
-    constexpr auto kern = k_bwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSU, false, XP>;
-    allow_lds<kern>(lds);
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, dx);
-  } else {
-    constexpr auto kern = k_bwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSU, true, XP>;
-    allow_lds<kern>(lds);
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, dx);
+  bool z3 = false;
+  if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds)) {
+    if (D_T != 16 || !plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU3, &C, &lds) || C.npz == 0) return false;
+    z3 = true;
+  } else if (C.npz > 0) {
+    if (D_T != 16 || !plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU3, &C, &lds)) return false;
+    z3 = true;
   }
+  constexpr int XP = D_T > 32 ? 8 : kXP;  // pairs per axis the instantiation keeps in registers
+  if (C.npx > (z3 ? 8 : XP) || C.npy > (z3 ? 8 : XP)) return false;
+  const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+#define PEA_XB(CROP_, XP_, PSU_, ZP_)                                                                  \
+  {                                                                                                    \
+    constexpr auto kern = k_bwd_xdma<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, XP_, kAuxNT, ZP_>;            \
+    allow_lds<kern>(lds);                                                                              \
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, dx);                              \
+  }
+  const bool crop = P.border != PEA_BORDER_CIRCULAR;
+  if constexpr (D_T == 16) {
+    if (z3) {
+      if (crop) PEA_XB(true, 8, kXdmaPSU3, kXZ) else PEA_XB(false, 8, kXdmaPSU3, kXZ)
+      return true;
+    }
+  }
+  if (crop) PEA_XB(true, XP, kXdmaPSU, 0) else PEA_XB(false, XP, kXdmaPSU, 0)
+#undef PEA_XB
   return true;
 }
 
@@ -259,17 +273,32 @@ bool try_fwd_xdma(const KParams& P, const float* e, const float* t, const float*
   if (TRAIN && ((P.tbs | P.wbs | P.mbs) & 3)) return false;
   XParams C;
   size_t lds;
-  if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds, true)) return false;
-  const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
-  if (P.border == PEA_BORDER_CIRCULAR) {
-    constexpr auto kern = k_fwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSU, false, TRAIN>;
-    allow_lds<kern>(lds);
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, e, t, w, m, affs, gout, partials, inv_out);
-  } else {
-    constexpr auto kern = k_fwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSU, true, TRAIN>;
-    allow_lds<kern>(lds);
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, e, t, w, m, affs, gout, partials, inv_out);
+  bool z3 = false;
+  if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds, true) || C.nfz > 0) {
+    if (D_T != 16 || !plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU3, &C, &lds, true) || C.nfz == 0) return false;
+    z3 = true;
   }
+  if (!z3 && P.K > kXP) return false;
+  if (z3 && P.K > kXP + 2) return false;
+  const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+#define PEA_XF(CROP_, PSU_, ZF_)                                                                       \
+  {                                                                                                    \
+    constexpr auto kern = k_fwd_xdma<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, TRAIN, ZF_>;                  \
+    allow_lds<kern>(lds);                                                                              \
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, e, t, w, m, affs, gout, partials, inv_out);      \
+  }
+  const bool crop = P.border != PEA_BORDER_CIRCULAR;
+  bool done = false;
+  if constexpr (D_T == 16) {
+    if (z3) {
+      if (crop) PEA_XF(true, kXdmaPSU3, kXZ / 2) else PEA_XF(false, kXdmaPSU3, kXZ / 2)
+      done = true;
+    }
+  }
+  if (!done) {
+    if (crop) PEA_XF(true, kXdmaPSU, 0) else PEA_XF(false, kXdmaPSU, 0)
+  }
+#undef PEA_XF
   *nparts = C.ntiles;
   return true;
 }
@@ -392,10 +421,10 @@ int launch_fwd(const KParams& P, const void* e, const void* eo, const float* t, 
   if (inv_out && (eo != nullptr && eo != e)) inv_out = nullptr;  // self loss only (caller runs k_inv_norm otherwise)
   if (env_int("PEA_FORCE_DIRECT", 0) == 0) {
     bool done = false;
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 4 && TRAIN) {
       // (inference keeps k_fwd_tiled: 60 us against 68 us at B=8 x 544^2 -- without the epilogue streams the one-sided
       //  box of the tiled kernel moves fewer bytes than six ring planes do)
-      if (TRAIN && op == ep) {
+      if (op == ep) {
         if (P.D == 16) done = try_fwd_xdma<16, TRAIN>(P, (const float*)ep, t, w, m, affs, gout, partials, inv_out, s, nparts);
         else if (P.D == 32) done = try_fwd_xdma<32, TRAIN>(P, (const float*)ep, t, w, m, affs, gout, partials, inv_out, s, nparts);
         else if (P.D == 64) done = try_fwd_xdma<64, TRAIN>(P, (const float*)ep, t, w, m, affs, gout, partials, inv_out, s, nparts);
@@ -763,7 +792,11 @@ int pea_cross_supported(const PeaDesc* desc, int backward) {
   if (env_int(backward ? "PEA_BWD_XDMA" : "PEA_FWD_XDMA", 1) == 0) return 0;
   XParams C;
   size_t lds;
+  if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU3, &C, &lds, backward == 0)) return 0;
+  const bool z3 = C.npz > 0 || C.nfz > 0;
+  if (z3) return (P.D == 16 && C.npx <= 8 && C.npy <= 8 && P.K <= kXP + 2) ? 1 : 0;
   if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds, backward == 0)) return 0;
+  if (!backward && P.K > kXP) return 0;
   return (backward && P.D > 32 && (C.npx > 8 || C.npy > 8)) ? 0 : 1;
 }
 

@@ -28,6 +28,8 @@
 namespace pea {
 
 constexpr int kXP = 10;  // (offset, role) pairs per axis held in registers (CVPPP: 5 shifts x 2 roles)
+constexpr int kXZ = 8;   // (offset, role) pairs along z (AC3/AC4 norm5: shifts 1, 2, 3, 4)
+constexpr int kXK = 16;  // channels (offsets) the forward's epilogue handles
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -42,11 +44,23 @@ struct XParams {
   int xm[kXP];             // strip coordinate mask of the x pair: d < 0 ? SW - 1 : 31
   int xgi[kXP], ygi[kXP];  // g channel
   int xgo[kXP], ygo[kXP];  // role A: 0 (g at p); role B: -o (g at p - o)
-  // forward (role A only, offsets in their own order): K <= kXP
+  // z offsets (3D volumes): not staged (a third LDS arm would cost 8 region pixels per pixel and does not fit beside the
+  // ring); their neighbour is the SAME (y, x) in another plane, read per chunk straight from global memory -- plane and
+  // validity are wave-uniform, so the displacement rides in the scalar offset and costs no VGPR
+  int npz;                 // backward: (offset, role) pairs along z
+  int zd[kXZ];             // plane displacement of the neighbour
+  int zgi[kXZ], zgo[kXZ];  // g channel; plane displacement of the g sample (role A: 0, role B: -oz)
+  int zrun;                // > 1: tiles walk z fastest (= Z), so the planes a z offset reaches were staged just before
+  // forward (role A only): in-plane offsets in their own order (nf <= kXP), z offsets (nfz <= kXZ / 2)
+  int nf, nfz;
   int fd[kXP];             // displacement along the offset's axis
   int fax[kXP];            // 1: along x, 0: along y
   int fm[kXP];             // strip coordinate mask (x offsets)
-  float fgs[kXP];          // 2 * lambda_i / N_i
+  int fi[kXP];             // channel of the in-plane offset
+  int fzd[kXZ / 2], fzi[kXZ / 2];  // plane displacement, channel of the z offset
+  // per CHANNEL (the forward's epilogue walks channels): 2 * lambda_i / N_i, axis (0 y, 1 x, 2 z), displacement
+  float gs[kXK];
+  int oax[kXK], od[kXK];
 };
 
 // inv[b, z, y, x] = 1 / max(|e|, eps), NEGATED where |e| < eps (the clamp branch of F.normalize: d ehat / d e = I / eps)
@@ -67,12 +81,57 @@ __global__ __launch_bounds__(256) void k_inv_norm(const KParams P, const T* __re
   inv[(size_t)b * P.S + p] = ss < P.eps * P.eps ? -r : r;
 }
 
+// tile id -> (plane = b * Z + z, y0, x0).  XCD g walks tiles [g * tpx, (g+1) * tpx); volumes with z offsets walk z FASTEST
+// (zrun = Z): the tiles running together on an XCD are a few (y, x) columns over all z, so the planes a z offset reaches
+// are in that XCD's L2.  The returned tile id stays plane-major (the loss-partial slot of a tile does not depend on the walk).
+template <int TH, int TW>
+__device__ __forceinline__ bool xdma_tile(const XParams& C, const KParams& P, int& tile, int& b, int& z, int& y0, int& x0) {
+  const int bid = blockIdx.x;
+  const int lin = (bid % kXcd) * C.tiles_per_xcd + bid / kXcd;
+  if (lin >= C.ntiles) return false;
+  int plane, rem;
+  if (C.zrun > 1) {
+    // walk: blocks of kGY x kGX tiles; inside a block z, then y, then x fastest -- the tiles in flight on an XCD (64) are a few
+    // planes of one block: the z neighbours were staged 1-4 planes ago, the in-plane halos are shared inside the block
+    constexpr int kGY = 4, kGX = 2;
+    const int per_b = C.tiles_per_plane * C.zrun;
+    b = lin / per_b;
+    int r = lin - b * per_b;
+    const int nbx = (C.tiles_x + kGX - 1) / kGX;
+    // block row (all of its x blocks), then block, then (z, y, x) inside the block; edge blocks are smaller
+    const int rows_full = kGY * C.tiles_x * C.zrun;            // tiles in a full block row
+    const int by = r / rows_full;
+    r -= by * rows_full;
+    const int gy = min(kGY, C.tiles_y - by * kGY);             // rows of this block row
+    const int blk_full = gy * kGX * C.zrun;                    // tiles in a full-width block of this block row
+    const int bx = min(r / blk_full, nbx - 1);
+    r -= bx * blk_full;
+    const int gx = min(kGX, C.tiles_x - bx * kGX);
+    z = r / (gy * gx);
+    r -= z * gy * gx;
+    const int ty_ = by * kGY + r / gx, tx_ = bx * kGX + r % gx;
+    rem = ty_ * C.tiles_x + tx_;
+    plane = b * C.zrun + z;
+  } else {
+    plane = lin / C.tiles_per_plane;
+    rem = lin - plane * C.tiles_per_plane;
+    b = plane / P.Z;
+    z = plane - b * P.Z;
+  }
+  tile = plane * C.tiles_per_plane + rem;
+  const int ty = rem / C.tiles_x;
+  y0 = ty * TH;
+  x0 = (rem - ty * C.tiles_x) * TW;
+  return true;
+}
+
 // self-loss backward (both roles, nb == x); f32 storage; X % 4 == 0 and 16-byte aligned planes (host-checked)
 // LDS: six planes of PS = PSU * 256 bytes: buffer b in {0,1,2}, channel j of the chunk at (2b + j) * PS; the 1 / norm
 // plane starts out in plane 4 (buffer 2 is first filled after the coefficients are done).
 // AUXS: cache policy of the gradient stores (non-temporal: they must not push the halo lines out of the L2, pea_tiled.h bs_emb)
 // XP: (offset, role) pairs per axis held in registers (<= kXP; the D = 64 instantiation takes 8 to stay inside 128 VGPRs)
-template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, int AUXS = kAuxNT>
+// ZP: pairs along z read from global memory (0: 2D; kXZ: the 3D instantiation)
+template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, int AUXS = kAuxNT, int ZP = 0>
 __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const XParams C, const float* __restrict__ xt,
                                                          const float* __restrict__ invp, const float* __restrict__ gin,
                                                          const float* __restrict__ dloss, float* __restrict__ dx) {
@@ -80,14 +139,8 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   static_assert(TW == 32 && D_T % 2 == 0, "lane mapping / channel pairs");
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
-  const int bid = blockIdx.x;
-  const int tile = (bid % kXcd) * C.tiles_per_xcd + bid / kXcd;
-  if (tile >= C.ntiles) return;
-  const int plane = tile / C.tiles_per_plane;
-  const int rem = tile - plane * C.tiles_per_plane;
-  const int ty = rem / C.tiles_x;
-  const int y0 = ty * TH, x0 = (rem - ty * C.tiles_x) * TW;
-  const int b = plane / P.Z, z = plane - b * P.Z;
+  int tile, b, z, y0, x0;
+  if (!xdma_tile<TH, TW>(C, P, tile, b, z, y0, x0)) return;
   const size_t S = (size_t)P.S;
   const unsigned YX = (unsigned)(P.Y * P.X);
   const rsrc_t xB = mkbuf(xt + (size_t)b * D_T * S), dB = mkbuf(dx + (size_t)b * D_T * S);
@@ -123,11 +176,19 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
     bool oky, okx;
     gy = wrap1<CROP>(gy, P.Y, oky);
     gx = wrap1<CROP>(gx, P.X, okx);
-    vo[s] = (oky && okx) ? (unsigned)(gy * P.X + gx) * 4u : kOOB;
+    vo[s] = (act[s] && oky && okx) ? (unsigned)(gy * P.X + gx) * 4u : kOOB;
   }
   const int wbase = wave * 1024;  // this wave's first block inside a plane; its second one is NW KiB further
+  // SDMA (the 3D instantiation): every wave issues BOTH slots for every plane, unconditionally -- a wave without a second block
+  // repeats its first one (same bytes to the same place), the tail lanes of the last block write zeros into the plane's
+  // padding.  The count of DMA instructions per chunk is then a compile-time 4, which is what lets the compiler wait for the
+  // z gathers with vmcnt(4) instead of vmcnt(0): with a DMA inside an `if` it has to assume that none was issued.
+  constexpr bool SDMA = ZP > 0;
+  const bool two = __builtin_amdgcn_readfirstlane(((NT / 64) + wave) * 64 < C.QA);
+  const unsigned vo1 = SDMA ? (two ? vo[1] : vo[0]) : vo[1];
+  const int w1 = SDMA ? (two ? wbase + (NT / 64) * 1024 : wbase) : wbase + (NT / 64) * 1024;
   // DMA instructions this wave issues per chunk (a slot without a live lane is skipped): what `vmcnt` has to count
-  const int npc = 2 * ((__builtin_amdgcn_ballot_w64(act[0]) != 0) + (__builtin_amdgcn_ballot_w64(act[1]) != 0));
+  const int npc = SDMA ? 4 : 2 * ((__builtin_amdgcn_ballot_w64(act[0]) != 0) + (__builtin_amdgcn_ballot_w64(act[1]) != 0));
   // wait until only the youngest chunk's DMA may still be in flight, then the workgroup barrier
 #define PEA_XWAIT1()                                                                             \
   {                                                                                              \
@@ -137,8 +198,13 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   }
 #define PEA_XDMA(rsrc, plane_byte, so)                                                                              \
   {                                                                                                                 \
-    if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, 0);        \
-    if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase + (NT / 64) * 1024), 16, vo[1], so, 0, 0); \
+    if (SDMA) {                                                                                                     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + w1), 16, vo1, so, 0, 0);      \
+    } else {                                                                                                        \
+      if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, 0);        \
+      if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + w1), 16, vo1, so, 0, 0); \
+    }                                                                                                               \
   }
   PEA_XDMA(iB, 4 * PS, ezo)
   PEA_XDMA(xB, 0, ezo)
@@ -172,6 +238,20 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
     cy[k] = bl32(gB, k < C.npy ? o : kOOB, ezo + (unsigned)C.ygi[k] * ecs);
     ay[k] = vown + C.yd[k] * TW * 4;
   }
+  // z pairs: g and the neighbour's 1 / norm (another plane, same (y, x): scalar plane offsets); a pair whose plane does not
+  // exist gets the coefficient 0 and reads plane z itself
+  float cz[ZP > 0 ? ZP : 1];
+  unsigned zso[ZP > 0 ? ZP : 1];  // byte offset of the neighbour's plane (scalar)
+#pragma unroll
+  for (int k = 0; k < ZP; ++k) {
+    bool okq, okg;
+    const int zq = wrap1<CROP>(z + C.zd[k], P.Z, okq), zg = wrap1<CROP>(z + C.zgo[k], P.Z, okg);
+    const bool ok = okq && okg && k < C.npz;
+    zso[k] = (unsigned)(ok ? zq : z) * YX * 4u;
+    const float gk = bl32(gB, pe, (unsigned)(ok ? zg : z) * YX * 4u + (unsigned)C.zgi[k] * ecs);
+    const float iq = bl32(iB, pe, zso[k]);
+    cz[k] = ok ? gk * fabsf(iq) : 0.f;
+  }
   PEA_XDMA(xB, 2 * PS, ezo + 2u * ecs)
   PEA_XDMA(xB, 3 * PS, ezo + 3u * ecs)
   // inv, chunk 0 and g have landed (the 4 DMA instructions of chunk 1 may still fly); every wave's share of them too
@@ -189,6 +269,17 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
     asm volatile("" : "+v"(cx[k]), "+v"(cy[k]));
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the inv plane is dead: buffer 2 may be filled
+  // the z neighbours' two channels of a chunk are requested BEFORE the DMA of the chunk two ahead (vmcnt retires in order:
+  // waiting for a gather issued after that DMA would wait for the DMA as well) and used after the chunk's LDS pairs
+  f2 zv[ZP > 0 ? ZP : 1];
+#define PEA_XZLOAD(ch)                                                        \
+  {                                                                           \
+    _Pragma("unroll") for (int k = 0; k < ZP; ++k) {                          \
+      zv[k].x = bl32(xB, pe, zso[k] + (unsigned)(2 * (ch)) * ecs);            \
+      zv[k].y = bl32(xB, pe, zso[k] + (unsigned)(2 * (ch) + 1) * ecs);        \
+    }                                                                         \
+  }
+  PEA_XZLOAD(0)
   if (NP > 2) {
     PEA_XDMA(xB, 4 * PS, ezo + 4u * ecs)
     PEA_XDMA(xB, 5 * PS, ezo + 5u * ecs)
@@ -228,6 +319,8 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       acc = __builtin_elementwise_fma((f2){cy[k], cy[k]}, v, acc);
       if (k % 5 == 4) asm volatile("" ::: "memory");
     }
+#pragma unroll
+    for (int k = 0; k < ZP; ++k) acc = __builtin_elementwise_fma((f2){cz[k], cz[k]}, zv[k], acc);
     if (!KEEP) {
       proj = fmaf(o.x, acc.x, fmaf(o.y, acc.y, proj));
       asm volatile("" : "+v"(proj));
@@ -238,6 +331,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       // chunk ps + 1 has landed (chunk ps + 2, issued after it, may still fly); everyone is done with buffer ps % 3
       if (ps + 2 < NP) PEA_XWAIT1()
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      PEA_XZLOAD(ps + 1)
       if (ps + 3 < NP) {
         PEA_XDMA(xB, bo, ezo + (unsigned)(2 * ps + 6) * ecs)
         PEA_XDMA(xB, bo + PS, ezo + (unsigned)(2 * ps + 7) * ecs)
@@ -246,6 +340,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   }
 #undef PEA_XDMA
 #undef PEA_XWAIT1
+#undef PEA_XZLOAD
 
   if (KEEP) {
 #pragma unroll
@@ -273,28 +368,26 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
 // four x-adjacent pixels per lane, so target / weight / affs / g are dwordx4 and the four masks one dword.
 // Needs K <= kXP, X % 4 == 0, 16-byte aligned planes.
 // ------------------------------------------------------------------------------------------------------------------
-template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN>
+// ZF: z offsets read from global memory (0: 2D; kXZ / 2: the 3D instantiation, which also issues its DMA unconditionally --
+// SDMA, see k_bwd_xdma -- and requests target / weight / mask only after the channel loop: their registers go to the z sums)
+template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN, int ZF = 0>
 __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const XParams C, const float* __restrict__ e,
                                                          const float* __restrict__ target, const float* __restrict__ weight,
                                                          const uint8_t* __restrict__ mask, float* __restrict__ affs,
                                                          float* __restrict__ gout, float* __restrict__ partials,
                                                          float* __restrict__ inv_out) {
   constexpr int NT = TH * TW, PS = PSU * 256, NP = D_T / 2, TP = NT, QP = TP / 4, NSL = QP / 64;
-  constexpr int ITEMS = (kXP * QP + NT - 1) / NT;
+  constexpr int KMAX = ZF > 0 ? kXP + 2 : kXP;      // channels the epilogue handles (norm5: 8 in-plane + 4 z offsets)
+  constexpr int ITEMS = (KMAX * QP + NT - 1) / NT;
+  constexpr bool SDMA = ZF > 0, LATE = ZF > 0;
   static_assert(TW == 32 && D_T % 2 == 0 && QP % 64 == 0, "lane mapping / channel pairs");
-  static_assert(kXP * TP * 4 + kXP * NSL * 4 <= 6 * PS, "the parked dot products fit the ring");
+  static_assert(KMAX * TP * 4 + KMAX * NSL * 4 <= 6 * PS && KMAX <= kXK, "the parked dot products fit the ring");
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   float* sA = (float*)lds;                          // [K][TP] dot products, laid over the ring once it is dead
-  float* s_part = (float*)(lds + kXP * TP * 4);     // [K][NSL]
-  const int bid = blockIdx.x;
-  const int tile = (bid % kXcd) * C.tiles_per_xcd + bid / kXcd;
-  if (tile >= C.ntiles) return;
-  const int plane = tile / C.tiles_per_plane;
-  const int rem = tile - plane * C.tiles_per_plane;
-  const int ty = rem / C.tiles_x;
-  const int y0 = ty * TH, x0 = (rem - ty * C.tiles_x) * TW;
-  const int b = plane / P.Z, z = plane - b * P.Z;
+  float* s_part = (float*)(lds + KMAX * TP * 4);    // [K][NSL]
+  int tile, b, z, y0, x0;
+  if (!xdma_tile<TH, TW>(C, P, tile, b, z, y0, x0)) return;
   const size_t S = (size_t)P.S;
   const unsigned YX = (unsigned)(P.Y * P.X);
   const rsrc_t xB = mkbuf(e + (size_t)b * D_T * S);
@@ -326,14 +419,19 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
     igx[it] = x0 + l4 % TW;
     const bool lv = ion[it] && igy[it] < P.Y && igx[it] < P.X;  // X % 4 == 0: a quad is inside or outside as a whole
     ivo[it] = lv ? (unsigned)(igy[it] * P.X + igx[it]) * 4u : kOOB;
-    if (TRAIN) {
-      const unsigned so = ezo + (unsigned)isl[it] * ecs;
-      t4[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(tB, ivo[it], so, kAuxNT));
-      w4[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wB, ivo[it], so, kAuxNT));
-      m4[it] = has_m ? __builtin_amdgcn_raw_buffer_load_b32(mB, lv ? ivo[it] >> 2 : kOOB, (ezo >> 2) + (unsigned)isl[it] * (unsigned)P.S, kAuxNT)
-                     : 0x01010101u;
-    }
   }
+#define PEA_XLOAD_TWM()                                                                                                   \
+  if (TRAIN) {                                                                                                            \
+    _Pragma("unroll") for (int it = 0; it < ITEMS; ++it) {                                                                \
+      const unsigned so = ezo + (unsigned)isl[it] * ecs;                                                                  \
+      t4[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(tB, ivo[it], so, kAuxNT));                    \
+      w4[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wB, ivo[it], so, kAuxNT));                    \
+      m4[it] = has_m ? __builtin_amdgcn_raw_buffer_load_b32(mB, ivo[it] == kOOB ? kOOB : ivo[it] >> 2,                    \
+                                                           (ezo >> 2) + (unsigned)isl[it] * (unsigned)P.S, kAuxNT)        \
+                     : 0x01010101u;                                                                                       \
+    }                                                                                                                     \
+  }
+  if (!LATE) PEA_XLOAD_TWM()
 
   const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
   const int py = y0 + ly, px = x0 + lx;
@@ -361,14 +459,22 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
     bool oky, okx;
     gy = wrap1<CROP>(gy, P.Y, oky);
     gx = wrap1<CROP>(gx, P.X, okx);
-    vo[s] = (oky && okx) ? (unsigned)(gy * P.X + gx) * 4u : kOOB;
+    vo[s] = (act[s] && oky && okx) ? (unsigned)(gy * P.X + gx) * 4u : kOOB;
   }
   const int wbase = wave * 1024;
-  const int npc = 2 * ((__builtin_amdgcn_ballot_w64(act[0]) != 0) + (__builtin_amdgcn_ballot_w64(act[1]) != 0));
+  const bool two = __builtin_amdgcn_readfirstlane(((NT / 64) + wave) * 64 < C.QA);
+  const unsigned vo1 = SDMA ? (two ? vo[1] : vo[0]) : vo[1];
+  const int w1 = SDMA ? (two ? wbase + (NT / 64) * 1024 : wbase) : wbase + (NT / 64) * 1024;
+  const int npc = SDMA ? 4 : 2 * ((__builtin_amdgcn_ballot_w64(act[0]) != 0) + (__builtin_amdgcn_ballot_w64(act[1]) != 0));
 #define PEA_XDMA(plane_byte, so)                                                                                    \
   {                                                                                                                 \
-    if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, 0);        \
-    if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (plane_byte) + wbase + (NT / 64) * 1024), 16, vo[1], so, 0, 0); \
+    if (SDMA) {                                                                                                     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, 0);   \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (plane_byte) + w1), 16, vo1, so, 0, 0);        \
+    } else {                                                                                                        \
+      if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, 0);        \
+      if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (plane_byte) + w1), 16, vo1, so, 0, 0); \
+    }                                                                                                               \
   }
 #define PEA_XWAIT1()                                                                             \
   {                                                                                              \
@@ -395,14 +501,36 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
   }
   if (NP > 1) PEA_XWAIT1()
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // z offsets: the neighbour is the same (y, x) in plane z + dz (wave-uniform plane and validity); requested before the DMA
+  // of the chunk two ahead, used after the chunk's LDS offsets (k_bwd_xdma)
+  unsigned zso[ZF > 0 ? ZF : 1];
+  bool zok[ZF > 0 ? ZF : 1];
+#pragma unroll
+  for (int k = 0; k < ZF; ++k) {
+    bool okq;
+    const int zq = wrap1<CROP>(z + C.fzd[k], P.Z, okq);
+    zok[k] = okq && k < C.nfz;
+    zso[k] = (unsigned)(zok[k] ? zq : z) * YX * 4u;
+  }
+  f2 zv[ZF > 0 ? ZF : 1];
+#define PEA_XZLOAD(ch)                                                        \
+  {                                                                           \
+    _Pragma("unroll") for (int k = 0; k < ZF; ++k) {                          \
+      zv[k].x = bl32(xB, pe, zso[k] + (unsigned)(2 * (ch)) * ecs);            \
+      zv[k].y = bl32(xB, pe, zso[k] + (unsigned)(2 * (ch) + 1) * ecs);        \
+    }                                                                         \
+  }
+  PEA_XZLOAD(0)
   if (NP > 2) {
     PEA_XDMA(4 * PS, ezo + 4u * ecs)
     PEA_XDMA(5 * PS, ezo + 5u * ecs)
   }
 
-  f2 dot[kXP], ssq[kXP], oss = {0.f, 0.f};
+  f2 dot[kXP], ssq[kXP], oss = {0.f, 0.f}, dotz[ZF > 0 ? ZF : 1], ssqz[ZF > 0 ? ZF : 1];
 #pragma unroll
   for (int k = 0; k < kXP; ++k) { dot[k] = (f2){0.f, 0.f}; ssq[k] = (f2){0.f, 0.f}; }
+#pragma unroll
+  for (int k = 0; k < ZF; ++k) { dotz[k] = (f2){0.f, 0.f}; ssqz[k] = (f2){0.f, 0.f}; }
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
     const int bo = (ps % 3) * 2 * PS;
@@ -420,11 +548,19 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
       if (k % 5 == 4) asm volatile("" ::: "memory");
     }
 #pragma unroll
+    for (int k = 0; k < ZF; ++k) {
+      dotz[k] = __builtin_elementwise_fma(o, zv[k], dotz[k]);
+      ssqz[k] = __builtin_elementwise_fma(zv[k], zv[k], ssqz[k]);
+    }
+#pragma unroll
     for (int k = 0; k < kXP; ++k) asm volatile("" : "+v"(dot[k]), "+v"(ssq[k]));  // the chunk's sums exist before its barrier
+#pragma unroll
+    for (int k = 0; k < ZF; ++k) asm volatile("" : "+v"(dotz[k]), "+v"(ssqz[k]));
     asm volatile("" : "+v"(oss));
     if (ps + 1 < NP) {
       if (ps + 2 < NP) PEA_XWAIT1()
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      PEA_XZLOAD(ps + 1)
       if (ps + 3 < NP) {
         PEA_XDMA(bo, ezo + (unsigned)(2 * ps + 6) * ecs)
         PEA_XDMA(bo + PS, ezo + (unsigned)(2 * ps + 7) * ecs)
@@ -433,6 +569,9 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
   }
 #undef PEA_XDMA
 #undef PEA_XWAIT1
+#undef PEA_XZLOAD
+  if (LATE) PEA_XLOAD_TWM()
+#undef PEA_XLOAD_TWM
 
   // ---- normalise; the lane's own 1 / norm for the backward
   const float osum = oss.x + oss.y;
@@ -442,13 +581,20 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
   lds_barrier();  // every lane is done with the ring: sA goes over it
 #pragma unroll
   for (int k = 0; k < kXP; ++k) {
-    if (k < P.K) {  // uniform
+    if (k < C.nf) {  // uniform
       float a = (dot[k].x + dot[k].y) * inv_own * rnorm(ssq[k].x + ssq[k].y, inv_eps);
       if (CROP) {
         const int q = (C.fax[k] ? px : py) + C.fd[k];
         a = (unsigned)q < (unsigned)(C.fax[k] ? P.X : P.Y) ? a : 0.f;
       }
-      sA[k * TP + (int)threadIdx.x] = a;
+      sA[C.fi[k] * TP + (int)threadIdx.x] = a;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ZF; ++k) {
+    if (k < C.nfz) {
+      const float a = zok[k] ? (dotz[k].x + dotz[k].y) * inv_own * rnorm(ssqz[k].x + ssqz[k].y, inv_eps) : 0.f;
+      sA[C.fzi[k] * TP + (int)threadIdx.x] = a;
     }
   }
   lds_barrier();
@@ -468,15 +614,16 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
     if (TRAIN) {
       float acc = 0.f;
       f4 g4;
-      const float gs = C.fgs[sl];
+      const float gs = C.gs[sl];
+      const int ax_ = C.oax[sl], od_ = C.od[sl];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float m = (float)((m4[it] >> (8 * j)) & 0xffu);
         const float r = a4[j] * m - t4[it][j] * m;
         float wr = w4[it][j] * r;
         if (CROP) {  // a cropped-away neighbour carries no loss term (its a is already 0)
-          const int q = (C.fax[sl] ? igx[it] + j : igy[it]) + C.fd[sl];
-          wr = (unsigned)q < (unsigned)(C.fax[sl] ? P.X : P.Y) ? wr : 0.f;
+          const int q = (ax_ == 1 ? igx[it] + j : ax_ == 0 ? igy[it] : z) + od_;
+          wr = (unsigned)q < (unsigned)(ax_ == 1 ? P.X : ax_ == 0 ? P.Y : P.Z) ? wr : 0.f;
         }
         g4[j] = gs * wr * m;
         acc = fmaf(wr, r, acc);
@@ -498,7 +645,9 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
 }
 
 // host: the plan.  false = not an axis-aligned in-plane stencil that fits (the caller falls back to k_bwd_tiled)
-// fwd = true: role A only (one-sided halos, offsets in their own order for the forward kernel)
+// fwd = true: role A only (one-sided halos, offsets in their own order for the forward kernel).
+// Offsets along z (3D volumes) are allowed: they are not staged but gathered per chunk (npz / nfz > 0 selects the 3D
+// instantiations, which issue their DMA unconditionally: the plane must then hold whole 64-quad blocks).
 inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, size_t* lds_bytes, bool fwd = false) {
   if (P.border == PEA_BORDER_REPLICATE) return false;
   if ((long long)P.Y * P.X >= (1LL << 28)) return false;                           // plane byte offsets + displacement < 2^31
@@ -506,16 +655,32 @@ inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, s
   if (P.X % 4 || P.S % 4) return false;                                            // quads never straddle a row end
   XParams C = {};
   int hx = 0, hy = 0;
-  if (P.K > kXP) return false;
+  if (P.K > kXK) return false;
   int up = 0, down = 0, left = 0, right = 0;
   for (int i = 0; i < P.K; ++i) {
     const int oz = P.off[i][0], oy = P.off[i][1], ox = P.off[i][2];
-    if (oz != 0 || (oy != 0) == (ox != 0)) return false;  // exactly one in-plane component
+    if ((oz != 0) + (oy != 0) + (ox != 0) != 1) return false;  // exactly one component: axis-aligned
+    C.gs[i] = P.gscale[i];
+    C.oax[i] = ox != 0 ? 1 : (oy != 0 ? 0 : 2);
+    C.od[i] = ox != 0 ? ox : (oy != 0 ? oy : oz);
+    if (oz != 0) {
+      if (oz <= -P.Z || oz >= P.Z) return false;
+      if (fwd) {
+        if (C.nfz >= kXZ / 2) return false;
+        C.fzd[C.nfz] = oz; C.fzi[C.nfz] = i; ++C.nfz;
+      } else {
+        if (C.npz + 2 > kXZ) return false;
+        C.zd[C.npz] = oz; C.zgi[C.npz] = i; C.zgo[C.npz] = 0; ++C.npz;     // role A: neighbour plane z + oz, g at z
+        C.zd[C.npz] = -oz; C.zgi[C.npz] = i; C.zgo[C.npz] = -oz; ++C.npz;  // role B: neighbour plane z - oz, g at z - oz
+      }
+      continue;
+    }
     up = oy < -up ? -oy : up; down = oy > down ? oy : down; left = ox < -left ? -ox : left; right = ox > right ? ox : right;
-    C.fd[i] = ox != 0 ? ox : oy;
-    C.fax[i] = ox != 0;
-    C.fgs[i] = P.gscale[i];
-    if (fwd) continue;
+    if (fwd) {
+      if (C.nf >= kXP) return false;
+      C.fd[C.nf] = ox != 0 ? ox : oy; C.fax[C.nf] = ox != 0; C.fi[C.nf] = i; ++C.nf;
+      continue;
+    }
     if (ox != 0) {
       if (C.npx + 2 > kXP) return false;
       hx = ox < 0 ? (hx > -ox ? hx : -ox) : (hx > ox ? hx : ox);
@@ -528,6 +693,8 @@ inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, s
       C.yd[C.npy] = -oy; C.ygi[C.npy] = i; C.ygo[C.npy] = -oy; ++C.npy;
     }
   }
+  const bool has_z = C.npz > 0 || C.nfz > 0;
+  if (has_z && P.Z > 1) C.zrun = P.Z;
   if (fwd) { hx = left > right ? left : right; C.hy0 = up; C.hy1 = down; }
   else { C.hy0 = C.hy1 = hy; left = right = hx; }
   if (hx > TW) return false;  // a neighbour column is inside the tile or in the strip next to it
@@ -539,7 +706,8 @@ inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, s
   C.QA = C.QV + TH * C.SW / 4;
   const int nw = TH * TW / 64;
   if (C.QA > 2 * nw * 64) return false;              // two quads per lane and plane
-  if (C.QA * 16 > psu * 256) return false;           // the plane holds the region
+  const int plane_bytes = has_z ? (C.QA + 63) / 64 * 1024 : C.QA * 16;  // unconditional DMA writes whole blocks
+  if (plane_bytes > psu * 256) return false;         // the plane holds the region
   // the kernels wrap with one conditional add
   if (P.Y < TH + C.hy1 || P.Y < C.hy0 || P.X < TW + C.SW || P.X < C.SW) return false;
   C.tiles_y = (P.Y + TH - 1) / TH;

@@ -151,4 +151,11 @@ def test_cross_kernels_cover_the_shipped_2d_shapes(pkg, lib):
         assert q(desc(16, 544, 542, cv), bwd) == 0                # X % 4 != 0
         assert q(desc(16, 40, 56, cv, B=2), bwd) == 0             # narrower than a tile plus its strips
     assert q(desc(16, 34, 34, cv[:2]), 0) == 0
+    # 3D: the AC3/AC4 norm5 table (z offsets gathered per chunk, y / x from LDS); the 26-neighbourhood is not axis-aligned
+    d3 = desc(16, 160, 160, [[-1, 0, 0], [0, -1, 0], [0, 0, -1], [-2, 0, 0], [0, -3, 0], [0, 0, -3], [-3, 0, 0], [0, -9, 0], [0, 0, -9],
+                             [-4, 0, 0], [0, -27, 0], [0, 0, -27]], border=1, B=2)
+    d3.ndim = 3
+    d3.dims[:] = [18, 160, 160]
+    d3.norm = 1
+    assert q(d3, 0) == 1 and q(d3, 1) == 1
     assert q(desc(64, 544, 544, cv), 0) == 1 and q(desc(64, 544, 544, cv), 1) == 0    # D = 64 backward: at most 8 pairs per axis

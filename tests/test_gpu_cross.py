@@ -151,3 +151,26 @@ def test_inv_norm_plane_and_ex_entry_points(pkg, dev, orc, synth):
     assert relmax(de_x.cpu().numpy(), o_grad) < GRAD_RTOL and relmax(de_t.cpu().numpy(), o_grad) < GRAD_RTOL
     # the zero-norm pixels take the clamp branch: d ehat / d e = I / eps, no projection
     assert relmax(de_x.cpu().numpy()[0, :, 5, 7], o_grad[0, :, 5, 7]) < GRAD_RTOL
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 48, 96), (1, 5, 64, 132), (1, 9, 43, 96)])
+def test_cross_3d_norm5_vs_oracle(pkg, dev, orc, synth, shape):
+    """the AC3/AC4 stencil (embedding_loss_norm5: 12 axis offsets, z 1-4, y / x 1, 3, 9, 27; CROP_ZERO, cropped normaliser) through the
+    3D instantiations of the cross kernels: in-plane offsets from LDS, z offsets gathered per chunk from the neighbouring planes"""
+    B, Z, Y, X = shape
+    sh = [1, 1, 1, 2, 3, 3, 3, 9, 9, 4, 27, 27]
+    offs = orc.norm_offsets(sh)
+    e, t, w = synth.synth_inputs_3d(B, 16, Z, Y, X, offs, 19 + Z)
+    L = pkg._lib.lib()
+    et = cu(e, dev).requires_grad_(True)
+    spec = pkg.AffinitySpec(3, offs, orc.affs0_lambda_3d(12, 2, 3), pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
+    d_hip = pkg.affinity_op.make_desc(spec, et.detach())
+    assert L.pea_cross_supported(ctypes.byref(d_hip), 0) == 1 and L.pea_cross_supported(ctypes.byref(d_hip), 1) == 1
+    loss, affs = pkg.embedding_loss_norm5(et, cu(t, dev), cu(w, dev), pkg.WeightedMSE(), affs0_weight=2)
+    (loss * 0.25).backward()
+    d = orc.desc_3d(e, sh, orc.affs0_lambda_3d(12, 2, 3))
+    o_affs, o_loss = orc.c_fwd(d, e, None, t, w, None)
+    o_grad, _ = orc.c_bwd(d, e, None, t, w, None, dloss=0.25)
+    assert np.abs(affs.cpu().numpy() - o_affs).max() < AFFS_ATOL
+    assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+    assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL
