@@ -21,7 +21,7 @@ from .loss.loss_embedding_mse_3d import (ema_embedding_loss_norm1, ema_embedding
                                          embedding_loss_norm5_from_labels, inf_embedding_loss_norm1, inf_embedding_loss_norm5)
 from .utils.affinity_ours import gen_offsets, multi_offset
 from .utils.postproc import fill_border_relu_, relu_
-from .utils.targets import gen_affs_ours, gen_targets
+from .utils.targets import gen_affs_ours, gen_targets, seg_to_aff
 from .harness.stitch import VolumeStitcher
 from .model.head import EmbeddingHead, OutConv, head_conv3d_block
 from .harness.loss_section import (ac3ac4_loss_section, ac3ac4_loss_section_composed, ac3ac4_loss_section_from_labels,
@@ -35,7 +35,7 @@ __all__ = [
     "embedding_loss", "ema_embedding_loss", "embedding2affs", "embedding_loss_norm1", "embedding_loss_norm5",
     "ema_embedding_loss_norm1", "ema_embedding_loss_norm5", "inf_embedding_loss_norm1", "inf_embedding_loss_norm5",
     "gen_offsets", "multi_offset", "fill_border_relu_", "relu_", "cvppp_loss_section", "ac3ac4_loss_section",
-    "deep_weight_factor", "finish_pred_2d_", "finish_pred_3d_", "gen_targets", "gen_affs_ours", "VolumeStitcher", "embedding_loss_from_labels",
+    "deep_weight_factor", "finish_pred_2d_", "finish_pred_3d_", "gen_targets", "gen_affs_ours", "seg_to_aff", "VolumeStitcher", "embedding_loss_from_labels",
     "ema_embedding_loss_from_labels", "LabelsAffinityMSE", "cvppp_loss_section_from_labels", "cvppp_loss_section_composed", "ac3ac4_loss_section_composed",
     "ac3ac4_loss_section_from_labels",
     "embedding_loss_norm1_from_labels", "embedding_loss_norm5_from_labels", "ema_embedding_loss_norm5_from_labels",

@@ -50,3 +50,16 @@ def gen_affs_ours(labels, offsets=((-1, 0), (0, -1)), ignore=False, padding=Fals
         raise NotImplementedError("ignore=True is not used by any shipped configuration")
     t, m, _ = gen_targets(labels, offsets, padding=padding, want_weight=False)
     return t, m
+
+
+def seg_to_aff(seg, nhood=((-1, 0, 0), (0, -1, 0), (0, 0, -1)), pad='replicate'):
+    """the reference's 3D target generator (scripts_ac3ac4/data/data_affinity.py:53-102), batched on the GPU:
+    aff[b, e, p] = [seg(p) == seg(p + nhood[e])] * [both > 0], 0 where the neighbour is outside the volume; with three edges and
+    pad='replicate' the first slice of channel c along axis c is (seg > 0) instead (:94-97).  seg: int tensor [B,Z,Y,X]."""
+    t, _, _ = gen_targets(seg, [list(o) for o in nhood], padding=False, both_foreground=True, want_mask=False, want_weight=False)
+    if len(nhood) == 3 and pad == 'replicate':
+        fg = (seg > 0).to(t.dtype)
+        t[:, 0, 0] = fg[:, 0]
+        t[:, 1, :, 0] = fg[:, :, 0]
+        t[:, 2, :, :, 0] = fg[:, :, :, 0]
+    return t

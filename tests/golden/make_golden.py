@@ -245,6 +245,81 @@ def case_model(name, seed, shape, nfeatures, emd):
          **{"out%d" % i: o.detach().numpy() for i, o in enumerate(outs)}, **sd)
 
 
+def case_seg_to_aff(name, seed, Z, Y, X):
+    """the reference's seg_to_aff (scripts_ac3ac4/data/data_affinity.py:53-102) as the 3D data provider calls it
+    (data_provider_labeled_deep.py:233-256): the 3-edge graph with pad='replicate' (deep-supervision scales) and the twelve
+    channels of the norm5 stencil with pad='' (four 3-edge calls concatenated)"""
+    refaff3 = load("ref_data_affinity", "scripts_ac3ac4/data/data_affinity.py")
+    rng = np.random.default_rng(seed)
+    seg = np.kron(rng.integers(0, 5, size=(-(-Z // 3), -(-Y // 5), -(-X // 6))), np.ones((3, 5, 6), dtype=np.int64))[:Z, :Y, :X]
+    seg[:, : Y // 4] = 0  # a background slab: the "both > 0" rule matters
+    seg = seg.astype(np.uint16)
+    a3 = refaff3.seg_to_aff(seg)  # pad='replicate'
+    nh = lambda a, b, c: np.asarray([-a, 0, 0, 0, -b, 0, 0, 0, -c]).reshape((3, 3))
+    a12 = np.concatenate([refaff3.seg_to_aff(seg, pad=''), refaff3.seg_to_aff(seg, nh(2, 3, 3), pad=''),
+                          refaff3.seg_to_aff(seg, nh(3, 9, 9), pad=''), refaff3.seg_to_aff(seg, nh(4, 27, 27), pad='')], axis=0)
+    save(name, seg=seg.astype(np.int32), aff3_replicate=a3, aff12_nopad=a12)
+
+
+def case_stitch_weight(name, out_size, sigma=0.2, mu=0.0):
+    """Provider_valid.get_weight (scripts_ac3ac4/data/provider_valid.py:306-318), num_z >= 18 branch.  The module needs cv2 / h5py
+    (absent here), so the formula is restated in THIS script, outside the product: the stitcher test compares the product's
+    weights with this stored array instead of with themselves."""
+    zz, yy, xx = np.meshgrid(np.linspace(-1, 1, out_size[0], dtype=np.float32), np.linspace(-1, 1, out_size[1], dtype=np.float32),
+                             np.linspace(-1, 1, out_size[2], dtype=np.float32), indexing='ij')
+    dd = np.sqrt(zz * zz + yy * yy + xx * xx)
+    weight = 1e-6 + np.exp(-((dd - mu) ** 2 / (2.0 * sigma ** 2)))
+    save(name, out_size=np.array(out_size), weight=weight[np.newaxis, ...].astype(np.float32))
+
+
+def case_section(name, seed, B, D, H, W):
+    """the loss section of the training loop, scripts_cvppp/main.py:284-310, run by the reference's own embedding_loss /
+    ema_embedding_loss in that order on a five-scale pyramid (deep_weight 1, self_emb = cross_emb = 1, affs0_weight 1, the EMA
+    operand detached as convert_consistency_flip leaves it): the six losses, the total, relu(pred) and the five gradients"""
+    rng = np.random.default_rng(seed)
+    offsets = refaff.multi_offset([1, 3, 5, 9, 27], neighbor=4)
+    nb_half = 2
+    labs, embs, downs = [], [], []
+    lab0 = np.stack([blocky_labels(rng, H, W, cell=8, n=7) for _ in range(B)])
+    for j in range(5):
+        lab = lab0[:, ::2 ** j, ::2 ** j]
+        labs.append(lab.astype(np.int32))
+        embs.append(rng.standard_normal((B, D, H >> j, W >> j)).astype(np.float32))
+    ema = rng.standard_normal((B, D, H, W)).astype(np.float32)
+    ks = [len(offsets), nb_half * 4, nb_half * 3, nb_half * 2, nb_half * 1]
+    twm = []
+    for j in range(5):
+        offs = offsets[:ks[j]]
+        t = np.zeros((B, ks[j]) + labs[j].shape[1:], np.float32); m = np.zeros_like(t, dtype=np.uint8); w = np.zeros_like(t)
+        for b in range(B):
+            t[b], m[b] = refaff.gen_affs_ours(labs[j][b].astype(np.float32), offs, ignore=False, padding=True)
+            for i in range(ks[j]):
+                w[b, i] = weight_binary_ratio(t[b, i])
+        twm.append((t, w, m))
+    et = [T(e).requires_grad_(True) for e in embs]
+    emat = T(ema)  # detached
+    losses = []
+    for j in range(1, 5):  # emd1..emd4 = scales 1/2 .. 1/16 with offsets[:8], [:6], [:4], [:2]  (main.py:284-287)
+        t, w, m = twm[j]
+        down = torch.cat([T(t), T(w), T(m).float()], dim=1)
+        k = ks[j]
+        lj, _, _ = ref2d.embedding_loss(et[j], down[:, 0:k], down[:, k:2 * k], down[:, 2 * k:3 * k], criterion, offsets[:k], affs0_weight=1, mode='ours')
+        losses.append(lj)
+    t, w, m = twm[0]
+    l0, pred, _ = ref2d.embedding_loss(et[0], T(t), T(w), T(m), criterion, offsets, affs0_weight=1, mode='ours')
+    lx, _ = ref2d.ema_embedding_loss(et[0], emat, T(t), T(w), T(m), criterion, offsets, affs0_weight=1, mode='ours')
+    total = (losses[0] + losses[1] + losses[2] + losses[3] + l0) * 1.0 + lx * 1.0
+    total.backward()
+    out = {"emb%d" % j: embs[j] for j in range(5)}
+    out.update({"lab%d" % j: labs[j] for j in range(5)})
+    for j in range(5):
+        out["t%d" % j], out["w%d" % j], out["m%d" % j] = twm[j]
+    out.update({"grad%d" % j: et[j].grad.numpy() for j in range(5)})
+    save(name, ema=ema, offsets=np.array(offsets, np.int32), total=np.float32(total.item()),
+         losses=np.array([l0.item()] + [l.item() for l in losses] + [lx.item()], np.float64),  # self@1, emd1..emd4, cross
+         pred=torch.relu(pred).detach().numpy(), **out)
+
+
 def case_full_summary(name, seed, B, D, H, W):
     """One full-size CVPPP case (B x 16 x 544 x 544, K=10): too big to store, so inputs are a closed-form
     function of the index (no RNG) and only summary statistics + samples of the outputs are kept."""
@@ -290,6 +365,11 @@ if __name__ == "__main__":
         case_head("ghead_2d_c32_d16", 61, B=2, C=32, D=16, spatial=(19, 23))
         case_head("ghead_2d_c64_d32", 62, B=1, C=64, D=32, spatial=(9, 31))
         case_head("ghead_3d_c28_d16", 63, B=1, C=28, D=16, spatial=(3, 10, 13))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "corners":  # fixtures that pin what round 1 had pinned to the text only
+        case_seg_to_aff("gseg2aff_3d", 91, Z=9, Y=40, X=42)
+        case_stitch_weight("gstitch_weight_18x160x160", (18, 160, 160))
+        case_section("gsection_cvppp", 92, B=2, D=16, H=48, W=64)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "model":  # only the backbone layout fixtures
         case_model("gmodel_resunet2d", 81, (2, 3, 48, 64), [4, 8, 12, 16, 20], 16)
@@ -340,3 +420,6 @@ if __name__ == "__main__":
     case_head("ghead_3d_c28_d16", 63, B=1, C=28, D=16, spatial=(3, 10, 13))
     case_model("gmodel_resunet2d", 81, (2, 3, 48, 64), [4, 8, 12, 16, 20], 16)
     case_model("gmodel_resunet2d_odd", 82, (1, 3, 40, 40), [4, 6, 8, 10, 12], 16)
+    case_seg_to_aff("gseg2aff_3d", 91, Z=9, Y=40, X=42)
+    case_stitch_weight("gstitch_weight_18x160x160", (18, 160, 160))
+    case_section("gsection_cvppp", 92, B=2, D=16, H=48, W=64)

@@ -1031,3 +1031,42 @@ def test_randomised_data_format_paths_sweep():
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_formats.py"), "30", "17"], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_seg_to_aff_matches_reference_golden(pkg, dev):
+    """pkg.seg_to_aff / gen_targets(both_foreground) on the GPU, bit-exact against the reference's seg_to_aff outputs"""
+    g = load_golden("gseg2aff_3d")
+    seg = cu(g["seg"][None], dev)
+    a3 = pkg.seg_to_aff(seg)
+    assert np.array_equal(a3[0].cpu().numpy(), g["aff3_replicate"])
+    nh = lambda a, b, c: [[-a, 0, 0], [0, -b, 0], [0, 0, -c]]
+    a12 = torch.cat([pkg.seg_to_aff(seg, pad=''), pkg.seg_to_aff(seg, nh(2, 3, 3), pad=''), pkg.seg_to_aff(seg, nh(3, 9, 9), pad=''),
+                     pkg.seg_to_aff(seg, nh(4, 27, 27), pad='')], dim=1)
+    assert np.array_equal(a12[0].cpu().numpy(), g["aff12_nopad"])
+
+
+@pytest.mark.parametrize("path", ["one_node", "composed", "labels"])
+def test_cvppp_loss_section_matches_reference_golden(pkg, dev, path):
+    """the six-loss section of the training loop against the reference's own functions called in scripts_cvppp/main.py:284-293's
+    order (tests/golden/gsection_cvppp.npz): per-loss values, total, relu(pred) and the five gradients"""
+    g = load_golden("gsection_cvppp")
+    offsets = g["offsets"].tolist()
+    nb_half = 2
+    crit = pkg.WeightedMSE()
+    embs = [cu(g["emb%d" % j], dev).requires_grad_(True) for j in range(5)]
+    ema = cu(g["ema"], dev)
+    if path == "labels":
+        labs = [cu(g["lab%d" % j], dev) for j in range(5)]
+        loss, pred, parts = pkg.cvppp_loss_section_from_labels(embs[0], embs[1:], ema, labs[0], labs[1:], crit, offsets, nb_half, relu_pred=True)
+    else:
+        downs = [torch.cat([cu(g["t%d" % j], dev), cu(g["w%d" % j], dev), cu(g["m%d" % j], dev).float()], dim=1) for j in range(1, 5)]
+        fn = pkg.cvppp_loss_section if path == "one_node" else pkg.cvppp_loss_section_composed
+        kw = {"relu_pred": True} if path == "one_node" else {}
+        loss, pred, parts = fn(embs[0], embs[1:], ema, cu(g["t0"], dev), cu(g["w0"], dev), cu(g["m0"], dev), downs, crit, offsets, nb_half, **kw)
+    loss.backward()
+    if path == "composed":
+        pkg.finish_pred_2d_(pred)
+    assert abs(loss.item() - float(g["total"])) <= 1e-5 * abs(float(g["total"]))
+    assert np.abs(pred.cpu().numpy() - g["pred"]).max() < AFFS_ATOL
+    for j in range(5):
+        assert relmax(embs[j].grad.cpu().numpy(), g["grad%d" % j]) < GRAD_RTOL, j

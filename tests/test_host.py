@@ -136,3 +136,16 @@ def test_labels_in_path_refuses_offsets_as_long_as_the_image(pkg):
     spec = pkg.AffinitySpec(2, [[-1, 0], [0, -40]], None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX)
     assert not pkg.affinity_op.labels_offsets_in_range(spec, torch.zeros(1, 16, 64, 34))
     assert pkg.affinity_op.labels_offsets_in_range(spec, torch.zeros(1, 16, 64, 48))
+
+
+def test_stitcher_blend_weights_match_the_stored_reference_array(pkg):
+    """harness/stitch.get_weight against an array computed OUTSIDE the product (tests/golden/make_golden.py restates
+    Provider_valid.get_weight, scripts_ac3ac4/data/provider_valid.py:306-318, whose module needs cv2 / h5py)"""
+    import importlib
+    import numpy as np
+    import __graft_entry__ as ge
+    from conftest import load_golden
+    g = load_golden("gstitch_weight_18x160x160")
+    st = importlib.import_module(ge.PKG_NAME + ".harness.stitch")
+    w = st.get_weight(tuple(int(v) for v in g["out_size"]))
+    assert w.dtype == np.float32 and np.array_equal(w, g["weight"])

@@ -178,3 +178,18 @@ def test_head_restatement_matches_reference(name):
     assert np.abs(dW - g["dW"]).max() <= 1e-5 * np.abs(g["dW"]).max()
     if bias is not None:
         assert np.abs(db - g["db"]).max() <= 1e-5 * np.abs(g["db"]).max()
+
+
+def test_oracle_target_generation_matches_reference_seg_to_aff(orc):
+    """np_gen_targets(both_foreground, no padding) against the reference's seg_to_aff run on the same segmentation
+    (tests/golden/gseg2aff_3d.npz: the twelve norm5 channels with pad='' and the 3-edge graph with pad='replicate')"""
+    g = load_golden("gseg2aff_3d")
+    seg = g["seg"][None]
+    offs12 = orc.norm_offsets([1, 1, 1, 2, 3, 3, 3, 9, 9, 4, 27, 27])
+    t12, _ = orc.np_gen_targets(seg, offs12, padding=False, both_foreground=True)
+    assert np.array_equal(t12[0], g["aff12_nopad"])
+    t3, _ = orc.np_gen_targets(seg, offs12[:3], padding=False, both_foreground=True)
+    t3 = t3[0].copy()
+    fg = (seg[0] > 0).astype(np.float32)
+    t3[0, 0], t3[1, :, 0], t3[2, :, :, 0] = fg[0], fg[:, 0], fg[:, :, 0]
+    assert np.array_equal(t3, g["aff3_replicate"])
