@@ -18,7 +18,7 @@ import torch
 from . import _lib
 from ._lib import PeaDesc
 
-SUPPORTED_TRAIN_D = (4, 8, 16, 32, 64)
+SPECIALISED_TRAIN_D = (4, 8, 16, 32, 64)  # every other width trains through the runtime-D backward (REPLICATE border excepted)
 
 
 class AffinitySpec(object):
@@ -195,8 +195,8 @@ class FusedAffinityMSE(torch.autograd.Function):
         want_o = ctx.has_other and ctx.needs_input_grad[1]
         if not (want_e or want_o) or dloss is None:
             return None, None, None, None, None, None
-        if e_c.shape[1] not in SUPPORTED_TRAIN_D:
-            raise NotImplementedError("backward needs D in %s (got %d); pad the embedding channels" % (SUPPORTED_TRAIN_D, e_c.shape[1]))
+        if e_c.shape[1] not in SPECIALISED_TRAIN_D and ctx.spec.border == _lib.BORDER_REPLICATE:
+            raise NotImplementedError("the replicate-border backward needs D in %s (got %d)" % (SPECIALISED_TRAIN_D, e_c.shape[1]))
         with torch.cuda.device(e_c.device):
             L = _lib.lib()
             dl = dloss.to(device=e_c.device, dtype=torch.float32).contiguous()
@@ -229,8 +229,8 @@ class AffinityMap(torch.autograd.Function):
             return None, None, None
         if ctx.spec.relu:
             raise NotImplementedError("relu epilogue is inference-only")
-        if e_c.shape[1] not in SUPPORTED_TRAIN_D:
-            raise NotImplementedError("backward needs D in %s (got %d)" % (SUPPORTED_TRAIN_D, e_c.shape[1]))
+        if e_c.shape[1] not in SPECIALISED_TRAIN_D and ctx.spec.border == _lib.BORDER_REPLICATE:
+            raise NotImplementedError("the replicate-border backward needs D in %s (got %d)" % (SPECIALISED_TRAIN_D, e_c.shape[1]))
         with torch.cuda.device(e_c.device):
             d = make_desc(ctx.spec, e_c)
             da = d_affs.to(torch.float32).contiguous()

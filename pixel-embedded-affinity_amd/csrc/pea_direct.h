@@ -313,4 +313,109 @@ __global__ __launch_bounds__(kBlock) void k_bwd_direct(const KParams P, const T*
   for (int c = 0; c < D_T; ++c) st(db, c * S + p, (G[c] - xc[c] * inv_p * proj) * sc);
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward for ANY embedding width (MODEL.emd is a free yaml key in the reference: scripts_cvppp/config/cvppp.yaml:7,
+// loss_embedding_mse.py:18-47 takes what it gets).  Runtime D, nothing D-sized in registers: the 2K pair coefficients
+// g * 1/|e(q)| are parked in LDS ([2K][256 lanes]); G_c is then formed channel by channel, written raw into dx while
+// <ehat, G> accumulates, and the projection is applied in a last sweep over the lane's own D outputs.  Three passes over
+// the neighbours: a correct fallback, not a fast path (the specialised kernels cover D = 4, 8, 16, 32, 64).
+// CIRCULAR / CROP_ZERO borders (REPLICATE keeps the specialised kernels).
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool ROLE_A, bool ROLE_B>
+__global__ __launch_bounds__(kBlock) void k_bwd_direct_anyd(const KParams P, const T* __restrict__ xt, const T* __restrict__ nbA,
+                                                            const T* __restrict__ nbB, const float* __restrict__ gin,
+                                                            const float* __restrict__ dloss, T* __restrict__ dx) {
+  extern __shared__ float s_coef[];  // [2K][kBlock]
+  const int tile = logical_tile(P);
+  if (tile >= P.tiles) return;
+  const int b = tile / P.chunks;
+  const int p = (tile - b * P.chunks) * kBlock + threadIdx.x;
+  if (p >= P.S) return;
+  const int D = P.D;
+  const size_t S = (size_t)P.S;
+  const T* xb = xt + (size_t)b * D * S;
+  const float* gb = gin + (size_t)b * P.K * S;
+  const float dl = dloss ? dloss[0] : 1.f;
+  const int yx = P.Y * P.X;
+  const int z = p / yx;
+  const int r0 = p - z * yx;
+  const int y = r0 / P.X;
+  const int x = r0 - y * P.X;
+
+  float ss = 0.f;
+  for (int c = 0; c < D; ++c) {
+    const float v = ld(xb, c * S + p);
+    ss = fmaf(v, v, ss);
+  }
+  const float nrm = sqrtf(ss);
+  const float inv_p = 1.0f / fmaxf(nrm, P.eps);
+
+  // (1) coefficient of every (offset, role) pair; 0 where the pair does not exist
+  for (int i = 0; i < P.K; ++i) {
+#pragma unroll
+    for (int role = 0; role < 2; ++role) {
+      float coef = 0.f;
+      if (role == 0 ? ROLE_A : ROLE_B) {
+        const int sg = role == 0 ? 1 : -1;
+        const T* nb = (role == 0 ? nbA : nbB) + (size_t)b * D * S;
+        const int q = neighbour(P, z, y, x, sg * P.off[i][0], sg * P.off[i][1], sg * P.off[i][2]);
+        if (q >= 0) {
+          float sq = 0.f;
+          for (int c = 0; c < D; ++c) {
+            const float v = ld(nb, c * S + q);
+            sq = fmaf(v, v, sq);
+          }
+          coef = gb[(size_t)i * S + (role == 0 ? p : q)] * inv_norm(sq, P.eps);
+        }
+      }
+      s_coef[(2 * i + role) * kBlock + threadIdx.x] = coef;
+    }
+  }
+  // (2) G_c, raw, into dx; <ehat, G>
+  T* db = dx + (size_t)b * D * S;
+  float proj = 0.f;
+  for (int c = 0; c < D; ++c) {
+    float Gc = 0.f;
+    for (int i = 0; i < P.K; ++i) {
+#pragma unroll
+      for (int role = 0; role < 2; ++role) {
+        if (role == 0 ? !ROLE_A : !ROLE_B) continue;
+        const float coef = s_coef[(2 * i + role) * kBlock + threadIdx.x];
+        if (coef == 0.f) continue;
+        const int sg = role == 0 ? 1 : -1;
+        const T* nb = (role == 0 ? nbA : nbB) + (size_t)b * D * S;
+        const int q = neighbour(P, z, y, x, sg * P.off[i][0], sg * P.off[i][1], sg * P.off[i][2]);
+        Gc = fmaf(coef, ld(nb, c * S + q), Gc);
+      }
+    }
+    proj = fmaf(ld(xb, c * S + p) * inv_p, Gc, proj);
+    if (sizeof(T) == 4) st(db, c * S + p, Gc);
+    // (f16 storage: G is recomputed in the last sweep instead of being rounded through dx)
+  }
+  if (nrm < P.eps) proj = 0.f;  // clamp_min branch of F.normalize: d ehat / d e = I / eps
+  const float sc = dl * inv_p;
+  // (3) projection
+  for (int c = 0; c < D; ++c) {
+    float Gc;
+    if (sizeof(T) == 4) {
+      Gc = ld(db, c * S + p);
+    } else {  // recompute (no f32 scratch per pixel): one more pass over the neighbours
+      Gc = 0.f;
+      for (int i = 0; i < P.K; ++i) {
+#pragma unroll
+        for (int role = 0; role < 2; ++role) {
+          if (role == 0 ? !ROLE_A : !ROLE_B) continue;
+          const float coef = s_coef[(2 * i + role) * kBlock + threadIdx.x];
+          if (coef == 0.f) continue;
+          const int sg = role == 0 ? 1 : -1;
+          const T* nb = (role == 0 ? nbA : nbB) + (size_t)b * D * S;
+          const int q = neighbour(P, z, y, x, sg * P.off[i][0], sg * P.off[i][1], sg * P.off[i][2]);
+          Gc = fmaf(coef, ld(nb, c * S + q), Gc);
+        }
+      }
+    }
+    st(db, c * S + p, (Gc - ld(xb, c * S + p) * inv_p * proj) * sc);
+  }
+}
+
 }  // namespace pea

@@ -514,8 +514,21 @@ int launch_bwd(const KParams& P, int roles, const void* x, const void* nbA, cons
     case 64: return launch_bwd_roles<T, 64>(P, roles, (const T*)x, (const T*)nbA, (const T*)nbB, g, dl, (T*)dx, s);
     case 4: return launch_bwd_roles<T, 4>(P, roles, (const T*)x, (const T*)nbA, (const T*)nbB, g, dl, (T*)dx, s);
     case 8: return launch_bwd_roles<T, 8>(P, roles, (const T*)x, (const T*)nbA, (const T*)nbB, g, dl, (T*)dx, s);
-    default: return PEA_E_UNSUPPORTED;  // training needs D in {4, 8, 16, 32, 64}
+    default: break;
   }
+  // any other width: the runtime-D kernel (pea_direct.h); the REPLICATE border keeps the specialised kernels
+  if (P.border == PEA_BORDER_REPLICATE) return PEA_E_UNSUPPORTED;
+  const size_t lds = (size_t)2 * P.K * kBlock * sizeof(float);
+  const dim3 grid((unsigned)(P.tiles_per_xcd * kXcd)), blk(kBlock);
+#define PEA_ANYD(RA_, RB_)                                                                                           \
+  {                                                                                                                  \
+    constexpr auto kern = k_bwd_direct_anyd<T, RA_, RB_>;                                                            \
+    allow_lds<kern>(lds);                                                                                            \
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, (const T*)x, (const T*)nbA, (const T*)nbB, g, dl, (T*)dx);        \
+  }
+  if (roles == 3) PEA_ANYD(true, true) else if (roles == 1) PEA_ANYD(true, false) else PEA_ANYD(false, true)
+#undef PEA_ANYD
+  return hip_rc();
 }
 
 
