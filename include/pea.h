@@ -64,7 +64,12 @@ extern "C" {
 #define PEA_NORM_CROPPED 1
 #define PEA_NORM_FULL 2
 /* flags */
-#define PEA_FLAG_RELU_AFFS 1u /* affs output = max(a, 0)  (F.relu(pred), scripts_cvppp/main.py:312) */
+/* activation of the affs OUTPUT (the loss and its gradient always use the raw cosine a); applied in this order: */
+#define PEA_FLAG_HALF_SHIFT 4u /* a -> (a + 1) / 2   (scripts_cvppp/loss/loss_embedding.py:10,35; for unit vectors also the L2 affinity
+                                  1 - |ehat_p - ehat_q|^2 / 4 of scripts_ac3ac4/loss/embedding2affs_3d_l2.py:10-11) */
+#define PEA_FLAG_RELU_AFFS 1u  /* a -> max(a, 0)     (F.relu(pred), scripts_cvppp/main.py:312, inference.py:193) */
+#define PEA_FLAG_CLAMP01 8u    /* a -> clamp(a, 0, 1) (torch.clamp(affs_temp, 0.0, 1.0), loss_embedding.py:11,36) */
+#define PEA_FLAG_ONE_MINUS 2u  /* a -> 1 - a         (what elf's mutex_watershed is handed: scripts_cvppp/utils/seg_mutex.py:4-5) */
 
 /* error codes: 0 = ok, negative = PEA_E_*, positive = a hipError_t from the runtime */
 #define PEA_OK 0

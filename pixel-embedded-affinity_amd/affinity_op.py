@@ -24,7 +24,7 @@ SPECIALISED_TRAIN_D = (4, 8, 16, 32, 64)  # every other width trains through the
 class AffinitySpec(object):
     """Everything about one call that is not a tensor."""
 
-    def __init__(self, ndim, offsets, lam, border, norm, eps=1e-12, relu=False):
+    def __init__(self, ndim, offsets, lam, border, norm, eps=1e-12, relu=False, act=0):
         self.ndim = int(ndim)
         self.offsets = [tuple([0] * (3 - len(o)) + [int(v) for v in o]) for o in offsets]
         self.K = len(self.offsets)
@@ -33,7 +33,17 @@ class AffinitySpec(object):
         self.lam = [1.0] * self.K if lam is None else [float(v) for v in lam]
         if len(self.lam) != self.K:
             raise ValueError("lambda list must have one entry per offset")
-        self.border, self.norm, self.eps, self.relu = border, norm, float(eps), bool(relu)
+        self.border, self.norm, self.eps = border, norm, float(eps)
+        self.act = int(act)  # _lib.FLAG_* activation bits of the affs output (the loss always uses the raw cosine)
+        self.relu = bool(relu) or bool(self.act & _lib.FLAG_RELU_AFFS)
+
+    @property
+    def relu(self):
+        return bool(self.act & _lib.FLAG_RELU_AFFS)
+
+    @relu.setter
+    def relu(self, on):
+        self.act = (self.act | _lib.FLAG_RELU_AFFS) if on else (self.act & ~_lib.FLAG_RELU_AFFS)
 
 
 def _spatial(e, ndim):
@@ -78,7 +88,7 @@ _DESC_CACHE = {}
 def make_desc(spec, e, tstride=0, wstride=0, mstride=0):
     """PeaDesc for `spec` on a tensor shaped like e.  Descriptors are immutable once built (the library takes them as
     const), so they are memoised: filling and validating one costs more host time than the launch it describes."""
-    key = (spec.ndim, tuple(spec.offsets), tuple(spec.lam), spec.border, spec.norm, spec.eps, spec.relu, tuple(e.shape),
+    key = (spec.ndim, tuple(spec.offsets), tuple(spec.lam), spec.border, spec.norm, spec.eps, spec.act, tuple(e.shape),
            e.dtype == torch.float16, int(tstride), int(wstride), int(mstride))
     d = _DESC_CACHE.get(key)
     if d is not None:
@@ -97,7 +107,7 @@ def _build_desc(spec, e, tstride, wstride, mstride):
     d.K = spec.K
     d.border, d.norm, d.eps = spec.border, spec.norm, spec.eps
     d.dtype = _lib.F16 if e.dtype == torch.float16 else _lib.F32
-    d.flags = _lib.FLAG_RELU_AFFS if spec.relu else 0
+    d.flags = spec.act
     for i, o in enumerate(spec.offsets):
         if spec.border == _lib.BORDER_CIRCULAR:  # torch.roll is modular: fold into (-dim, dim)
             o = tuple(int(v) - dims[a] * int(int(v) / dims[a]) if dims[a] else 0 for a, v in enumerate(o))
@@ -227,8 +237,8 @@ class AffinityMap(torch.autograd.Function):
         want_o = ctx.has_other and ctx.needs_input_grad[1]
         if not (want_e or want_o):
             return None, None, None
-        if ctx.spec.relu:
-            raise NotImplementedError("relu epilogue is inference-only")
+        if ctx.spec.act:
+            raise NotImplementedError("an activation of the affs output is inference-only: apply it to the map yourself")
         if e_c.shape[1] not in SPECIALISED_TRAIN_D and ctx.spec.border == _lib.BORDER_REPLICATE:
             raise NotImplementedError("the replicate-border backward needs D in %s (got %d)" % (SPECIALISED_TRAIN_D, e_c.shape[1]))
         with torch.cuda.device(e_c.device):
@@ -290,6 +300,24 @@ def labels_offsets_in_range(spec, e):
     fall back to gen_targets (true offsets) + the tensor path."""
     dims = _spatial(e, spec.ndim)
     return all(abs(o[a]) < dims[a] for o in spec.offsets for a in range(3))
+
+
+ACTIVATIONS = {
+    None: 0, "none": 0,
+    "relu": _lib.FLAG_RELU_AFFS,                                   # F.relu(pred): scripts_cvppp/main.py:312, inference.py:193
+    "mutex": _lib.FLAG_RELU_AFFS | _lib.FLAG_ONE_MINUS,            # 1 - relu(a): what seg_mutex hands to elf (utils/seg_mutex.py:4-5)
+    "half": _lib.FLAG_HALF_SHIFT,                                  # (a + 1) / 2 = the L2 affinity 1 - |ehat_p - ehat_q|^2 / 4
+    "half_clamp": _lib.FLAG_HALF_SHIFT | _lib.FLAG_CLAMP01,        # loss_embedding.py's embedding2affs: clamp((a + 1) / 2, 0, 1)
+}
+
+
+def activation_flags(activation):
+    if isinstance(activation, int):
+        return activation
+    try:
+        return ACTIVATIONS[activation]
+    except KeyError:
+        raise ValueError("activation must be one of %s (or FLAG_* bits), got %r" % (sorted(k for k in ACTIVATIONS if k), activation))
 
 
 def _labels_int32(labels):

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(TH* TW, (DC > 16 ? 2 : 4)) void k_fwd_tiled_chunked
   U.kzo = (unsigned)z * YX * 4u;
   U.S32 = (unsigned)P.S;
   U.has_a = affs != nullptr; U.has_g = gout != nullptr; U.has_m = mask != nullptr;
-  U.relu = P.flags & PEA_FLAG_RELU_AFFS;
+  U.af = P.flags & kActMask;
   const unsigned ecs = (unsigned)P.S * (unsigned)sizeof(T);  // embedding channel stride, bytes
   const unsigned ezo = (unsigned)z * YX * (unsigned)sizeof(T);
 

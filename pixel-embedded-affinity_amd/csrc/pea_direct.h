@@ -74,6 +74,17 @@ __device__ __forceinline__ int neighbour(const KParams& P, int z, int y, int x, 
   return (zz * P.Y + yy) * P.X + xx;
 }
 
+// activation of the affs output (include/pea.h PEA_FLAG_*): flags are wave-uniform, the common case (0) is one scalar branch
+constexpr unsigned kActMask = PEA_FLAG_RELU_AFFS | PEA_FLAG_ONE_MINUS | PEA_FLAG_HALF_SHIFT | PEA_FLAG_CLAMP01;
+__device__ __forceinline__ float act_affs(float a, unsigned af) {
+  if (af == 0) return a;
+  if (af & PEA_FLAG_HALF_SHIFT) a = (a + 1.0f) * 0.5f;
+  if (af & PEA_FLAG_RELU_AFFS) a = fmaxf(a, 0.f);
+  if (af & PEA_FLAG_CLAMP01) a = fminf(fmaxf(a, 0.f), 1.0f);
+  if (af & PEA_FLAG_ONE_MINUS) a = 1.0f - a;
+  return a;
+}
+
 __device__ __forceinline__ float inv_norm(float ss, float eps) { return 1.0f / fmaxf(sqrtf(ss), eps); }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd_direct(const KParams P, const T*
         a = dot * inv_p * inv_norm(sq, P.eps);
       }
       const size_t in = (size_t)i * S + p;
-      if (affs) affs[kb + in] = (P.flags & PEA_FLAG_RELU_AFFS) ? fmaxf(a, 0.f) : a;
+      if (affs) affs[kb + in] = act_affs(a, P.flags & kActMask);
       if (TRAIN) {
         float g = 0.f;
         if (q >= 0) {

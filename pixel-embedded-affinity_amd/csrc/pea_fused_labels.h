@@ -49,7 +49,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fused_labels(con
   const rsrc_t lB = mkbuf(labels + (size_t)b * S);
   const rsrc_t aB = mkbuf(affs ? affs + (size_t)b * P.K * S : nullptr);
   const bool has_a = affs != nullptr;
-  const bool relu = P.flags & PEA_FLAG_RELU_AFFS;
+  const unsigned af = P.flags & kActMask;
   const bool pad = lflags & PEA_TGT_PADDING, fg = lflags & PEA_TGT_BOTH_FOREGROUND, msk = lflags & kLabMask;
   const unsigned ecs = (unsigned)P.S * (unsigned)sizeof(T);
   const unsigned ezo = (unsigned)z * YX * (unsigned)sizeof(T);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fused_labels(con
     const float rr_ = a_ * m_ - t_ * m_;                                                                      \
     const float wr_ = (exists) ? w_ * rr_ : 0.f;                                                              \
     if ((ROLE) == 0) {                                                                                        \
-      if (has_a) bs32<true>(aB, relu ? fmaxf(a_, 0.f) : a_, pb, kzo + (unsigned)(ent).i * kcs);              \
+      if (has_a) bs32<true>(aB, act_affs(a_, af), pb, kzo + (unsigned)(ent).i * kcs);              \
       const float red_ = wave_sum63(wr_ * rr_);                                                               \
       if ((threadIdx.x & 63) == 63) s_part[wave * P.K + (ent).i] = red_;                                      \
     }                                                                                                         \
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fused_labels_dua
   const rsrc_t lB = mkbuf(labels + (size_t)b * S);
   const rsrc_t aB = mkbuf(affs ? affs + (size_t)b * P.K * S : nullptr);
   const bool has_a = affs != nullptr;
-  const bool relu = P.flags & PEA_FLAG_RELU_AFFS;
+  const unsigned af = P.flags & kActMask;
   const bool pad = lflags & PEA_TGT_PADDING, fg = lflags & PEA_TGT_BOTH_FOREGROUND, msk = lflags & kLabMask;
   const unsigned ecs = (unsigned)P.S * (unsigned)sizeof(T);
   const unsigned ezo = (unsigned)z * YX * (unsigned)sizeof(T);
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fused_labels_dua
     const float rr_ = a_ * m_ - t_ * m_;                                                                      \
     const float wr_ = (exists) ? w_ * rr_ : 0.f;                                                              \
     if ((ROLE) == 0) {                                                                                        \
-      if (has_a) bs32<true>(aB, relu ? fmaxf(a_, 0.f) : a_, pb, kzo + (unsigned)(ent).i * kcs);              \
+      if (has_a) bs32<true>(aB, act_affs(a_, af), pb, kzo + (unsigned)(ent).i * kcs);              \
       const float red_ = wave_sum63(wr_ * rr_);                                                               \
       if ((threadIdx.x & 63) == 63) s_part[wave * P.K + (ent).i] = red_;                                      \
     }                                                                                                         \

@@ -276,7 +276,8 @@ __device__ __forceinline__ void lane_pixel(int& ly, int& lx) {
 struct FwdU {  // uniform per-workgroup state
   rsrc_t aB, gB, tB, wB, mB;
   unsigned kzo, kcs, S32;  // byte offset of plane z / stride of one offset channel (f32); elements per channel
-  bool has_a, has_g, has_m, relu;
+  bool has_a, has_g, has_m;
+  unsigned af;  // activation flags of the affs output (act_affs)
 };
 
 template <int N>
@@ -302,7 +303,7 @@ template <bool TRAIN>
 __device__ __forceinline__ void fwd_finish(const FwdU U, int K, float* s_part, const OffEnt e, float a, bool valid, float t,
                                            float w, float m, unsigned pb) {
   const unsigned so = U.kzo + (unsigned)e.i * U.kcs;
-  if (U.has_a) bs32<true>(U.aB, U.relu ? fmaxf(a, 0.f) : a, pb, so);
+  if (U.has_a) bs32<true>(U.aB, act_affs(a, U.af), pb, so);
   if (TRAIN) {
     const float r = a * m - t * m;
     const float wr = valid ? w * r : 0.f;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled(const 
   U.kzo = (unsigned)z * YX * 4u;
   U.S32 = (unsigned)P.S;
   U.has_a = affs != nullptr; U.has_g = gout != nullptr; U.has_m = mask != nullptr;
-  U.relu = P.flags & PEA_FLAG_RELU_AFFS;
+  U.af = P.flags & kActMask;
   const unsigned ecs = (unsigned)P.S * (unsigned)sizeof(T);  // embedding channel stride, bytes
   const unsigned ezo = (unsigned)z * YX * (unsigned)sizeof(T);
 
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled_v(cons
   const rsrc_t mB = mkbuf(mask ? mask + (size_t)b * P.mbs : nullptr);
   const unsigned kcs = (unsigned)P.S * 4u, kzo = (unsigned)z * YX * 4u;
   const bool has_a = affs != nullptr, has_g = gout != nullptr, has_m = mask != nullptr;
-  const bool relu = P.flags & PEA_FLAG_RELU_AFFS;
+  const unsigned af = P.flags & kActMask;
   const unsigned ecs = (unsigned)P.S * (unsigned)sizeof(T);
   const unsigned ezo = (unsigned)z * YX * (unsigned)sizeof(T);
 
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled_v(cons
     const unsigned so = kzo + (unsigned)en.i * kcs;
     if (has_a) {
       f4 o = a4;
-      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (af) { o.x = act_affs(o.x, af); o.y = act_affs(o.y, af); o.z = act_affs(o.z, af); o.w = act_affs(o.w, af); }
       bs128<true>(aB, o, ivo[it], so);
     }
     if (TRAIN) {

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
   const rsrc_t iB = mkbuf(inv_out ? inv_out + (size_t)b * S : nullptr);
   const unsigned ecs = (unsigned)P.S * 4u, ezo = (unsigned)z * YX * 4u;
   const bool has_a = affs != nullptr, has_g = gout != nullptr, has_m = mask != nullptr;
-  const bool relu = P.flags & PEA_FLAG_RELU_AFFS;
+  const unsigned af = P.flags & kActMask;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 
   // ---- (0) the epilogue's operands: item = (offset, quad of 4 x-adjacent tile pixels); requested first
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
     const unsigned so = ezo + (unsigned)sl * ecs;
     if (has_a) {
       f4 o = a4;
-      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (af) { o.x = act_affs(o.x, af); o.y = act_affs(o.y, af); o.z = act_affs(o.z, af); o.w = act_affs(o.w, af); }
       bs128<true>(aB, o, ivo[it], so);
     }
     if (TRAIN) {

@@ -17,7 +17,7 @@ Semantics kept from the reference (file:line there):
 import torch
 
 from .. import _lib
-from ..affinity_op import (AffinityMap, AffinitySpec, FusedAffinityMSE, LabelsAffinityMSE, LabelsStepUnsupported, LossList,
+from ..affinity_op import (AffinityMap, activation_flags, AffinitySpec, FusedAffinityMSE, LabelsAffinityMSE, LabelsStepUnsupported, LossList,
                            affinity_infer)
 
 
@@ -25,8 +25,8 @@ def _eps(mode):
     return 1e-12 if mode == 'ours' else 1e-6
 
 
-def _spec(offsets, lam, mode, relu=False):
-    return AffinitySpec(2, offsets, lam, _lib.BORDER_CIRCULAR, _lib.NORM_BX, _eps(mode), relu)
+def _spec(offsets, lam, mode, relu=False, act=0):
+    return AffinitySpec(2, offsets, lam, _lib.BORDER_CIRCULAR, _lib.NORM_BX, _eps(mode), relu, act)
 
 
 def _fused(criterion):
@@ -55,9 +55,12 @@ def embedding_loss(embedding, target, weightmap, mask, criterion, offsets, affs0
     return loss, affs, LossList(parts)
 
 
-def embedding2affs(embedding, offsets, mode='ours'):
-    """-> affs [B,K,H,W] -- reference :58-66"""
-    return affinity_infer(embedding, None, _spec(offsets, None, mode))
+def embedding2affs(embedding, offsets, mode='ours', activation=None):
+    """-> affs [B,K,H,W] -- reference :58-66.  activation (beyond the reference's signature): the statement the caller applies
+    to the map next, fused into its store -- 'relu' (F.relu(pred), inference.py:193), 'mutex' (1 - relu(a): the map
+    elf.mutex_watershed is handed, utils/seg_mutex.py:4-5), 'half' ((a + 1) / 2 = the L2 affinity 1 - d^2 / 4 of unit vectors),
+    'half_clamp' (clamp((a + 1) / 2, 0, 1): the embedding2affs of scripts_cvppp/loss/loss_embedding.py:33-46, with mode='cos')."""
+    return affinity_infer(embedding, None, _spec(offsets, None, mode, act=activation_flags(activation)))
 
 
 def ema_embedding_loss(embedding, ema_embedding, target, weightmap, mask, criterion, offsets, affs0_weight=1, mode='ours'):

@@ -320,6 +320,19 @@ def case_section(name, seed, B, D, H, W):
          pred=torch.relu(pred).detach().numpy(), **out)
 
 
+def case_activation(name, seed, B, D, H, W, shifts):
+    """the affinity maps of the reference's experimental loss (scripts_cvppp/loss/loss_embedding.py:33-46): CosineSimilarity
+    (eps 1e-6) -> (a + 1) / 2 -> clamp; and the shipped hand-off statements on the shipped map: relu (inference.py:193), 1 - relu (seg_mutex.py:5)"""
+    refexp = load("ref_loss_embedding", "scripts_cvppp/loss/loss_embedding.py")
+    rng = np.random.default_rng(seed)
+    offsets = refaff.multi_offset(shifts, neighbor=4)
+    e = (rng.standard_normal((B, D, H, W)) * 2.0).astype(np.float32)
+    half_clamp = refexp.embedding2affs(T(e), offsets).numpy()
+    ours = ref2d.embedding2affs(T(e), offsets, mode='ours')
+    relu = torch.relu(ours)
+    save(name, e=e, offsets=np.array(offsets, np.int32), half_clamp_cos=half_clamp, relu_ours=relu.numpy(), mutex_ours=(1.0 - relu).numpy())
+
+
 def case_full_summary(name, seed, B, D, H, W):
     """One full-size CVPPP case (B x 16 x 544 x 544, K=10): too big to store, so inputs are a closed-form
     function of the index (no RNG) and only summary statistics + samples of the outputs are kept."""
@@ -370,6 +383,7 @@ if __name__ == "__main__":
         case_seg_to_aff("gseg2aff_3d", 91, Z=9, Y=40, X=42)
         case_stitch_weight("gstitch_weight_18x160x160", (18, 160, 160))
         case_section("gsection_cvppp", 92, B=2, D=16, H=48, W=64)
+        case_activation("gact_2d", 93, B=1, D=16, H=40, W=72, shifts=[1, 3, 9])
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "model":  # only the backbone layout fixtures
         case_model("gmodel_resunet2d", 81, (2, 3, 48, 64), [4, 8, 12, 16, 20], 16)
@@ -423,3 +437,4 @@ if __name__ == "__main__":
     case_seg_to_aff("gseg2aff_3d", 91, Z=9, Y=40, X=42)
     case_stitch_weight("gstitch_weight_18x160x160", (18, 160, 160))
     case_section("gsection_cvppp", 92, B=2, D=16, H=48, W=64)
+    case_activation("gact_2d", 93, B=1, D=16, H=40, W=72, shifts=[1, 3, 9])

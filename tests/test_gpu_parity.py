@@ -1073,3 +1073,24 @@ def test_cvppp_loss_section_matches_reference_golden(pkg, dev, path):
     assert np.abs(pred.cpu().numpy() - g["pred"]).max() < AFFS_ATOL
     for j in range(5):
         assert relmax(embs[j].grad.cpu().numpy(), g["grad%d" % j]) < GRAD_RTOL, j
+
+
+def test_affs_activations_match_reference_golden(pkg, dev):
+    """the activation flags of the affs output (include/pea.h PEA_FLAG_*) against what the reference computes: relu and 1 - relu
+    of the shipped map (inference.py:193, seg_mutex.py:5) and the (a + 1) / 2 + clamp map of loss_embedding.py's embedding2affs"""
+    g = load_golden("gact_2d")
+    e, offsets = cu(g["e"], dev), g["offsets"].tolist()
+    assert np.abs(pkg.embedding2affs(e, offsets, activation="relu").cpu().numpy() - g["relu_ours"]).max() < AFFS_ATOL
+    assert np.abs(pkg.embedding2affs(e, offsets, activation="mutex").cpu().numpy() - g["mutex_ours"]).max() < AFFS_ATOL
+    assert np.abs(pkg.embedding2affs(e, offsets, mode="cos", activation="half_clamp").cpu().numpy() - g["half_clamp_cos"]).max() < AFFS_ATOL
+    half = pkg.embedding2affs(e, offsets, activation="half").cpu().numpy()
+    raw = pkg.embedding2affs(e, offsets).cpu().numpy()
+    assert np.abs(half - (raw + 1) / 2).max() < 1e-6
+    # the hand-off: one pinned [N, K, H, W] array in the layout of affs.hdf, 1 - affs for elf
+    ho = __import__("importlib").import_module(ge.PKG_NAME + ".harness.handoff")
+    col = ho.AffsCollector(2, len(offsets), 40, 72)
+    col.add(pkg.embedding2affs(e, offsets, activation="relu"))
+    col.add(pkg.embedding2affs(e, offsets, activation="relu")[0])
+    a = col.numpy()
+    assert a.shape == (2, len(offsets), 40, 72) and a.flags["C_CONTIGUOUS"] and np.abs(a[1] - g["relu_ours"][0]).max() < AFFS_ATOL
+    assert np.abs(col.mutex_input(0) - g["mutex_ours"][0]).max() < AFFS_ATOL

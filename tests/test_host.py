@@ -14,7 +14,8 @@ def test_reference_signatures(pkg):
                                        ("offsets", E), ("affs0_weight", 1), ("mode", "ours")]
     assert sig(pkg.ema_embedding_loss) == [("embedding", E), ("ema_embedding", E), ("target", E), ("weightmap", E), ("mask", E),
                                            ("criterion", E), ("offsets", E), ("affs0_weight", 1), ("mode", "ours")]
-    assert sig(pkg.embedding2affs) == [("embedding", E), ("offsets", E), ("mode", "ours")]
+    # the reference's three arguments first; `activation` (include/pea.h PEA_FLAG_*) is this package's trailing extension
+    assert sig(pkg.embedding2affs) == [("embedding", E), ("offsets", E), ("mode", "ours"), ("activation", None)]
     for f in (pkg.embedding_loss_norm1, pkg.embedding_loss_norm5):
         assert sig(f) == [("embedding", E), ("target", E), ("weightmap", E), ("criterion", E), ("affs0_weight", 1),
                           ("shift", 1), ("fill", True)]
@@ -149,3 +150,14 @@ def test_stitcher_blend_weights_match_the_stored_reference_array(pkg):
     st = importlib.import_module(ge.PKG_NAME + ".harness.stitch")
     w = st.get_weight(tuple(int(v) for v in g["out_size"]))
     assert w.dtype == np.float32 and np.array_equal(w, g["weight"])
+
+
+def test_activation_flags_and_spec(pkg):
+    L, op = pkg._lib, pkg.affinity_op
+    assert op.activation_flags(None) == 0 and op.activation_flags("relu") == L.FLAG_RELU_AFFS
+    assert op.activation_flags("mutex") == L.FLAG_RELU_AFFS | L.FLAG_ONE_MINUS
+    assert op.activation_flags("half_clamp") == L.FLAG_HALF_SHIFT | L.FLAG_CLAMP01
+    with pytest.raises(ValueError):
+        op.activation_flags("sigmoid")
+    spec = op.AffinitySpec(2, [[-1, 0]], None, L.BORDER_CIRCULAR, L.NORM_BX, act=op.activation_flags("mutex"))
+    assert spec.relu and op.make_desc(spec, torch.empty(1, 16, 8, 8)).flags & (L.FLAG_RELU_AFFS | L.FLAG_ONE_MINUS) == 3
