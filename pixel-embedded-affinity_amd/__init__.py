@@ -23,6 +23,9 @@ from .utils.affinity_ours import gen_offsets, multi_offset
 from .utils.postproc import fill_border_relu_, relu_
 from .utils.targets import gen_affs_ours, gen_targets, seg_to_aff
 from .harness.stitch import VolumeStitcher
+from .harness.handoff import AffsCollector
+from .harness.train_step import CvpppTrainStep, convert_consistency_flip, label_pyramid, make_optimizer
+from .model.unet2d_residual import ResidualUNet2D_deep
 from .model.head import EmbeddingHead, OutConv, head_conv3d_block
 from .harness.loss_section import (ac3ac4_loss_section, ac3ac4_loss_section_composed, ac3ac4_loss_section_from_labels,
                                    cvppp_loss_section, cvppp_loss_section_composed,
