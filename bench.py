@@ -638,9 +638,14 @@ def main():
         hwork = torch.empty(hws // 4, device=dev)
         head_fwd = lambda: L.pea_head_fwd(B, HC, D, H * W, P(hx), P(hw), P(hb), P(dE), st)
         head_bwd = lambda: L.pea_head_bwd(B, HC, D, H * W, P(hx), P(hw), P(dE), P(hdx), P(hdw), P(hdb), P(hwork), hws, st)
+        # f1: the loss' backward with the head's backward in its epilogue (one launch instead of bwd + head_bwd)
+        fb = L.pea_bwd_head_workspace_bytes(ctypes.byref(desc), HC)
+        fwork = torch.empty(max(fb, 4) // 4, device=dev)
+        bwd_head = lambda: L.pea_affinity_bwd_head(ctypes.byref(desc), P(Ed), P(G), P(INV), P(one), None, P(hx), P(hw), HC, P(hdx),
+                                                   P(hdw), P(hdb), None, P(fwork), fb, st)
         kt = {}
         for name, fn in (("fwd", fwd), ("bwd", bwd), ("infer", inf), ("labels_step", labels_step),
-                         ("head_fwd", head_fwd), ("head_bwd", head_bwd)):
+                         ("head_fwd", head_fwd), ("head_bwd", head_bwd)) + ((("bwd_head_fused", bwd_head),) if fb else ()):
             event_time_ms(fn, 10)
             kt[name] = event_time_ms(fn, max(20, min(args.steps, 200)))
         # ---- the training loop's loss section (five self losses over the scales + EMA cross loss + backward + relu,

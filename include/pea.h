@@ -245,6 +245,19 @@ int pea_stitch_add(float *out_affs, float *weight_map, const float *affs_vol, co
                    int X, int oz, int oy, int ox, int z0, int y0, int x0, void *stream);
 int pea_stitch_finalize(float *out_affs, const float *weight_map, int C, size_t voxels, void *stream);
 
+/* ---- f1: the self-loss backward with the embedding head's backward in its epilogue ------------
+ * The step before this path is e = W x + b (OutConv, scripts_cvppp/model/unet2d_residual.py:67-74, outconv_emb :307, applied
+ * :346); autograd runs its backward (dx = W^T de, dW = sum_p de x^T, db = sum_p de) right after the loss' (main.py:311).  Here
+ * both happen in ONE launch: de = dloss * d loss / d e (+ de_add, the gradient reaching the embedding from the other losses of
+ * the section, or NULL) never has to leave the chip -- `de` may be NULL.  x [B, C, Y, X], W [D, C], dx [B, C, Y, X] (or NULL),
+ * dW [D, C], db [D] (or NULL); e, g, inv_norm as for pea_affinity_bwd_ex (self loss).  Workspace: pea_bwd_head_workspace_bytes
+ * (0 = this shape is not covered).  Covered: 2D, D = 16, C = 32, f32, circular border, axis-aligned stencil, X % 4 == 0;
+ * everything else returns PEA_E_UNSUPPORTED and the caller runs pea_affinity_bwd_ex + pea_head_bwd. */
+size_t pea_bwd_head_workspace_bytes(const PeaDesc *desc, int C);
+int pea_affinity_bwd_head(const PeaDesc *desc, const void *e, const float *g, const float *inv_norm, const float *dloss,
+                          const float *de_add, const float *x, const float *W, int C, float *dx, float *dW, float *db, void *de,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,7 @@ from .utils.postproc import fill_border_relu_, relu_
 from .utils.targets import gen_affs_ours, gen_targets, seg_to_aff
 from .harness.stitch import VolumeStitcher
 from .harness.handoff import AffsCollector
+from .harness.head_loss import HeadAffinityMSE, head_embedding_loss
 from .harness.train_step import CvpppTrainStep, convert_consistency_flip, label_pyramid, make_optimizer
 from .model.unet2d_residual import ResidualUNet2D_deep
 from .model.head import EmbeddingHead, OutConv, head_conv3d_block

@@ -25,6 +25,7 @@ TGT_PADDING, TGT_BOTH_FOREGROUND, TGT_MASK_INSIDE, TGT_ACCUMULATE = 1, 2, 4, 8
 
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",
            "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_ex", "pea_affinity_bwd_ex", "pea_inv_norm", "pea_cross_supported", "pea_affinity_bwd_dual", "pea_scale_inplace", "pea_scale_inplace_multi", "pea_fill_border_relu", "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd",
+           "pea_bwd_head_workspace_bytes", "pea_affinity_bwd_head",
            "pea_targets_workspace_bytes", "pea_gen_targets", "pea_stitch_add", "pea_stitch_finalize",
            "pea_label_weights", "pea_affinity_fwd_bwd_labels", "pea_affinity_fwd_bwd_labels_dual")
 
@@ -132,6 +133,10 @@ def lib():
     L.pea_head_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     L.pea_head_fwd.restype = ctypes.c_int
     L.pea_head_fwd.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, vp, vp, vp, vp, vp]
+    L.pea_bwd_head_workspace_bytes.restype = ctypes.c_size_t
+    L.pea_bwd_head_workspace_bytes.argtypes = [dp, ctypes.c_int]
+    L.pea_affinity_bwd_head.restype = ctypes.c_int
+    L.pea_affinity_bwd_head.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.pea_head_bwd.restype = ctypes.c_int
     L.pea_head_bwd.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     if L.pea_version() != PEA_ABI_VERSION:

@@ -248,7 +248,7 @@ bool try_bwd_xdma(const KParams& P, const float* x, const float* inv, const floa
   {                                                                                                    \
     constexpr auto kern = k_bwd_xdma<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, XP_, kAuxNT, ZP_>;            \
     allow_lds<kern>(lds);                                                                              \
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, dx);                              \
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, dx, HeadArgs{});                  \
   }
   const bool crop = P.border != PEA_BORDER_CIRCULAR;
   if constexpr (D_T == 16) {
@@ -259,6 +259,27 @@ bool try_bwd_xdma(const KParams& P, const float* x, const float* inv, const floa
   }
   if (crop) PEA_XB(true, XP, kXdmaPSU, 0) else PEA_XB(false, XP, kXdmaPSU, 0)
 #undef PEA_XB
+  return true;
+}
+
+// the cross backward with the embedding head's backward in its epilogue (k_bwd_xdma<.., HC>): 2D, D = 16, circular border
+// (every CVPPP call), C = 32 input channels (outconv_emb of ResidualUNet2D_deep).  `ntiles_out`: rows of H.partials written.
+constexpr int kHeadFuseC = 32;
+bool plan_bwd_head(const KParams& P, XParams* C, size_t* lds) {
+  if (P.D != 16 || P.border != PEA_BORDER_CIRCULAR) return false;
+  if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, C, lds) || C->npz > 0) return false;
+  return C->npx <= kXP && C->npy <= kXP;
+}
+bool try_bwd_xdma_head(const KParams& P, const float* x, const float* inv, const float* g, const float* dl, float* de,
+                       const HeadArgs& H, hipStream_t s, int* ntiles_out) {
+  XParams C;
+  size_t lds;
+  if (!plan_bwd_head(P, &C, &lds)) return false;
+  const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  constexpr auto kern = k_bwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, kXP, kAuxNT, 0, kHeadFuseC>;
+  allow_lds<kern>(lds);
+  hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, de, H);
+  *ntiles_out = C.ntiles;
   return true;
 }
 
@@ -1163,6 +1184,47 @@ int pea_head_bwd(int B, int C, int D, size_t S, const float* x, const float* W, 
   if (rc) return rc;
   const int n = D * C + D;
   hipLaunchKernelGGL(k_head_finalize, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, partials, nwg, D * C, n, dW, db);
+  return hip_rc();
+}
+
+// f1: the self-loss backward with the embedding head's backward in its epilogue
+size_t pea_bwd_head_workspace_bytes(const PeaDesc* desc, int C) {
+  if (validate(desc) || C != kHeadFuseC) return 0;
+  const KParams P = make_params(desc);
+  XParams X;
+  size_t lds;
+  if (desc->dtype != PEA_F32 || !plan_bwd_head(P, &X, &lds)) return 0;
+  return (size_t)X.ntiles * ((size_t)P.D * C + P.D) * sizeof(float);
+}
+
+int pea_affinity_bwd_head(const PeaDesc* desc, const void* e, const float* g, const float* inv_norm, const float* dloss,
+                          const float* de_add, const float* x, const float* W, int C, float* dx, float* dW, float* db, void* de,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  const int v = validate(desc);
+  if (v) return v;
+  if (!e || !g || !inv_norm || !x || !W || !dW) return PEA_E_NULL;
+  if (misaligned(e, 16) || misaligned(inv_norm, 16) || misaligned(g, 4) || misaligned(dloss, 4) || misaligned(de_add, 4) ||
+      misaligned(x, 4) || misaligned(W, 4) || misaligned(dx, 4) || misaligned(dW, 4) || misaligned(db, 4) || misaligned(de, 4) ||
+      misaligned(workspace, 4))
+    return PEA_E_ALIGN;
+  if (desc->dtype != PEA_F32 || C != kHeadFuseC || env_int("PEA_FORCE_DIRECT", 0) != 0 || env_int("PEA_BWD_XDMA", 1) == 0)
+    return PEA_E_UNSUPPORTED;
+  const size_t need = pea_bwd_head_workspace_bytes(desc, C);
+  if (need == 0) return PEA_E_UNSUPPORTED;
+  if (!workspace || workspace_bytes < need) return PEA_E_WORKSPACE;
+  const KParams P = make_params(desc);
+  if ((size_t)C * P.S * 4 >= (1ull << 31)) return PEA_E_UNSUPPORTED;  // the head tensors are addressed like e (2 GiB rule)
+  hipStream_t s = (hipStream_t)stream;
+  HeadArgs H;
+  H.x = x; H.W = W; H.de_add = de_add; H.dx = dx; H.partials = (float*)workspace;
+  if (env_int("PEA_DBG_NODW", 0)) H.partials = nullptr;
+  if (env_int("PEA_DBG_NODX", 0)) H.dx = nullptr;
+  int ntiles = 0;
+  if (!try_bwd_xdma_head(P, (const float*)e, inv_norm, g, dloss, (float*)de, H, s, &ntiles)) return PEA_E_UNSUPPORTED;
+  const int rc = hip_rc();
+  if (rc) return rc;
+  const int n = P.D * C + P.D;
+  hipLaunchKernelGGL(k_head_finalize, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, (const float*)workspace, ntiles, P.D * C, n, dW, db);
   return hip_rc();
 }
 

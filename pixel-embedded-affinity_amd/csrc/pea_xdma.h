@@ -131,10 +131,24 @@ __device__ __forceinline__ bool xdma_tile(const XParams& C, const KParams& P, in
 // AUXS: cache policy of the gradient stores (non-temporal: they must not push the halo lines out of the L2, pea_tiled.h bs_emb)
 // XP: (offset, role) pairs per axis held in registers (<= kXP; the D = 64 instantiation takes 8 to stay inside 128 VGPRs)
 // ZP: pairs along z read from global memory (0: 2D; kXZ: the 3D instantiation)
-template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, int AUXS = kAuxNT, int ZP = 0>
+// HC: input channels of the embedding head whose backward rides in the epilogue (0: none) -- SURVEY.md section 8f, f1:
+//   e = W x + b was the step before this path (OutConv, scripts_cvppp/model/unet2d_residual.py:67-74, :346), so the gradient
+//   this kernel holds in registers at its end is all the head's backward needs: dx[c] = sum_d W[d,c] de[d] leaves from here
+//   (v_fmac with W in SGPRs), and the tile's share of dW = sum_p de x^T and db = sum_p de goes through the matrix cores
+//   (v_mfma_f32_16x16x4_f32, exact f32; operands transposed through per-wave tiles laid over the dead ring, as k_head_dw does;
+//   db is the column of a constant-one "channel").  `de` itself need not be written at all.
+struct HeadArgs {
+  const float* x;       // [B, HC, S] the head's input
+  const float* W;       // [D, HC]
+  const float* de_add;  // [B, D, S] gradient reaching the embedding from elsewhere (added before the head's backward), or null
+  float* dx;            // [B, HC, S]
+  float* partials;      // [ntiles][D * HC + D]: per-tile shares of dW and db (pea_affinity_bwd_head reduces them)
+};
+template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, int AUXS = kAuxNT, int ZP = 0, int HC = 0>
 __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const XParams C, const float* __restrict__ xt,
                                                          const float* __restrict__ invp, const float* __restrict__ gin,
-                                                         const float* __restrict__ dloss, float* __restrict__ dx) {
+                                                         const float* __restrict__ dloss, float* __restrict__ dx,
+                                                         const HeadArgs H) {
   constexpr int NT = TH * TW, PS = PSU * 256, NP = D_T / 2;
   static_assert(TW == 32 && D_T % 2 == 0, "lane mapping / channel pairs");
   extern __shared__ f4 lds4[];
@@ -196,6 +210,9 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
     else if (npc == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                \
   }
+  // in the chunk loop of the 3D instantiation the z gathers of the NEXT chunk (2 * ZP loads, issued one iteration earlier) sit
+  // between the DMA that has to have landed and the youngest DMA: they may stay in flight too
+#define PEA_XWAITZ() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * ZP + 4) : "memory");
 #define PEA_XDMA(rsrc, plane_byte, so)                                                                              \
   {                                                                                                                 \
     if (SDMA) {                                                                                                     \
@@ -269,17 +286,19 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
     asm volatile("" : "+v"(cx[k]), "+v"(cy[k]));
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the inv plane is dead: buffer 2 may be filled
-  // the z neighbours' two channels of a chunk are requested BEFORE the DMA of the chunk two ahead (vmcnt retires in order:
-  // waiting for a gather issued after that DMA would wait for the DMA as well) and used after the chunk's LDS pairs
-  f2 zv[ZP > 0 ? ZP : 1];
-#define PEA_XZLOAD(ch)                                                        \
-  {                                                                           \
-    _Pragma("unroll") for (int k = 0; k < ZP; ++k) {                          \
-      zv[k].x = bl32(xB, pe, zso[k] + (unsigned)(2 * (ch)) * ecs);            \
-      zv[k].y = bl32(xB, pe, zso[k] + (unsigned)(2 * (ch) + 1) * ecs);        \
-    }                                                                         \
+  // the z neighbours' two channels of a chunk are requested TWO chunks ahead (two register sets), before the DMA of the chunk
+  // three ahead: a gather from another plane is an L2 miss more often than not here (section 5.7 item 9), and one chunk's LDS
+  // pairs do not cover that latency.  vmcnt retires in order, so the waits count the younger DMA / gathers exactly.
+  f2 zv[2][ZP > 0 ? ZP : 1];
+#define PEA_XZLOAD(ch)                                                                  \
+  {                                                                                     \
+    _Pragma("unroll") for (int k = 0; k < ZP; ++k) {                                    \
+      zv[(ch) & 1][k].x = bl32(xB, pe, zso[k] + (unsigned)(2 * (ch)) * ecs);            \
+      zv[(ch) & 1][k].y = bl32(xB, pe, zso[k] + (unsigned)(2 * (ch) + 1) * ecs);        \
+    }                                                                                   \
   }
   PEA_XZLOAD(0)
+  if (NP > 1) PEA_XZLOAD(1)
   if (NP > 2) {
     PEA_XDMA(xB, 4 * PS, ezo + 4u * ecs)
     PEA_XDMA(xB, 5 * PS, ezo + 5u * ecs)
@@ -320,7 +339,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       if (k % 5 == 4) asm volatile("" ::: "memory");
     }
 #pragma unroll
-    for (int k = 0; k < ZP; ++k) acc = __builtin_elementwise_fma((f2){cz[k], cz[k]}, zv[k], acc);
+    for (int k = 0; k < ZP; ++k) acc = __builtin_elementwise_fma((f2){cz[k], cz[k]}, zv[ps & 1][k], acc);
     if (!KEEP) {
       proj = fmaf(o.x, acc.x, fmaf(o.y, acc.y, proj));
       asm volatile("" : "+v"(proj));
@@ -329,9 +348,11 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
     G[ps] = acc;
     if (ps + 1 < NP) {
       // chunk ps + 1 has landed (chunk ps + 2, issued after it, may still fly); everyone is done with buffer ps % 3
-      if (ps + 2 < NP) PEA_XWAIT1()
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      PEA_XZLOAD(ps + 1)
+      if (ps + 2 < NP) {
+        if (ZP > 0) PEA_XWAITZ()
+        else PEA_XWAIT1()
+      } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (ps + 2 < NP) PEA_XZLOAD(ps + 2)
       if (ps + 3 < NP) {
         PEA_XDMA(xB, bo, ezo + (unsigned)(2 * ps + 6) * ecs)
         PEA_XDMA(xB, bo + PS, ezo + (unsigned)(2 * ps + 7) * ecs)
@@ -340,6 +361,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   }
 #undef PEA_XDMA
 #undef PEA_XWAIT1
+#undef PEA_XWAITZ
 #undef PEA_XZLOAD
 
   if (KEEP) {
@@ -349,13 +371,104 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   if (invo < 0.f) proj = 0.f;  // clamp branch of F.normalize
   const float sc = dl * inv_own;
   const float pn = proj * inv_own;  // !KEEP: ehat * proj = e * (inv_own * proj)
+  if constexpr (HC == 0) {
 #pragma unroll
-  for (int ps = 0; ps < NP; ++ps) {
-    float ex, ey;
-    if (KEEP) { ex = eh[ps].x * proj; ey = eh[ps].y * proj; }
-    else { ex = bl32(xB, pe, ezo + (unsigned)(2 * ps) * ecs) * pn; ey = bl32(xB, pe, ezo + (unsigned)(2 * ps + 1) * ecs) * pn; }
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (G[ps].x - ex) * sc), dB, pe, ezo + (unsigned)(2 * ps) * ecs, AUXS);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (G[ps].y - ey) * sc), dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs, AUXS);
+    for (int ps = 0; ps < NP; ++ps) {
+      float ex, ey;
+      if (KEEP) { ex = eh[ps].x * proj; ey = eh[ps].y * proj; }
+      else { ex = bl32(xB, pe, ezo + (unsigned)(2 * ps) * ecs) * pn; ey = bl32(xB, pe, ezo + (unsigned)(2 * ps + 1) * ecs) * pn; }
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (G[ps].x - ex) * sc), dB, pe, ezo + (unsigned)(2 * ps) * ecs, AUXS);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (G[ps].y - ey) * sc), dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs, AUXS);
+    }
+  } else {
+    static_assert(HC == 0 || (KEEP && D_T == 16 && HC % 16 == 0 && HC <= 64), "head epilogue: D = 16, C a multiple of 16");
+    constexpr int kRow = 68;                      // LDS row stride (floats) of a [channel][64 px] tile: conflict-free both ways
+    constexpr int CC = HC / 16, NW = NT / 64;     // 16-channel blocks of x (+ one block for db), waves
+    constexpr int kRed = D_T * 16 * (CC + 1);     // one wave's [d][16 * (CC + 1)] result tile
+    static_assert(NW * 2 * 16 * kRow * 4 <= 6 * PS && NW * kRed * 4 <= 6 * PS, "the transposition tiles fit the dead ring");
+    // ---- the gradient of this lane's pixel (dead lanes: 0), plus whatever reaches the embedding from other losses
+    float dv[D_T];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      dv[2 * ps] = live ? (G[ps].x - eh[ps].x * proj) * sc : 0.f;
+      dv[2 * ps + 1] = live ? (G[ps].y - eh[ps].y * proj) * sc : 0.f;
+    }
+    if (H.de_add) {
+      const rsrc_t aB = mkbuf(H.de_add + (size_t)b * D_T * S);
+#pragma unroll
+      for (int d = 0; d < D_T; ++d) dv[d] += bl32(aB, pe, ezo + (unsigned)d * ecs);
+    }
+    if (dx) {
+#pragma unroll
+      for (int d = 0; d < D_T; ++d)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dv[d]), dB, pe, ezo + (unsigned)d * ecs, AUXS);
+    }
+    // ---- dx = W^T de: one output channel at a time, W through the scalar cache
+    const rsrc_t hxB = mkbuf(H.x + (size_t)b * HC * S), hdB = mkbuf(H.dx + (size_t)b * HC * S);
+    const float* __restrict__ Wm = H.W;
+    if (H.dx) {
+#pragma unroll
+      for (int c = 0; c < HC; ++c) {
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < D_T; ++d) a = fmaf(Wm[d * HC + c], dv[d], a);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a), hdB, pe, ezo + (unsigned)c * ecs, AUXS);
+      }
+    }
+    if (!H.partials) return;  // dx only (uniform)
+    // ---- dW / db share of this tile.  MFMA operand coordinates of a lane: row / column mi, k index mk; a k-step is 4 pixels
+    lds_barrier();  // every wave is done with the ring
+    float* tA = (float*)lds + wave * (2 * 16 * kRow);
+    float* tB = tA + 16 * kRow;
+    const int mi = lane & 15, mk = lane >> 4;
+    typedef float hv4_t __attribute__((ext_vector_type(4)));
+    hv4_t acc[CC + 1];
+#pragma unroll
+    for (int j = 0; j <= CC; ++j) acc[j] = hv4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < D_T; ++d) tA[d * kRow + lane] = dv[d];
+    __builtin_amdgcn_wave_barrier();
+    float av[16];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) av[st] = tA[mi * kRow + 4 * st + mk];
+#pragma unroll
+    for (int j = 0; j <= CC; ++j) {
+      float xv[16];
+      if (j < CC) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xv[r] = bl32(hxB, pe, ezo + (unsigned)(16 * j + r) * ecs);  // dead lanes read 0
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xv[r] = (r == 0 && live) ? 1.f : 0.f;  // the constant-one channel: its dW column is db
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tB[r * kRow + lane] = xv[r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {
+        const float bv = tB[mi * kRow + 4 * st + mk];
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv, acc[j], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();  // the next block's writes come after these reads
+    }
+    // ---- the waves' tiles summed in wave order -> partials[tile]
+    lds_barrier();
+    float* red = (float*)lds;  // [NW][kRed]
+#pragma unroll
+    for (int j = 0; j <= CC; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)  // C/D layout: row = 4 * (lane >> 4) + r, column = lane & 15
+        red[wave * kRed + (4 * mk + r) * (16 * (CC + 1)) + 16 * j + mi] = acc[j][r];
+    lds_barrier();
+    float* out = H.partials + (size_t)tile * (D_T * HC + D_T);
+    for (int t = threadIdx.x; t < D_T * HC + D_T; t += NT) {
+      const int d = t < D_T * HC ? t / HC : t - D_T * HC;
+      const int col = t < D_T * HC ? t - d * HC : 16 * CC;
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sum += red[w * kRed + d * (16 * (CC + 1)) + col];
+      out[t] = sum;
+    }
   }
 }
 
@@ -482,6 +595,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
     else if (npc == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                \
   }
+#define PEA_XWAITZ() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * ZF + 4) : "memory");
   PEA_XDMA(0, ezo)
   PEA_XDMA(PS, ezo + ecs)
   if (NP > 1) {
@@ -501,8 +615,8 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
   }
   if (NP > 1) PEA_XWAIT1()
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  // z offsets: the neighbour is the same (y, x) in plane z + dz (wave-uniform plane and validity); requested before the DMA
-  // of the chunk two ahead, used after the chunk's LDS offsets (k_bwd_xdma)
+  // z offsets: the neighbour is the same (y, x) in plane z + dz (wave-uniform plane and validity); requested two chunks ahead
+  // into two register sets, used after the chunk's LDS offsets (k_bwd_xdma)
   unsigned zso[ZF > 0 ? ZF : 1];
   bool zok[ZF > 0 ? ZF : 1];
 #pragma unroll
@@ -512,15 +626,16 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
     zok[k] = okq && k < C.nfz;
     zso[k] = (unsigned)(zok[k] ? zq : z) * YX * 4u;
   }
-  f2 zv[ZF > 0 ? ZF : 1];
-#define PEA_XZLOAD(ch)                                                        \
-  {                                                                           \
-    _Pragma("unroll") for (int k = 0; k < ZF; ++k) {                          \
-      zv[k].x = bl32(xB, pe, zso[k] + (unsigned)(2 * (ch)) * ecs);            \
-      zv[k].y = bl32(xB, pe, zso[k] + (unsigned)(2 * (ch) + 1) * ecs);        \
-    }                                                                         \
+  f2 zv[2][ZF > 0 ? ZF : 1];
+#define PEA_XZLOAD(ch)                                                                  \
+  {                                                                                     \
+    _Pragma("unroll") for (int k = 0; k < ZF; ++k) {                                    \
+      zv[(ch) & 1][k].x = bl32(xB, pe, zso[k] + (unsigned)(2 * (ch)) * ecs);            \
+      zv[(ch) & 1][k].y = bl32(xB, pe, zso[k] + (unsigned)(2 * (ch) + 1) * ecs);        \
+    }                                                                                   \
   }
   PEA_XZLOAD(0)
+  if (NP > 1) PEA_XZLOAD(1)
   if (NP > 2) {
     PEA_XDMA(4 * PS, ezo + 4u * ecs)
     PEA_XDMA(5 * PS, ezo + 5u * ecs)
@@ -549,8 +664,8 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
     }
 #pragma unroll
     for (int k = 0; k < ZF; ++k) {
-      dotz[k] = __builtin_elementwise_fma(o, zv[k], dotz[k]);
-      ssqz[k] = __builtin_elementwise_fma(zv[k], zv[k], ssqz[k]);
+      dotz[k] = __builtin_elementwise_fma(o, zv[ps & 1][k], dotz[k]);
+      ssqz[k] = __builtin_elementwise_fma(zv[ps & 1][k], zv[ps & 1][k], ssqz[k]);
     }
 #pragma unroll
     for (int k = 0; k < kXP; ++k) asm volatile("" : "+v"(dot[k]), "+v"(ssq[k]));  // the chunk's sums exist before its barrier
@@ -558,9 +673,11 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
     for (int k = 0; k < ZF; ++k) asm volatile("" : "+v"(dotz[k]), "+v"(ssqz[k]));
     asm volatile("" : "+v"(oss));
     if (ps + 1 < NP) {
-      if (ps + 2 < NP) PEA_XWAIT1()
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      PEA_XZLOAD(ps + 1)
+      if (ps + 2 < NP) {
+        if (ZF > 0) PEA_XWAITZ()
+        else PEA_XWAIT1()
+      } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (ps + 2 < NP) PEA_XZLOAD(ps + 2)
       if (ps + 3 < NP) {
         PEA_XDMA(bo, ezo + (unsigned)(2 * ps + 6) * ecs)
         PEA_XDMA(bo + PS, ezo + (unsigned)(2 * ps + 7) * ecs)
@@ -569,6 +686,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
   }
 #undef PEA_XDMA
 #undef PEA_XWAIT1
+#undef PEA_XWAITZ
 #undef PEA_XZLOAD
   if (LATE) PEA_XLOAD_TWM()
 #undef PEA_XLOAD_TWM

@@ -28,7 +28,7 @@ def test_header_declares_the_expected_entry_points():
                                          "pea_scale_inplace", "pea_scale_inplace_multi", "pea_fill_border_relu",
                                          "pea_targets_workspace_bytes", "pea_gen_targets",
                                          "pea_stitch_add", "pea_stitch_finalize", "pea_label_weights",
-                                         "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd",
+                                         "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd", "pea_bwd_head_workspace_bytes", "pea_affinity_bwd_head",
                                          "pea_affinity_fwd_bwd_labels", "pea_affinity_fwd_bwd_labels_dual"])
 
 

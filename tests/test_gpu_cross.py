@@ -174,3 +174,56 @@ def test_cross_3d_norm5_vs_oracle(pkg, dev, orc, synth, shape):
     assert np.abs(affs.cpu().numpy() - o_affs).max() < AFFS_ATOL
     assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
     assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL
+
+
+@pytest.mark.parametrize("with_other_loss,one_launch", [(False, True), (True, True), (True, False)])
+def test_head_backward_in_the_loss_backward_epilogue(pkg, dev, orc, synth, with_other_loss, one_launch):
+    """f1: head(x) -> embedding_loss -> backward as ONE node (pea_affinity_bwd_head: dx, dW, db leave the cross backward's
+    epilogue) against the two separate nodes, and against the oracle chain c_bwd -> np_head_bwd (float64 head restatement);
+    with_other_loss: a second loss on the embedding output, whose gradient the kernel adds before the head's backward"""
+    B, C, D, H, W = 2, 32, 16, 72, 96                       # ragged in y (4.5 tiles), K = 10 shipped stencil
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], neighbor=4)
+    K = len(offsets)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    wt = (rng.standard_normal((D, C, 1, 1)) * 0.3).astype(np.float32)
+    bs = rng.standard_normal(D).astype(np.float32)
+    _, t, w, m = _inputs(synth, B, D, [1, H, W], K, 5)
+    t, w, m = t[:, :, 0], w[:, :, 0], m[:, :, 0]
+    R = rng.standard_normal((B, D, H, W)).astype(np.float32) * 1e-3
+    crit = pkg.WeightedMSE()
+
+    def run(fused):
+        head = pkg.OutConv(C, D).to(dev)
+        with torch.no_grad():
+            head.conv.weight.copy_(cu(wt, dev)); head.conv.bias.copy_(cu(bs, dev))
+        xt = cu(x, dev).requires_grad_(True)
+        if fused:
+            loss, affs, parts, emb = pkg.head_embedding_loss(xt, head, cu(t, dev), cu(w, dev), cu(m, dev), crit, offsets,
+                                                             fused_backward=one_launch)
+        else:
+            emb = head(xt)
+            loss, affs, parts = pkg.embedding_loss(emb, cu(t, dev), cu(w, dev), cu(m, dev), crit, offsets)
+        total = loss * 0.5
+        if with_other_loss:
+            total = total + (emb * cu(R, dev)).sum()
+        total.backward()
+        return (loss.item(), affs.cpu().numpy(), xt.grad.cpu().numpy(), head.conv.weight.grad.cpu().numpy().reshape(D, C),
+                head.conv.bias.grad.cpu().numpy(), emb.detach().cpu().numpy())
+
+    lf, af, dxf, dwf, dbf, ef = run(True)
+    ls, a_s, dxs, dws, dbs, es = run(False)
+    assert lf == ls and np.array_equal(af, a_s) and np.array_equal(ef, es)          # same forward kernels
+    assert relmax(dxf, dxs) < 2e-6 and relmax(dwf, dws) < 1e-5 and relmax(dbf, dbs) < 1e-5
+    # the oracle chain
+    e_o = orc.np_head_fwd(x, wt.reshape(D, C), bs)
+    d = orc.desc_2d(e_o, offsets)
+    o_de, _ = orc.c_bwd(d, e_o, None, t, w, m, dloss=0.5)
+    if with_other_loss:
+        o_de = o_de + R
+    o_dx, o_dw, o_db = orc.np_head_bwd(x, wt.reshape(D, C), o_de)
+    assert relmax(dxf, o_dx) < GRAD_RTOL and relmax(dwf, o_dw) < GRAD_RTOL and relmax(dbf, o_db) < GRAD_RTOL
+    # the fused entry point did run (this shape is covered)
+    L = pkg._lib.lib()
+    spec = pkg.affinity_op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX)
+    assert L.pea_bwd_head_workspace_bytes(ctypes.byref(pkg.affinity_op.make_desc(spec, cu(ef, dev))), C) > 0
