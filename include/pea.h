@@ -69,6 +69,9 @@ extern "C" {
                                   1 - |ehat_p - ehat_q|^2 / 4 of scripts_ac3ac4/loss/embedding2affs_3d_l2.py:10-11) */
 #define PEA_FLAG_RELU_AFFS 1u  /* a -> max(a, 0)     (F.relu(pred), scripts_cvppp/main.py:312, inference.py:193) */
 #define PEA_FLAG_CLAMP01 8u    /* a -> clamp(a, 0, 1) (torch.clamp(affs_temp, 0.0, 1.0), loss_embedding.py:11,36) */
+#define PEA_FLAG_ACCUMULATE_DE 16u /* pea_affinity_bwd_ex with a detached second operand: de += (the self loss' gradient of the same
+                                    embedding is already in `de`: loss_embedding + loss_embedding_cross, main.py:306-310, one buffer);
+                                    PEA_E_UNSUPPORTED where the role-A cross kernel does not apply (the caller adds two buffers) */
 #define PEA_FLAG_ONE_MINUS 2u  /* a -> 1 - a         (what elf's mutex_watershed is handed: scripts_cvppp/utils/seg_mutex.py:4-5) */
 
 /* error codes: 0 = ok, negative = PEA_E_*, positive = a hipError_t from the runtime */
@@ -143,7 +146,12 @@ int pea_affinity_bwd(const PeaDesc *desc, const void *e, const void *e_other, co
  * (csrc/pea_xdma.h): the channels go through LDS two at a time and sum_i g_i ehat(q_i) needs 1 / |e(q_i)| before the
  * first chunk.  pea_affinity_bwd_ex with inv_norm == NULL, a second operand, f16 storage, D != 16 or any other stencil
  * takes the kernels of pea_affinity_bwd -- same result either way.  pea_inv_norm computes the plane alone (for callers
- * that hold e but did not run the forward: the vjp of a foreign criterion). */
+ * that hold e but did not run the forward: the vjp of a foreign criterion).
+ * With a second operand (e_other != NULL: ema_embedding_loss, loss_embedding_mse.py:79-95) inv_norm is TWO planes,
+ * [2, B, Z, Y, X]: 1 / norm of e, then of e_other.  The forward then stages e_other and reads the own pixel from e; the backward
+ * with de_other == NULL (the shipped, detached case) is the role-A cross kernel: sum_i g_i(p) ehat_other(p + o_i), projected on
+ * e's tangent space, written to de -- or ADDED to it with PEA_FLAG_ACCUMULATE_DE in desc->flags.  2D, D = 16, f32 only; other
+ * shapes fill the two planes with separate launches and take the tiled kernels. */
 int pea_affinity_fwd_ex(const PeaDesc *desc, const void *e, const void *e_other, const float *target,
                         const float *weight, const uint8_t *mask, float *affs, float *g_out, float *inv_norm_out,
                         float *loss_out, void *workspace, size_t workspace_bytes, void *stream);
@@ -151,7 +159,8 @@ int pea_affinity_bwd_ex(const PeaDesc *desc, const void *e, const void *e_other,
                         const float *dloss, void *de, void *de_other, void *stream);
 int pea_inv_norm(const PeaDesc *desc, const void *e, float *inv_norm_out, void *stream);
 /* Host-only: 1 when the LDS-DMA cross kernels cover the descriptor (self loss, 16-byte aligned tensors assumed) for the
- * forward (backward == 0) or the backward (backward != 0, given the 1 / norm plane), else 0 (the tiled / direct kernels run). */
+ * forward (backward == 0) or the backward (backward == 1, given the 1 / norm plane); backward == 2: the cross loss with a detached
+ * second operand (forward and role-A backward, given the two planes); else 0 (the tiled / direct kernels run). */
 int pea_cross_supported(const PeaDesc *desc, int backward);
 
 /* The backward of the full-resolution pair of the training loop in one launch: g is what pea_affinity_fwd wrote for the self

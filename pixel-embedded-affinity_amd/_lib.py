@@ -20,7 +20,7 @@ E_UNSUPPORTED = -3
 BORDER_CIRCULAR, BORDER_CROP_ZERO, BORDER_REPLICATE = 0, 1, 2
 F32, F16 = 0, 1
 NORM_BX, NORM_CROPPED, NORM_FULL = 0, 1, 2
-FLAG_RELU_AFFS, FLAG_ONE_MINUS, FLAG_HALF_SHIFT, FLAG_CLAMP01 = 1, 2, 4, 8  # activation of the affs output (include/pea.h)
+FLAG_RELU_AFFS, FLAG_ONE_MINUS, FLAG_HALF_SHIFT, FLAG_CLAMP01, FLAG_ACCUMULATE_DE = 1, 2, 4, 8, 16  # activation of the affs output (include/pea.h)
 TGT_PADDING, TGT_BOTH_FOREGROUND, TGT_MASK_INSIDE, TGT_ACCUMULATE = 1, 2, 4, 8
 
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",

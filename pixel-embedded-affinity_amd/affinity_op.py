@@ -185,9 +185,13 @@ class FusedAffinityMSE(torch.autograd.Function):
             work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=e_c.device)
             # g = d loss / d affs is all the backward needs besides the embeddings; skip it when nothing trains
             g = torch.empty(kshape, dtype=torch.float32, device=e_c.device) if (want_e or want_o) else None
-            # 1 / norm of e, 4 bytes per pixel: what the cross backward (self loss, axis-aligned stencil) stages next to e
-            inv = (torch.empty((e_c.shape[0],) + tuple(e_c.shape[2:]), dtype=torch.float32, device=e_c.device)
-                   if (want_e and o_c is None) else None)
+            # 1 / norm of e, 4 bytes per pixel: what the cross backward (self loss, axis-aligned stencil) stages next to e;
+            # with a detached second operand two planes (e, e_other) where the role-A cross kernels cover the shape
+            inv = None
+            if want_e and o_c is None:
+                inv = torch.empty((e_c.shape[0],) + tuple(e_c.shape[2:]), dtype=torch.float32, device=e_c.device)
+            elif want_e and not want_o and L.pea_cross_supported(ctypes.byref(d), 2):
+                inv = torch.empty((2, e_c.shape[0]) + tuple(e_c.shape[2:]), dtype=torch.float32, device=e_c.device)
             _lib.check(L.pea_affinity_fwd_ex(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(target), _ptr(weight), _ptr(mask),
                                              _ptr(affs), _ptr(g), _ptr(inv), _ptr(loss_vec), _ptr(work), wsb, _stream()),
                        "pea_affinity_fwd_ex")

@@ -248,7 +248,7 @@ bool try_bwd_xdma(const KParams& P, const float* x, const float* inv, const floa
   {                                                                                                    \
     constexpr auto kern = k_bwd_xdma<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, XP_, kAuxNT, ZP_>;            \
     allow_lds<kern>(lds);                                                                              \
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, dx, HeadArgs{});                  \
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, dx, HeadArgs{}, OtherArgs{});     \
   }
   const bool crop = P.border != PEA_BORDER_CIRCULAR;
   if constexpr (D_T == 16) {
@@ -278,8 +278,45 @@ bool try_bwd_xdma_head(const KParams& P, const float* x, const float* inv, const
   const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
   constexpr auto kern = k_bwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, kXP, kAuxNT, 0, kHeadFuseC>;
   allow_lds<kern>(lds);
-  hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, de, H);
+  hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, de, H, OtherArgs{});
   *ntiles_out = C.ntiles;
+  return true;
+}
+
+// the cross loss with a second operand on the cross kernels: 2D, D = 16, f32, circular border, axis-aligned stencil.
+// forward: e_other staged, own pixel from e, both 1 / norm planes written (inv2[0 .. B*S) own, inv2[B*S .. 2*B*S) second operand)
+bool try_fwd_xdma_other(const KParams& P, const float* e, const float* e_other, const float* t, const float* w, const uint8_t* m,
+                        float* affs, float* gout, float* partials, float* inv2, hipStream_t s, int* nparts) {
+  if (env_int("PEA_FWD_XDMA", 1) == 0 || P.D != 16 || P.border != PEA_BORDER_CIRCULAR) return false;
+  if (misaligned(e, 4) || misaligned(e_other, 16) || misaligned(t, 16) || misaligned(w, 16) || misaligned(affs, 16) ||
+      misaligned(gout, 16) || misaligned(m, 4) || misaligned(inv2, 4))
+    return false;
+  if ((P.tbs | P.wbs | P.mbs) & 3) return false;
+  XParams C;
+  size_t lds;
+  if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds, 1) || C.nfz > 0 || P.K > kXP) return false;
+  const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  constexpr auto kern = k_fwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, true, 0, true>;
+  allow_lds<kern>(lds);
+  hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, e_other, t, w, m, affs, gout, partials, inv2, e,
+                     inv2 ? inv2 + (size_t)P.B * P.S : nullptr);
+  *nparts = C.ntiles;
+  return true;
+}
+// backward, role A only (the second operand is detached): de (+)= dloss * d loss / d e
+bool try_bwd_xdma_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* dl,
+                        float* de, bool accumulate, hipStream_t s) {
+  if (!inv2 || env_int("PEA_BWD_XDMA", 1) == 0 || P.D != 16 || P.border != PEA_BORDER_CIRCULAR) return false;
+  if (misaligned(e_other, 16) || misaligned(inv2, 16) || ((size_t)P.B * P.S) % 4) return false;
+  XParams C;
+  size_t lds;
+  if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds, 2) || C.npx > kXP || C.npy > kXP) return false;
+  const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  constexpr auto kern = k_bwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, kXP, kAuxNT, 0, 0, true>;
+  allow_lds<kern>(lds);
+  OtherArgs O;
+  O.own = e; O.own_inv = inv2; O.accumulate = accumulate ? 1 : 0;
+  hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, e_other, inv2 + (size_t)P.B * P.S, g, dl, de, HeadArgs{}, O);
   return true;
 }
 
@@ -306,7 +343,7 @@ bool try_fwd_xdma(const KParams& P, const float* e, const float* t, const float*
   {                                                                                                    \
     constexpr auto kern = k_fwd_xdma<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, TRAIN, ZF_>;                  \
     allow_lds<kern>(lds);                                                                              \
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, e, t, w, m, affs, gout, partials, inv_out);      \
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, e, t, w, m, affs, gout, partials, inv_out, (const float*)nullptr, (float*)nullptr); \
   }
   const bool crop = P.border != PEA_BORDER_CIRCULAR;
   bool done = false;
@@ -801,13 +838,25 @@ int pea_affinity_fwd_ex(const PeaDesc* desc, const void* e, const void* e_other,
   float* partials = (float*)workspace;
   int nparts = 0;
   const bool self = !e_other || e_other == e;
+  if (!self && inv_norm_out && desc->dtype == PEA_F32 && env_int("PEA_FORCE_DIRECT", 0) == 0 &&
+      try_fwd_xdma_other(P, (const float*)e, (const float*)e_other, target, weight, mask, affs, g_out, partials, inv_norm_out, s,
+                         &nparts)) {
+    launch_loss_finalize(P, partials, nparts, loss_out, s);
+    return hip_rc();
+  }
   rc = desc->dtype == PEA_F16
            ? launch_fwd<__half, true>(P, e, e_other, target, weight, mask, affs, g_out, partials, self ? inv_norm_out : nullptr, s, &nparts)
            : launch_fwd<float, true>(P, e, e_other, target, weight, mask, affs, g_out, partials, self ? inv_norm_out : nullptr, s, &nparts);
   if (rc) return rc;
-  if (inv_norm_out && !self) {  // second operand: the staging works on e_other, so the plane of e takes its own launch
-    if (desc->dtype == PEA_F16) launch_inv_norm<__half>(P, (const __half*)e, inv_norm_out, s);
-    else launch_inv_norm<float>(P, (const float*)e, inv_norm_out, s);
+  if (inv_norm_out && !self) {  // second operand, not on the cross kernels: the two planes take their own launches
+    float* inv_o = inv_norm_out + (size_t)P.B * P.S;
+    if (desc->dtype == PEA_F16) {
+      launch_inv_norm<__half>(P, (const __half*)e, inv_norm_out, s);
+      launch_inv_norm<__half>(P, (const __half*)e_other, inv_o, s);
+    } else {
+      launch_inv_norm<float>(P, (const float*)e, inv_norm_out, s);
+      launch_inv_norm<float>(P, (const float*)e_other, inv_o, s);
+    }
   }
   launch_loss_finalize(P, partials, nparts, loss_out, s);
   return hip_rc();
@@ -826,6 +875,11 @@ int pea_cross_supported(const PeaDesc* desc, int backward) {
   if (env_int(backward ? "PEA_BWD_XDMA" : "PEA_FWD_XDMA", 1) == 0) return 0;
   XParams C;
   size_t lds;
+  if (backward == 2) {  // the cross loss with a detached second operand: forward and role-A backward
+    if (P.D != 16 || P.border != PEA_BORDER_CIRCULAR || P.K > kXP || env_int("PEA_FWD_XDMA", 1) == 0) return 0;
+    if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds, 1) || C.nfz > 0) return 0;
+    return plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds, 2) ? 1 : 0;
+  }
   if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU3, &C, &lds, backward == 0)) return 0;
   const bool z3 = C.npz > 0 || C.nfz > 0;
   if (z3) return (P.D == 16 && C.npx <= 8 && C.npy <= 8 && P.K <= kXP + 2) ? 1 : 0;
@@ -869,6 +923,11 @@ int pea_affinity_bwd_ex(const PeaDesc* desc, const void* e, const void* e_other,
     }
     return h ? launch_bwd<__half>(P, 3, e, e, e, g, dloss, de, s) : launch_bwd<float>(P, 3, e, e, e, g, dloss, de, s);
   }
+  const bool accumulate = (desc->flags & PEA_FLAG_ACCUMULATE_DE) != 0;
+  if (de && !de_other && !h && env_int("PEA_FORCE_DIRECT", 0) == 0 &&
+      try_bwd_xdma_other(P, (const float*)e, (const float*)e_other, inv_norm, g, dloss, (float*)de, accumulate, s))
+    return hip_rc();  // detached second operand: the role-A cross kernel (inv_norm = the two planes pea_affinity_fwd_ex wrote)
+  if (accumulate) return PEA_E_UNSUPPORTED;
   if (de) {
     rc = h ? launch_bwd<__half>(P, 1, e, e_other, nullptr, g, dloss, de, s)
            : launch_bwd<float>(P, 1, e, e_other, nullptr, g, dloss, de, s);

@@ -144,11 +144,21 @@ struct HeadArgs {
   float* dx;            // [B, HC, S]
   float* partials;      // [ntiles][D * HC + D]: per-tile shares of dW and db (pea_affinity_bwd_head reduces them)
 };
-template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, int AUXS = kAuxNT, int ZP = 0, int HC = 0>
+// OTHER: the cross loss with a detached second operand (ema_embedding_loss, scripts_cvppp/loss/loss_embedding_mse.py:79-95 with
+//   convert_consistency_flip's detach): role A only.  xt / invp are the SECOND operand and its 1 / norm plane (the neighbours);
+//   the own pixel and its 1 / norm come from O.own / O.own_inv (global loads, once per tile); O.accumulate: dx += instead of =
+//   (the self loss' gradient of the same embedding is already there).  plan_xdma mode 2.
+struct OtherArgs {
+  const float* own;      // [B, D, S] the embedding that is differentiated
+  const float* own_inv;  // [B, S] its signed 1 / norm plane
+  int accumulate;
+};
+template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, int AUXS = kAuxNT, int ZP = 0, int HC = 0, bool OTHER = false>
 __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const XParams C, const float* __restrict__ xt,
                                                          const float* __restrict__ invp, const float* __restrict__ gin,
                                                          const float* __restrict__ dloss, float* __restrict__ dx,
-                                                         const HeadArgs H) {
+                                                         const HeadArgs H, const OtherArgs O) {
+  static_assert(!OTHER || (D_T <= 16 && ZP == 0 && HC == 0), "role-A instantiation: D <= 16, in-plane, no head epilogue");
   constexpr int NT = TH * TW, PS = PSU * 256, NP = D_T / 2;
   static_assert(TW == 32 && D_T % 2 == 0, "lane mapping / channel pairs");
   extern __shared__ f4 lds4[];
@@ -269,13 +279,25 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
     const float iq = bl32(iB, pe, zso[k]);
     cz[k] = ok ? gk * fabsf(iq) : 0.f;
   }
+  // OTHER: the own pixel (all channels) and its 1 / norm, requested before the second chunk's DMA like the coefficients
+  f2 eo[OTHER ? D_T / 2 : 1];
+  float invo_g = 0.f;
+  if (OTHER) {
+    const rsrc_t oB = mkbuf(O.own + (size_t)b * D_T * S), oiB = mkbuf(O.own_inv + (size_t)b * S);
+#pragma unroll
+    for (int ps = 0; ps < D_T / 2; ++ps) {
+      eo[ps].x = bl32(oB, pe, ezo + (unsigned)(2 * ps) * ecs);
+      eo[ps].y = bl32(oB, pe, ezo + (unsigned)(2 * ps + 1) * ecs);
+    }
+    invo_g = bl32(oiB, pe, ezo);
+  }
   PEA_XDMA(xB, 2 * PS, ezo + 2u * ecs)
   PEA_XDMA(xB, 3 * PS, ezo + 3u * ecs)
   // inv, chunk 0 and g have landed (the 4 DMA instructions of chunk 1 may still fly); every wave's share of them too
   PEA_XWAIT1()
 
   // coefficient of a pair = g * 1 / |e(q)|
-  const float invo = *(const float*)(lds + 4 * PS + vown);
+  const float invo = OTHER ? invo_g : *(const float*)(lds + 4 * PS + vown);
   const float inv_own = fabsf(invo);
 #pragma unroll
   for (int k = 0; k < XP; ++k) {
@@ -314,8 +336,11 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   for (int ps = 0; ps < NP; ++ps) {
     const int bo = (ps % 3) * 2 * PS;
     f2 o;
-    o.x = *(const float*)(lds + bo + vown);
-    o.y = *(const float*)(lds + bo + PS + vown);
+    if (OTHER) o = eo[ps];
+    else {
+      o.x = *(const float*)(lds + bo + vown);
+      o.y = *(const float*)(lds + bo + PS + vown);
+    }
     o = o * inv_own;
     if (KEEP) {
       eh[ps] = o;
@@ -372,13 +397,24 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   const float sc = dl * inv_own;
   const float pn = proj * inv_own;  // !KEEP: ehat * proj = e * (inv_own * proj)
   if constexpr (HC == 0) {
+    f2 old[OTHER ? NP : 1];
+    const bool accum = OTHER && O.accumulate != 0;  // uniform
+    if (OTHER && accum) {
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        old[ps].x = bl32(dB, pe, ezo + (unsigned)(2 * ps) * ecs);
+        old[ps].y = bl32(dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs);
+      }
+    }
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
       float ex, ey;
       if (KEEP) { ex = eh[ps].x * proj; ey = eh[ps].y * proj; }
       else { ex = bl32(xB, pe, ezo + (unsigned)(2 * ps) * ecs) * pn; ey = bl32(xB, pe, ezo + (unsigned)(2 * ps + 1) * ecs) * pn; }
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (G[ps].x - ex) * sc), dB, pe, ezo + (unsigned)(2 * ps) * ecs, AUXS);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (G[ps].y - ey) * sc), dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs, AUXS);
+      float vx = (G[ps].x - ex) * sc, vy = (G[ps].y - ey) * sc;
+      if (OTHER && accum) { vx += old[ps].x; vy += old[ps].y; }
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), dB, pe, ezo + (unsigned)(2 * ps) * ecs, AUXS);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs, AUXS);
     }
   } else {
     static_assert(HC == 0 || (KEEP && D_T == 16 && HC % 16 == 0 && HC <= 64), "head epilogue: D = 16, C a multiple of 16");
@@ -483,16 +519,21 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
 // ------------------------------------------------------------------------------------------------------------------
 // ZF: z offsets read from global memory (0: 2D; kXZ / 2: the 3D instantiation, which also issues its DMA unconditionally --
 // SDMA, see k_bwd_xdma -- and requests target / weight / mask only after the channel loop: their registers go to the z sums)
-template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN, int ZF = 0>
+// OTHER: the cross loss a_i(p) = <ehat(p), ehat_other(p + o_i)> (ema_embedding_loss): `e` is the SECOND operand (staged: the
+//   neighbours), the own pixel comes from `own` (global loads, all channels up front); both 1 / norm planes are written
+//   (inv_out: own, inv_other_out: the second operand's, from the staged centre) for the role-A backward
+template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN, int ZF = 0, bool OTHER = false>
 __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const XParams C, const float* __restrict__ e,
                                                          const float* __restrict__ target, const float* __restrict__ weight,
                                                          const uint8_t* __restrict__ mask, float* __restrict__ affs,
                                                          float* __restrict__ gout, float* __restrict__ partials,
-                                                         float* __restrict__ inv_out) {
+                                                         float* __restrict__ inv_out, const float* __restrict__ own,
+                                                         float* __restrict__ inv_other_out) {
+  static_assert(!OTHER || (D_T <= 16 && ZF == 0), "cross-loss instantiation: D <= 16, in-plane");
   constexpr int NT = TH * TW, PS = PSU * 256, NP = D_T / 2, TP = NT, QP = TP / 4, NSL = QP / 64;
   constexpr int KMAX = ZF > 0 ? kXP + 2 : kXP;      // channels the epilogue handles (norm5: 8 in-plane + 4 z offsets)
   constexpr int ITEMS = (KMAX * QP + NT - 1) / NT;
-  constexpr bool SDMA = ZF > 0, LATE = ZF > 0;
+  constexpr bool SDMA = ZF > 0, LATE = ZF > 0 || OTHER;  // OTHER: the own pixel's registers instead of the early t / w / m
   static_assert(TW == 32 && D_T % 2 == 0 && QP % 64 == 0, "lane mapping / channel pairs");
   static_assert(KMAX * TP * 4 + KMAX * NSL * 4 <= 6 * PS && KMAX <= kXK, "the parked dot products fit the ring");
   extern __shared__ f4 lds4[];
@@ -579,6 +620,15 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
   const unsigned vo1 = SDMA ? (two ? vo[1] : vo[0]) : vo[1];
   const int w1 = SDMA ? (two ? wbase + (NT / 64) * 1024 : wbase) : wbase + (NT / 64) * 1024;
   const int npc = SDMA ? 4 : 2 * ((__builtin_amdgcn_ballot_w64(act[0]) != 0) + (__builtin_amdgcn_ballot_w64(act[1]) != 0));
+  f2 eo[OTHER ? NP : 1];  // OTHER: the own pixel, requested before the first DMA (vmcnt retires in order)
+  if (OTHER) {
+    const rsrc_t oB = mkbuf(own + (size_t)b * D_T * S);
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      eo[ps].x = bl32(oB, pe, ezo + (unsigned)(2 * ps) * ecs);
+      eo[ps].y = bl32(oB, pe, ezo + (unsigned)(2 * ps + 1) * ecs);
+    }
+  }
 #define PEA_XDMA(plane_byte, so)                                                                                    \
   {                                                                                                                 \
     if (SDMA) {                                                                                                     \
@@ -641,7 +691,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
     PEA_XDMA(5 * PS, ezo + 5u * ecs)
   }
 
-  f2 dot[kXP], ssq[kXP], oss = {0.f, 0.f}, dotz[ZF > 0 ? ZF : 1], ssqz[ZF > 0 ? ZF : 1];
+  f2 dot[kXP], ssq[kXP], oss = {0.f, 0.f}, css = {0.f, 0.f}, dotz[ZF > 0 ? ZF : 1], ssqz[ZF > 0 ? ZF : 1];
 #pragma unroll
   for (int k = 0; k < kXP; ++k) { dot[k] = (f2){0.f, 0.f}; ssq[k] = (f2){0.f, 0.f}; }
 #pragma unroll
@@ -652,6 +702,10 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
     f2 o;
     o.x = *(const float*)(lds + bo + vown);
     o.y = *(const float*)(lds + bo + PS + vown);
+    if (OTHER) {  // the staged centre is the second operand's pixel: its norm goes to the backward; the own pixel is eo
+      css = __builtin_elementwise_fma(o, o, css);
+      o = eo[ps];
+    }
     oss = __builtin_elementwise_fma(o, o, oss);
 #pragma unroll
     for (int k = 0; k < kXP; ++k) {
@@ -672,6 +726,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
 #pragma unroll
     for (int k = 0; k < ZF; ++k) asm volatile("" : "+v"(dotz[k]), "+v"(ssqz[k]));
     asm volatile("" : "+v"(oss));
+    if (OTHER) asm volatile("" : "+v"(css));
     if (ps + 1 < NP) {
       if (ps + 2 < NP) {
         if (ZF > 0) PEA_XWAITZ()
@@ -696,6 +751,11 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
   const float inv_eps = 1.0f / P.eps;
   const float inv_own = rnorm(osum, inv_eps);
   if (inv_out) bs32(iB, osum < P.eps * P.eps ? -inv_own : inv_own, pe, ezo);
+  if (OTHER && inv_other_out) {
+    const float csum = css.x + css.y;
+    const float inv_c = rnorm(csum, inv_eps);
+    bs32(mkbuf(inv_other_out + (size_t)b * S), csum < P.eps * P.eps ? -inv_c : inv_c, pe, ezo);
+  }
   lds_barrier();  // every lane is done with the ring: sA goes over it
 #pragma unroll
   for (int k = 0; k < kXP; ++k) {
@@ -766,7 +826,10 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
 // fwd = true: role A only (one-sided halos, offsets in their own order for the forward kernel).
 // Offsets along z (3D volumes) are allowed: they are not staged but gathered per chunk (npz / nfz > 0 selects the 3D
 // instantiations, which issue their DMA unconditionally: the plane must then hold whole 64-quad blocks).
-inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, size_t* lds_bytes, bool fwd = false) {
+// mode 0: backward, both roles (self loss); 1: forward (role A, one-sided cross); 2: backward, role A only (the detached-EMA
+// cross loss: the neighbours are the second operand's, the cross is the forward's one-sided one; in-plane stencils only)
+inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, size_t* lds_bytes, int mode = 0) {
+  const bool fwd = mode == 1, role_a = mode == 2;
   if (P.border == PEA_BORDER_REPLICATE) return false;
   if ((long long)P.Y * P.X >= (1LL << 28)) return false;                           // plane byte offsets + displacement < 2^31
   if ((long long)(P.D > P.K ? P.D : P.K) * P.S * 4 >= (1LL << 31)) return false;   // soffset counts in the range check (plan_tiles)
@@ -782,7 +845,7 @@ inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, s
     C.oax[i] = ox != 0 ? 1 : (oy != 0 ? 0 : 2);
     C.od[i] = ox != 0 ? ox : (oy != 0 ? oy : oz);
     if (oz != 0) {
-      if (oz <= -P.Z || oz >= P.Z) return false;
+      if (oz <= -P.Z || oz >= P.Z || role_a) return false;
       if (fwd) {
         if (C.nfz >= kXZ / 2) return false;
         C.fzd[C.nfz] = oz; C.fzi[C.nfz] = i; ++C.nfz;
@@ -803,17 +866,17 @@ inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, s
       if (C.npx + 2 > kXP) return false;
       hx = ox < 0 ? (hx > -ox ? hx : -ox) : (hx > ox ? hx : ox);
       C.xd[C.npx] = ox; C.xgi[C.npx] = i; C.xgo[C.npx] = 0; ++C.npx;     // role A: neighbour p + o, g at p
-      C.xd[C.npx] = -ox; C.xgi[C.npx] = i; C.xgo[C.npx] = -ox; ++C.npx;  // role B: neighbour p - o, g at p - o
+      if (!role_a) { C.xd[C.npx] = -ox; C.xgi[C.npx] = i; C.xgo[C.npx] = -ox; ++C.npx; }  // role B: neighbour p - o, g at p - o
     } else {
       if (C.npy + 2 > kXP) return false;
       hy = oy < 0 ? (hy > -oy ? hy : -oy) : (hy > oy ? hy : oy);
       C.yd[C.npy] = oy; C.ygi[C.npy] = i; C.ygo[C.npy] = 0; ++C.npy;
-      C.yd[C.npy] = -oy; C.ygi[C.npy] = i; C.ygo[C.npy] = -oy; ++C.npy;
+      if (!role_a) { C.yd[C.npy] = -oy; C.ygi[C.npy] = i; C.ygo[C.npy] = -oy; ++C.npy; }
     }
   }
   const bool has_z = C.npz > 0 || C.nfz > 0;
   if (has_z && P.Z > 1) C.zrun = P.Z;
-  if (fwd) { hx = left > right ? left : right; C.hy0 = up; C.hy1 = down; }
+  if (fwd || role_a) { hx = left > right ? left : right; C.hy0 = up; C.hy1 = down; }
   else { C.hy0 = C.hy1 = hy; left = right = hx; }
   if (hx > TW) return false;  // a neighbour column is inside the tile or in the strip next to it
   if (left > 0 && right > 0) { C.SW = hx <= 16 ? 32 : 64; C.split = C.SW / 2; }

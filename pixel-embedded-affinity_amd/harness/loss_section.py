@@ -6,6 +6,7 @@ can replace scripts_cvppp/main.py:282-312 / scripts_ac3ac4/main.py:216-238 by on
 happens inside (the reference's K `.item()` calls per loss are gone), so the section can be captured in a HIP graph
 (tests/test_gpu_parity.py::test_loss_section_graph_replay).
 """
+import collections.abc
 import copy
 import ctypes
 import os
@@ -67,6 +68,9 @@ class _side_stream(object):
             self.main.wait_stream(self.side)  # the gradients / loss rows of the small scales are ready for what follows
 
 
+CROSS_PAIR = False  # see _TensorSection.forward
+
+
 class _TensorSection(torch.autograd.Function):
     """cvppp_loss_section's six losses as ONE autograd node on the tensor path: per loss one forward launch (saving g)
     and one backward launch whose dloss is the loss' weight; the EMA cross gradient is added to the self gradient with one
@@ -84,8 +88,9 @@ class _TensorSection(torch.autograd.Function):
             rows = torch.empty((ncall, 1 + kmax), dtype=torch.float32, device=dev)
             grads, pred = [], None
 
-            def forward_one(j, e_c, o_c, want_affs):
-                """forward launch of loss j -> (desc, g, affs)"""
+            def forward_one(j, e_c, o_c, want_affs, planes=0):
+                """forward launch of loss j -> (desc, g, affs, inv); planes: 1 / norm planes wanted for the cross backward
+                (1: self loss, 2: cross loss with the detached second operand), allocated where those kernels cover the shape"""
                 spec = specs[j]
                 kshape = op._affs_shape(e_c, spec.K)
                 t, w, m = tensors[0] if j == ncall - 1 else tensors[j]
@@ -101,38 +106,56 @@ class _TensorSection(torch.autograd.Function):
                 work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=dev)
                 affs = torch.empty(kshape, dtype=torch.float32, device=dev) if want_affs else None
                 g = torch.empty(kshape, dtype=torch.float32, device=dev)
-                _lib.check(L.pea_affinity_fwd(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(t), op._ptr(w), op._ptr(m),
-                                              op._ptr(affs), op._ptr(g), op._ptr(rows[j]), op._ptr(work), wsb, op._stream()), "pea_affinity_fwd")
-                return d, g, affs
+                inv = None
+                if planes and L.pea_cross_supported(ctypes.byref(d), planes):
+                    inv = torch.empty(((planes,) if planes == 2 else ()) + (e_c.shape[0],) + tuple(e_c.shape[2:]), dtype=torch.float32,
+                                      device=dev)
+                _lib.check(L.pea_affinity_fwd_ex(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(t), op._ptr(w), op._ptr(m),
+                                                 op._ptr(affs), op._ptr(g), op._ptr(inv), op._ptr(rows[j]), op._ptr(work), wsb,
+                                                 op._stream()), "pea_affinity_fwd_ex")
+                return d, g, affs, inv
 
-            def backward_one(j, d, e_c, o_c, g):
-                de = torch.empty_like(e_c)
-                _lib.check(L.pea_affinity_bwd(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(g), op._ptr(wdev[j:j + 1]),
-                                              op._ptr(de), None, op._stream()), "pea_affinity_bwd")
+            def backward_one(j, d, e_c, o_c, g, inv=None, de=None):
+                de = torch.empty_like(e_c) if de is None else de
+                rc = L.pea_affinity_bwd_ex(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(g), op._ptr(inv), op._ptr(wdev[j:j + 1]),
+                                           op._ptr(de), None, op._stream())
+                if rc == _lib.E_UNSUPPORTED:
+                    return None
+                _lib.check(rc, "pea_affinity_bwd_ex")
                 return de
 
-            # ---- full resolution: self + cross; their backwards run as one launch with two LDS phases when the library
-            #      has it (pea_affinity_bwd_dual), else as two launches and an add
+            # ---- full resolution: self + cross.  The two backwards run as one tiled launch with two LDS phases
+            #      (pea_affinity_bwd_dual: 246 us at B=8 x 544^2), else as two launches and an add.  CROSS_PAIR: the self backward
+            #      on the cross kernel (97 us) and the cross loss' role-A backward ADDING into the same buffer (150 us: it has to
+            #      read e and de again, 304 B/px) -- the same time for 200 B/px more traffic, so it is off
             jx = ncall - 1
             small = []
             fork = _side_stream(dev)
             with fork:  # the deep-supervision scales, on their own stream beside the full-resolution pair
                 for j in range(1, jx):
                     e_c = op._embedding_arg(embs[j], "embedding")
-                    d, g, _ = forward_one(j, e_c, None, False)
-                    small.append(backward_one(j, d, e_c, None, g))
+                    d, g, _, inv = forward_one(j, e_c, None, False, 1 if CROSS_PAIR else 0)
+                    small.append(backward_one(j, d, e_c, None, g, inv))
             e0 = op._embedding_arg(embs[0], "embedding")
             ema_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e0.dtype)
-            d0, g0, pred = forward_one(0, e0, None, True)
-            dxx, gx, _ = forward_one(jx, e0, ema_c, False)
-            de0 = torch.empty_like(e0)
-            rc = L.pea_affinity_bwd_dual(ctypes.byref(d0), op._ptr(e0), op._ptr(ema_c), op._ptr(g0), op._ptr(gx), op._ptr(wdev[0:1]),
-                                         op._ptr(wdev[jx:jx + 1]), op._ptr(de0), op._stream())
-            if rc == _lib.E_UNSUPPORTED:
-                de0 = backward_one(0, d0, e0, None, g0)
-                de0.add_(backward_one(jx, dxx, e0, ema_c, gx))
-            else:
-                _lib.check(rc, "pea_affinity_bwd_dual")
+            d0, g0, pred, inv0 = forward_one(0, e0, None, True, 1 if CROSS_PAIR else 0)
+            dxx, gx, _, invx = forward_one(jx, e0, ema_c, False, 2 if CROSS_PAIR else 0)
+            de0 = None
+            if inv0 is not None and invx is not None:
+                de0 = backward_one(0, d0, e0, None, g0, inv0)
+                dacc = copy.copy(dxx)
+                dacc.flags = dxx.flags | _lib.FLAG_ACCUMULATE_DE
+                if backward_one(jx, dacc, e0, ema_c, gx, invx, de0) is None:
+                    de0.add_(backward_one(jx, dxx, e0, ema_c, gx))
+            if de0 is None:
+                de0 = torch.empty_like(e0)
+                rc = L.pea_affinity_bwd_dual(ctypes.byref(d0), op._ptr(e0), op._ptr(ema_c), op._ptr(g0), op._ptr(gx), op._ptr(wdev[0:1]),
+                                             op._ptr(wdev[jx:jx + 1]), op._ptr(de0), op._stream())
+                if rc == _lib.E_UNSUPPORTED:
+                    de0 = backward_one(0, d0, e0, None, g0)
+                    de0.add_(backward_one(jx, dxx, e0, ema_c, gx))
+                else:
+                    _lib.check(rc, "pea_affinity_bwd_dual")
             grads.append(de0)
             grads.extend(small)
             fork.join()
@@ -192,11 +215,36 @@ def _build_section_specs(offsets, nb_half, affs0_weight, dis_mode, deep_weight, 
     return specs, weights
 
 
+class _SectionParts(collections.abc.Mapping):
+    """{"loss_embedding", "loss_emd": [4], "loss_embedding_cross"}: the individual weighted losses the reference's loop logs
+    (main.py:298-309), evaluated on first access -- seven 5 us elementwise launches that a step which only calls
+    loss.backward() never needs"""
+    _KEYS = ("loss_embedding", "loss_emd", "loss_embedding_cross")
+
+    def __init__(self, losses, weights, self_emb, cross_emb):
+        self._args, self._d = (losses, weights, self_emb, cross_emb), None
+
+    def _get(self):
+        if self._d is None:
+            losses, weights, self_emb, cross_emb = self._args
+            wl = losses * _weights_on(losses.device, weights)
+            self._d = {"loss_embedding": wl[0] / self_emb if self_emb else wl[0],
+                       "loss_emd": [wl[1 + j] / self_emb if self_emb else wl[1 + j] for j in range(4)],
+                       "loss_embedding_cross": wl[5] / cross_emb if cross_emb else wl[5]}
+        return self._d
+
+    def __getitem__(self, k):
+        return self._get()[k]
+
+    def __iter__(self):
+        return iter(self._KEYS)
+
+    def __len__(self):
+        return len(self._KEYS)
+
+
 def _section_parts(losses, weights, self_emb, cross_emb):
-    wl = losses * _weights_on(losses.device, weights)
-    return {"loss_embedding": wl[0] / self_emb if self_emb else wl[0],
-            "loss_emd": [wl[1 + j] / self_emb if self_emb else wl[1 + j] for j in range(4)],
-            "loss_embedding_cross": wl[5] / cross_emb if cross_emb else wl[5]}
+    return _SectionParts(losses, weights, self_emb, cross_emb)
 
 
 def cvppp_loss_section(embedding, emds, ema_embedding, target, weightmap, affs_mask, downs, criterion, offsets, nb_half,

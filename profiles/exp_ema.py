@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""ema_embedding_loss (detached second operand) at B=8 x 16 x 544^2, K=10: forward / role-A backward on the cross kernels against
+the tiled kernels (PEA_FWD_XDMA=0 / PEA_BWD_XDMA=0), through the C ABI, HIP events"""
+import ctypes, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+pkg = ge.load_package()
+dev = torch.device("cuda:0"); op, L = pkg.affinity_op, pkg._lib.lib()
+P = lambda x: ctypes.c_void_p(x.data_ptr()) if x is not None else None
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+B, D, H, W = 8, 16, 544, 544
+offsets = pkg.multi_offset([1, 3, 5, 9, 27], neighbor=4); K = len(offsets)
+E = torch.randn(B, D, H, W, device=dev); EO = torch.randn(B, D, H, W, device=dev)
+T = (torch.rand(B, K, H, W, device=dev) < 0.6).float(); Wt = torch.rand(B, K, H, W, device=dev) + 0.5
+M = (torch.rand(B, K, H, W, device=dev) < 0.9).to(torch.uint8)
+desc = op.make_desc(op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX), E)
+import copy
+dacc = copy.copy(desc); dacc.flags |= pkg._lib.FLAG_ACCUMULATE_DE
+affs = torch.empty(B, K, H, W, device=dev); G = torch.empty_like(affs); lossv = torch.empty(1 + K, device=dev)
+wsb = L.pea_workspace_bytes(ctypes.byref(desc)); work = torch.empty(max(wsb, 4) // 4, device=dev)
+INV2 = torch.empty(2, B, H, W, device=dev); dE = torch.zeros_like(E); one = torch.ones((), device=dev)
+def t(fn, n=30):
+    for _ in range(5):
+        rc = fn()
+        assert rc == 0, rc
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); b.synchronize(); return a.elapsed_time(b) / n * 1e3
+fwd = lambda inv: L.pea_affinity_fwd_ex(ctypes.byref(desc), P(E), P(EO), P(T), P(Wt), P(M), P(affs), P(G), P(inv), P(lossv), P(work), wsb, st)
+bwd = lambda d, inv: L.pea_affinity_bwd_ex(ctypes.byref(d), P(E), P(EO), P(G), P(inv), P(one), P(dE), None, st)
+for _ in range(300): fwd(INV2)   # clocks settle
+torch.cuda.synchronize()
+print("cross : fwd %.1f  bwd %.1f  bwd accumulate %.1f" % (t(lambda: fwd(INV2)), t(lambda: bwd(desc, INV2)), t(lambda: bwd(dacc, INV2))))
+print("tiled : fwd %.1f  bwd %.1f" % (t(lambda: fwd(None)), t(lambda: bwd(desc, None))))

@@ -87,6 +87,12 @@ def labels_section_tables():
 
 
 px = B * H * W
+if os.environ.get("ONLY"):   # one case only, for a kernel trace (profiles/prof_script.sh): ONLY=tensor | labels | tables
+    fn = {"tensor": lambda: tensor_section(False), "labels": labels_section, "tables": labels_section_tables}[os.environ["ONLY"]]
+    for _ in range(40): fn()
+    torch.cuda.synchronize()
+    print("%s: %.1f us per section" % (os.environ["ONLY"], timed(fn)))
+    sys.exit(0)
 for _ in range(30):  # clocks and allocator pools settle before the first timed case
     tensor_section(False)
 torch.cuda.synchronize()

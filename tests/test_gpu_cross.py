@@ -227,3 +227,65 @@ def test_head_backward_in_the_loss_backward_epilogue(pkg, dev, orc, synth, with_
     L = pkg._lib.lib()
     spec = pkg.affinity_op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX)
     assert L.pea_bwd_head_workspace_bytes(ctypes.byref(pkg.affinity_op.make_desc(spec, cu(ef, dev))), C) > 0
+
+
+@pytest.mark.parametrize("shape,shifts", [((2, 50, 100), [1, 3, 5, 9, 27]), ((1, 43, 96), [1, 3, 5, 9, 27]), ((2, 37, 72), [1, 3, 5, 9, 11])])
+def test_cross_loss_with_detached_second_operand_on_the_cross_kernels(pkg, dev, orc, synth, shape, shifts):
+    """ema_embedding_loss with the detached EMA operand (the shipped configs): forward with e_other staged and the own pixel from
+    e, the two 1 / norm planes, the role-A backward -- overwrite and PEA_FLAG_ACCUMULATE_DE -- against the oracle; and the same call
+    through the Python mirror against the tiled kernels (PEA_FWD_XDMA=0 / PEA_BWD_XDMA=0 is what the old path is)"""
+    B, H, W = shape
+    D = 16
+    offsets = pkg.multi_offset(shifts, 4)
+    K = len(offsets)
+    lam = [2.0, 2.0] + [1.0] * (K - 2)                      # affs0_weight on the first two offsets (reference :90-93)
+    e, t, w, m = _inputs(synth, B, D, [1, H, W], K, 21, zero_px=True)
+    e, t, w, m = e[:, :, 0], t[:, :, 0], w[:, :, 0], m[:, :, 0]
+    eo = synth.synth_embedding((B, D, H * W), 977).reshape(B, D, H, W)
+    eo[0, :, 9, 11] = 0.0                                   # a zero-norm pixel in the second operand
+    op, L = pkg.affinity_op, pkg._lib.lib()
+    E, EO, T, Wt, M = cu(e, dev), cu(eo, dev), cu(t, dev), cu(w, dev), cu(m, dev)
+    spec = op.AffinitySpec(2, offsets, lam, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX)
+    desc = op.make_desc(spec, E)
+    assert L.pea_cross_supported(ctypes.byref(desc), 2) == 1
+    P = lambda x: ctypes.c_void_p(x.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    affs, g = torch.empty(B, K, H, W, device=dev), torch.empty(B, K, H, W, device=dev)
+    inv2 = torch.full((2, B, H, W), 7.0, device=dev)
+    lossv = torch.empty(1 + K, device=dev)
+    wsb = L.pea_workspace_bytes(ctypes.byref(desc))
+    work = torch.empty(max(wsb, 4) // 4, device=dev)
+    assert L.pea_affinity_fwd_ex(ctypes.byref(desc), P(E), P(EO), P(T), P(Wt), P(M), P(affs), P(g), P(inv2), P(lossv), P(work), wsb, st) == 0
+    d = orc.desc_2d(e, offsets, lam)
+    o_affs, o_loss = orc.c_fwd(d, e, eo, t, w, m)
+    assert np.abs(affs.cpu().numpy() - o_affs).max() < AFFS_ATOL
+    assert abs(lossv[0].item() - o_loss[0]) <= LOSS_RTOL * abs(o_loss[0])
+    for k, src in enumerate((e, eo)):
+        nrm = np.sqrt((src.astype(np.float64) ** 2).sum(1))
+        np.testing.assert_allclose(inv2[k].cpu().numpy(), np.where(nrm < 1e-12, -1e12, 1.0 / np.maximum(nrm, 1e-12)), rtol=3e-7)
+    o_de, _ = orc.c_bwd(d, e, eo, t, w, m, dloss=0.75)
+    dl = torch.full((), 0.75, device=dev)
+    de = torch.empty_like(E)
+    assert L.pea_affinity_bwd_ex(ctypes.byref(desc), P(E), P(EO), P(g), P(inv2), P(dl), P(de), None, st) == 0
+    assert relmax(de.cpu().numpy(), o_de) < GRAD_RTOL
+    # accumulate onto what is there
+    base = synth.synth_embedding((B, D, H * W), 31).reshape(B, D, H, W)
+    de2 = cu(base, dev)
+    dacc = __import__("copy").copy(desc)                   # (make_desc memoises: never mutate what it returns)
+    dacc.flags |= pkg._lib.FLAG_ACCUMULATE_DE
+    assert desc.flags == 0
+    assert L.pea_affinity_bwd_ex(ctypes.byref(dacc), P(E), P(EO), P(g), P(inv2), P(dl), P(de2), None, st) == 0
+    assert relmax(de2.cpu().numpy() - base, o_de) < GRAD_RTOL
+    # without the planes the flag is refused (the tiled kernels do not accumulate)
+    assert L.pea_affinity_bwd_ex(ctypes.byref(dacc), P(E), P(EO), P(g), None, P(dl), P(de2), None, st) == pkg._lib.E_UNSUPPORTED
+    # the Python mirror picks the same kernels; against the tiled path
+    crit = pkg.WeightedMSE()
+
+    def run():
+        x = E.clone().requires_grad_(True)
+        loss, a = pkg.ema_embedding_loss(x, EO, T, Wt, M, crit, offsets, affs0_weight=2)
+        (loss * 0.75).backward()
+        return loss.item(), a.cpu().numpy(), x.grad.cpu().numpy()
+
+    l1, a1, g1 = run()
+    assert relmax(g1, o_de) < GRAD_RTOL and np.abs(a1 - o_affs).max() < AFFS_ATOL
