@@ -269,237 +269,30 @@ def cpu_baseline(offsets, e, t, w, m, budget_s=20.0, shifts3d=None, what=None):
     dt = (time.perf_counter() - t0) / iters
     px = et.shape[0] * int(np.prod(et.shape[2:]))
     what = what or "the same B=%d x %d x %dx%d K=%d batch" % (et.shape[0], et.shape[1], et.shape[2], et.shape[3], len(offsets))
-    return {"value": round(px / dt / 1e6, 4), "unit": "Mpx/s", "cores": cores, "kind": "port",
-            "sample": "%d timed fwd+bwd iterations (after 1 warm-up) of %s, oracle/pea_oracle.py torch restatement, %.2f s/iter" % (iters, what, dt)}
-
-
-def train_leg(pkg, dev, world, rank, dist, shared, fence, b=2, steps=8, warm=3):
-    """BASELINE.json's second metric: train imgs/s of a full step at this N -- the ResidualUNet2D_deep backbone (plain PyTorch-ROCm,
-    4.7 M parameters, model/unet2d_residual.py) forward + EMA forward + the labels-in loss section on the HIP kernels + backward +
-    Adam, one rank per GPU under DistributedDataParallel over RCCL (bucketed gradient all-reduce overlapped with the backward;
-    per-rank BatchNorm, as the reference's DataParallel has it).  b images of 544x544 per GPU (cvppp.yaml batch_size 2), weak scaling,
-    synthetic images and instance labels.  Time = max over ranks of `steps` steps between barriers."""
-    import importlib
-    mod = importlib.import_module(ge.PKG_NAME + ".model.unet2d_residual")
-    ts = importlib.import_module(ge.PKG_NAME + ".harness.train_step")
-    synth = importlib.import_module(ge.PKG_NAME + ".utils.synth")
-    torch.manual_seed(555)
-    net = mod.ResidualUNet2D_deep(in_channels=3, out_channels=2, nfeatures=[16, 32, 64, 128, 256], emd=16).to(dev)
-    model = net
-    if dist is not None:
-        from torch.nn.parallel import DistributedDataParallel as DDP
-        # the mask head takes no part in the shipped loss (mask_weight / ct_weight 0): its parameters never get a gradient
-        DDP._set_params_and_buffers_to_ignore_for_model(net, [n for n, _ in net.named_parameters() if n.startswith("binary_seg.")]
-                                                        + [n for n, _ in net.named_buffers() if n.startswith("binary_seg.")])
-        model = DDP(net, device_ids=None if shared else [dev.index], broadcast_buffers=False, gradient_as_bucket_view=True)
-    stepper = ts.CvpppTrainStep(model, ts.make_optimizer(net))
-    g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    x = torch.randn(b, 3, H, W, generator=g, device=dev)
-    x_ema = x + 0.1 * torch.randn(b, 3, H, W, generator=g, device=dev)
-    labels = torch.from_numpy(synth.synth_labels(b, (1, H, W), 555 + rank)[:, 0].copy()).to(dev).to(torch.int32)
-    for _ in range(warm):
-        stepper.step(x, x_ema, labels)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = stepper.step(x, x_ema, labels)
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    return {"train_imgs_per_s": round(world * b * steps / dt, 2), "train_step_ms": round(dt / steps * 1e3, 3),
-            "train_config": {"model": "ResidualUNet2D_deep [16,32,64,128,256] emd 16 (PyTorch-ROCm) + HIP heads + labels-in loss section",
-                             "images_per_gpu": b, "steps": steps, "optimizer": "Adam(amsgrad)",
-                             "parallelism": ("ddp%d over RCCL" % world) if (dist is not None and not shared) else ("ddp%d over gloo (shared device)" % world if dist is not None else "single GPU"),
-                             "loss": float(loss.item())}}
-
-
-def other_config(args, pkg, dev, world, rank, dist, fence):
-    """--config c3 | c4 | c4n26 | c5: same step timing, roofline (from the entry points' in-step HIP-event durations) and a
-    bounded cpu_baseline; inputs are drawn on the GPU (torch.Generator, seed 555 + rank): N(0,1) embeddings,
-    Bernoulli(0.6) targets, U(0.5,1.5) weights, Bernoulli(0.9) masks (2D)."""
-    c = CONFIGS[args.config]
-    B, Dm, dims, K = (args.batch if args.batch != B_PER_GPU else c["B"]), c["D"], list(c["dims"]), c["K"]
-    g = torch.Generator(device=dev).manual_seed(555 + rank)
-    E = torch.randn([B, Dm] + dims, generator=g, device=dev)
-    if c["f16"]:
-        E = E.half()
-    E.requires_grad_(True)
-    T = (torch.rand([B, K] + dims, generator=g, device=dev) < 0.6).float()
-    Wt = torch.rand([B, K] + dims, generator=g, device=dev) + 0.5
-    M = (torch.rand([B, K] + dims, generator=g, device=dev) < 0.9).to(torch.uint8) if c["ndim"] == 2 else None
-    crit = pkg.WeightedMSE()
-    L, op = pkg._lib.lib(), pkg.affinity_op
-    if c["ndim"] == 2:
-        offsets = pkg.multi_offset(c["shifts"], NEIGHBOR)[:K]
-        spec = op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX)
-    else:
-        if c["stencil"] == "norm5":
-            offsets = pkg.utils.affinity_ours.axis_offsets_3d(pkg.utils.affinity_ours.NORM5_SHIFTS)
-        else:
-            offsets = [[dz, dy, dx] for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dz, dy, dx) != (0, 0, 0)]
-        spec = op.AffinitySpec(3, offsets, None, pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
-
-    def step():
-        E.grad = None
-        loss, affs, _ = op.FusedAffinityMSE.apply(E, None, T, Wt, M, spec)
-        loss.backward()
-
-    for _ in range(max(args.warmup, 3)):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    npx = B * int(np.prod(dims))
-    value = world * npx * args.steps / dt / 1e6
-    if rank != 0:
-        return None
-    Ed = E.detach()
-    desc = op.make_desc(spec, Ed)
-    affs, G = torch.empty([B, K] + dims, device=dev), torch.empty([B, K] + dims, device=dev)
-    lossv, INV, dE, one = torch.empty(1 + K, device=dev), torch.empty([B] + dims, device=dev), torch.empty_like(Ed), torch.ones((), device=dev)
-    wsb = L.pea_workspace_bytes(ctypes.byref(desc))
-    work = torch.empty(max(wsb, 4) // 4, device=dev)
-    P = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    fwd = lambda: L.pea_affinity_fwd_ex(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(affs), P(G), P(INV), P(lossv), P(work), wsb, st)
-    bwd = lambda: L.pea_affinity_bwd_ex(ctypes.byref(desc), P(Ed), None, P(G), P(INV), P(one), P(dE), None, st)
-    in_step_times_ms(fwd, bwd, 3)
-    kf, kb = in_step_times_ms(fwd, bwd, max(10, min(args.steps, 50)))
-    ab = algorithmic_bytes_per_px(Dm, K, 2 if c["f16"] else 4, mask=M is not None)
-    dom = "bwd" if kb >= kf else "fwd"
-    achieved = ab[dom] * npx / (max(kf, kb) * 1e-3) / 1e9
-    step_gbs = ab["step"] * npx / ((kf + kb) * 1e-3) / 1e9
-    out = {
-        "metric": "affinity-map Mpixels/sec (fwd+bwd)", "value": round(value, 2), "unit": "Mpx/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 storage / f32 arithmetic" if c["f16"] else "f32",
-        "data": "synthetic",
-        "config": {"workload": "%s: B=%d per GPU x D=%d x %s, K=%d offsets" % (c["what"], B, Dm, "x".join(str(v) for v in dims), K),
-                   "images_per_gpu": B, "embedding_dim": Dm, "dims": dims, "offsets": K, "sharding": "batch across ranks, no data-path collective"},
-        "kernel_ms": {"fwd": round(kf, 5), "bwd": round(kb, 5)},
-        "cross_kernels": {"fwd": int(L.pea_cross_supported(ctypes.byref(desc), 0)), "bwd": int(L.pea_cross_supported(ctypes.byref(desc), 1))},
-        "roofline": {"bound": "hbm", "kernel": "pea_affinity_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_px": ab[dom], "px_per_launch": npx,
-                     "ms": round(max(kf, kb), 5), "fwd_plus_bwd_GBs": round(step_gbs, 1), "fwd_plus_bwd_frac": round(step_gbs / HBM_PEAK_GBS, 4)},
-    }
-    if world == 1 and not args.no_cpu_baseline:
-        # bounded sample: one image (2D) / one 24 x 256 x 256 block of the sub-volume (3D), same op sequence on the host cores
-        orc = ge.load_oracle()
-        cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-        torch.set_num_threads(cores)
-        if c["ndim"] == 2:
-            ec, tc, wc, mc = (x[:1].float().cpu() if x.dtype != torch.uint8 else x[:1].cpu() for x in (Ed, T, Wt, M))
-            fn = lambda x: orc.torch_embedding_loss(x, tc, wc, mc, offsets)[0]
-            sample = "1 image of the batch"
-        else:
-            sl = (slice(0, 1), slice(None), slice(None), slice(0, 256), slice(0, 256))
-            ec, tc, wc = (x[sl].float().cpu().contiguous() for x in (Ed, T[:, :12], Wt[:, :12]))
-            fn = lambda x: orc.torch_embedding_loss_3d(x, tc, wc, pkg.utils.affinity_ours.NORM5_SHIFTS)[0]
-            sample = "a 24x256x256 block of the sub-volume, the norm5 stencil (K=12)"
-        def one():
-            x = ec.clone().requires_grad_(True)
-            fn(x).backward()
-        t0 = time.perf_counter(); one(); first = time.perf_counter() - t0
-        iters = int(max(1, min(5, 20.0 // max(first, 1e-3) - 1)))
+    out = {"value": round(px / dt / 1e6, 4), "unit": "Mpx/s", "cores": cores, "kind": "port",
+           "sample": "%d timed fwd+bwd iterations (after 1 warm-up) of %s, oracle/pea_oracle.py torch restatement, %.2f s/iter" % (iters, what, dt)}
+    if shifts3d is None:
+        # the same arithmetic as one scalar C thread (oracle/pea_oracle.c: fused loops, no temporaries) and as one torch thread,
+        # on the first image: what a single core of the host does (BASELINE.md section 3 asks for the 1-thread lines)
+        e1, t1, w1 = (np.ascontiguousarray(x[:1].numpy()) for x in (et, tt, wt))
+        m1 = None if mt is None else np.ascontiguousarray(mt[:1].numpy())
+        d = orc.desc_2d(e1, offsets)
         t0 = time.perf_counter()
-        for _ in range(iters):
-            one()
-        dtc = (time.perf_counter() - t0) / iters
-        out["cpu_baseline"] = {"value": round(ec[0, 0].numel() / dtc / 1e6, 4), "unit": "Mpx/s", "cores": cores, "kind": "port",
-                               "sample": "%d timed fwd+bwd iterations of %s, oracle/pea_oracle.py torch restatement, %.2f s/iter" % (iters, sample, dtc)}
+        orc.c_fwd(d, e1, None, t1, w1, m1)
+        orc.c_bwd(d, e1, None, t1, w1, m1)
+        dc = time.perf_counter() - t0
+        out["c_1thread"] = {"value": round(e1[0, 0].size / dc / 1e6, 4), "unit": "Mpx/s", "cores": 1, "kind": "port",
+                            "sample": "one fwd + bwd of 1 image, oracle/pea_oracle.c, %.2f s" % dc}
+        torch.set_num_threads(1)
+        et1, tt1, wt1, mt1 = et[:1], tt[:1], wt[:1], (None if mt is None else mt[:1])
+        t0 = time.perf_counter()
+        x = et1.clone().requires_grad_(True)
+        orc.torch_embedding_loss(x, tt1, wt1, mt1, offsets)[0].backward()
+        d1 = time.perf_counter() - t0
+        torch.set_num_threads(cores)
+        out["torch_1thread"] = {"value": round(e1[0, 0].size / d1 / 1e6, 4), "unit": "Mpx/s", "cores": 1, "kind": "port",
+                                "sample": "one fwd + bwd of 1 image, torch restatement with 1 thread, %.2f s" % d1}
     return out
-
-
-def event_time_ms(fn, iters):
-    """average duration of fn() over `iters` back-to-back calls, by HIP events on the launch stream"""
-    s = torch.cuda.current_stream()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(s)
-    for _ in range(iters):
-        fn()
-    b.record(s)
-    b.synchronize()
-    return a.elapsed_time(b) / iters
-
-
-def in_step_times_ms(fwd, bwd, iters):
-    """durations of the forward and of the backward INSIDE the alternating step (fwd, bwd, fwd, bwd, ...): what each kernel
-    takes in the cache state the training loop leaves it in (a kernel repeated back to back finds its own inputs in the
-    Infinity Cache and reads faster than it ever does in a step).  HIP events on the launch stream between the launches."""
-    s = torch.cuda.current_stream()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(iters)]
-    for a, b, c in ev:
-        a.record(s)
-        fwd()
-        b.record(s)
-        bwd()
-        c.record(s)
-    ev[-1][2].synchronize()
-    return (sum(a.elapsed_time(b) for a, b, _ in ev) / iters, sum(b.elapsed_time(c) for _, b, c in ev) / iters)
-
-
-def source_sha16():
-    """hash of the kernel sources: profiles/traffic.json (PMC bytes of a profiled run) is only quoted for the code it measured"""
-    h = hashlib.sha256()
-    csrc = os.path.join(ge.PKG_DIR, "csrc")
-    for f in sorted(os.listdir(csrc)):
-        if f.endswith((".h", ".hip")):
-            h.update(open(os.path.join(csrc, f), "rb").read())
-    return h.hexdigest()[:16]
-
-
-def isolated_time_ms(fn, iters):
-    """average duration of fn() when every call is drained before the next is launched: what a profiler that separates
-    dispatches reports (no overlap of one launch's tail with the next one's ramp-up)"""
-    s = torch.cuda.current_stream()
-    tot = 0.0
-    for _ in range(iters):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(s)
-        fn()
-        b.record(s)
-        b.synchronize()
-        tot += a.elapsed_time(b)
-    return tot / iters
-
-
-def cpu_baseline(offsets, e, t, w, m, budget_s=20.0):
-    """The reference's arithmetic (F.normalize -> K x roll/mul/sum -> WeightedMSE -> autograd backward) as the
-    oracle's torch-CPU restatement, on all host cores, same workload; at most ~budget_s of CPU work."""
-    orc = ge.load_oracle()
-    # the GPU box gives one GPU a 16-core CPU share; more threads than that only oversubscribes
-    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-    torch.set_num_threads(cores)
-    et, tt, wt, mt = (torch.from_numpy(x) for x in (e, t, w, m))
-
-    def one():
-        x = et.clone().requires_grad_(True)
-        loss, _, _ = orc.torch_embedding_loss(x, tt, wt, mt, offsets)
-        loss.backward()
-        return float(loss.detach())
-
-    t0 = time.perf_counter()
-    one()  # warm-up (allocator, thread pool)
-    first = time.perf_counter() - t0
-    iters = int(max(1, min(5, budget_s // max(first, 1e-3) - 1)))
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        one()
-    dt = (time.perf_counter() - t0) / iters
-    px = e.shape[0] * e.shape[2] * e.shape[3]
-    return {"value": round(px / dt / 1e6, 4), "unit": "Mpx/s", "cores": cores, "kind": "port",
-            "sample": "%d timed fwd+bwd iterations (after 1 warm-up) of the same B=%d x %d x %dx%d K=%d batch, "
-                      "oracle/pea_oracle.py torch_embedding_loss, %.2f s/iter" % (iters, e.shape[0], e.shape[1], e.shape[2], e.shape[3], len(offsets), dt)}
 
 
 def main():
@@ -597,7 +390,12 @@ def main():
         dt = float(tmax.item())
     px_per_step = world * B * H * W
     value = px_per_step * args.steps / dt / 1e6
-    train = None if args.no_train else train_leg(pkg, dev, world, rank, dist, shared, fence)
+    train = None
+    if not args.no_train:
+        try:
+            train = train_leg(pkg, dev, world, rank, dist, shared, fence)
+        except Exception as ex:  # the headline line must not be lost to the second metric's leg
+            train = {"train_imgs_per_s": None, "train_error": repr(ex)[:300]}
 
     out = None
     if rank == 0:
