@@ -148,7 +148,9 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
     Ed = E.detach()
     desc = op.make_desc(spec, Ed)
     affs, G = torch.empty([B, K] + dims, device=dev), torch.empty([B, K] + dims, device=dev)
-    lossv, INV, dE, one = torch.empty(1 + K, device=dev), torch.empty([B] + dims, device=dev), torch.empty_like(Ed), torch.ones((), device=dev)
+    lossv, dE, one = torch.empty(1 + K, device=dev), torch.empty_like(Ed), torch.ones((), device=dev)
+    # the 1 / norm plane only where the cross backward takes it (as affinity_op.FusedAffinityMSE does)
+    INV = torch.empty([B] + dims, device=dev) if L.pea_cross_supported(ctypes.byref(desc), 1) else None
     wsb = L.pea_workspace_bytes(ctypes.byref(desc))
     work = torch.empty(max(wsb, 4) // 4, device=dev)
     P = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())

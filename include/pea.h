@@ -111,7 +111,8 @@ const char *pea_strerror(int code);
 /* Host-only check of a descriptor: PEA_OK or PEA_E_DESC / PEA_E_UNSUPPORTED. No GPU needed. */
 int pea_desc_validate(const PeaDesc *desc);
 
-/* Bytes of device scratch pea_affinity_fwd needs for its per-workgroup loss partials. */
+/* Bytes of device scratch pea_affinity_fwd needs for its per-workgroup loss partials and the slice sums of their two-level
+ * reduction; the buffer must be 8-byte aligned. */
 size_t pea_workspace_bytes(const PeaDesc *desc);
 
 /* Inference: affs[B,K,Z,Y,X] only.  e_other may be NULL. */

@@ -188,7 +188,7 @@ class FusedAffinityMSE(torch.autograd.Function):
             # 1 / norm of e, 4 bytes per pixel: what the cross backward (self loss, axis-aligned stencil) stages next to e;
             # with a detached second operand two planes (e, e_other) where the role-A cross kernels cover the shape
             inv = None
-            if want_e and o_c is None:
+            if want_e and o_c is None and L.pea_cross_supported(ctypes.byref(d), 1):
                 inv = torch.empty((e_c.shape[0],) + tuple(e_c.shape[2:]), dtype=torch.float32, device=e_c.device)
             elif want_e and not want_o and L.pea_cross_supported(ctypes.byref(d), 2):
                 inv = torch.empty((2, e_c.shape[0]) + tuple(e_c.shape[2:]), dtype=torch.float32, device=e_c.device)

@@ -230,6 +230,51 @@ __global__ __launch_bounds__(1024) void k_loss_finalize(const KParams P, const f
   }
 }
 
+// Large partial tables (the 3D sub-volumes: 49152 tiles x 12 offsets took one workgroup 100 us): two levels.  Level 1: workgroup
+// (slice, offset) sums a contiguous slice of the offset's row in double, fixed pattern; level 2: k_loss_finalize2 adds the kFinSlices
+// slice sums of every offset in a fixed tree.  Still nothing depends on timing.
+constexpr int kFinSlices = 32;
+__global__ __launch_bounds__(256) void k_loss_slices(const float* __restrict__ partials, int nparts, double* __restrict__ slices) {
+  __shared__ double red[4];
+  const int i = blockIdx.y, sl = blockIdx.x;
+  const int per = (nparts + kFinSlices - 1) / kFinSlices;
+  const int lo = sl * per, hi = min(nparts, lo + per);
+  const float* row = partials + (size_t)i * nparts;
+  double a0 = 0.0, a1 = 0.0;
+  int t = lo + (int)threadIdx.x;
+  for (; t + 256 < hi; t += 512) {
+    a0 += (double)row[t];
+    a1 += (double)row[t + 256];
+  }
+  for (; t < hi; t += 256) a0 += (double)row[t];
+  double acc = a0 + a1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) slices[i * kFinSlices + sl] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(1024) void k_loss_finalize2(const KParams P, const double* __restrict__ slices, float* __restrict__ loss_out) {
+  __shared__ double s_l[PEA_MAX_K];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = wave; i < P.K; i += 16) {
+    double acc = lane < kFinSlices ? slices[i * kFinSlices + lane] : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) {
+      const double Li = acc * (double)P.inv_n[i];
+      s_l[i] = Li;
+      loss_out[1 + i] = (float)Li;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < P.K; ++i) tot += (double)P.lam[i] * s_l[i];
+    loss_out[0] = (float)tot;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward (direct gather form).  x = the tensor being differentiated, g = d loss / d affs [B,K,S].
 //   ROLE_A: x is the first operand:  G(p) += g_i(p)       * nhat(p + o_i),  n = nbA (second operand)

@@ -201,7 +201,9 @@ void allow_lds(size_t bytes) {
 }
 
 // workspace = [K][fwd_partials] f32 loss partials
-size_t ws_bytes(size_t nparts_max, int K) { return nparts_max * K * sizeof(float); }
+// [K][nparts] float partials, then (8-byte aligned) the [K][kFinSlices] double slice sums of the two-level loss reduction
+constexpr size_t kSliceBytes = (size_t)PEA_MAX_K * kFinSlices * sizeof(double);
+size_t ws_bytes(size_t nparts_max, int K) { return ((nparts_max * K * sizeof(float) + 7) & ~(size_t)7) + kSliceBytes; }
 
 size_t fwd_partials(const KParams& P) {
   // worst case over the paths pea_affinity_fwd may take
@@ -778,7 +780,13 @@ __global__ __launch_bounds__(256) void k_scale_multi(const ScaleMulti M, const f
 // One workgroup: a second reduction launch costs more than it saves (measured: 16-workgroup slice sums + a final kernel
 // took 8 + 5 us against 10 us for this one; any launch is >= 4.5 us here and one CU pulls ~20 GB/s)
 void launch_loss_finalize(const KParams& P, float* partials, int nparts, float* loss_out, hipStream_t s) {
-  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P, (const float*)partials, nparts, loss_out);
+  if ((size_t)nparts * P.K <= 65536) {  // one workgroup: 8-10 us at the CVPPP batch (4624 tiles x 10), less than two launches
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, P, (const float*)partials, nparts, loss_out);
+    return;
+  }
+  double* slices = (double*)((char*)partials + ws_bytes(fwd_partials(P), P.K) - kSliceBytes);
+  hipLaunchKernelGGL(k_loss_slices, dim3(kFinSlices, P.K), dim3(256), 0, s, (const float*)partials, nparts, slices);
+  hipLaunchKernelGGL(k_loss_finalize2, dim3(1), dim3(1024), 0, s, P, (const double*)slices, loss_out);
 }
 
 }  // namespace
@@ -829,7 +837,7 @@ int pea_affinity_fwd_ex(const PeaDesc* desc, const void* e, const void* e_other,
   if (!e || !target || !weight || !loss_out) return PEA_E_NULL;
   const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
   if (misaligned(e, es) || misaligned(e_other, es) || misaligned(affs, 4) || misaligned(g_out, 4) ||
-      misaligned(target, 4) || misaligned(weight, 4) || misaligned(loss_out, 4) || misaligned(workspace, 4) ||
+      misaligned(target, 4) || misaligned(weight, 4) || misaligned(loss_out, 4) || misaligned(workspace, 8) ||
       misaligned(inv_norm_out, 4))
     return PEA_E_ALIGN;
   const KParams P = make_params(desc);
@@ -1065,7 +1073,7 @@ int pea_affinity_fwd_bwd_labels(const PeaDesc* desc, const void* e, const void* 
   if (!e || !labels || !wtab || !loss_out || !de) return PEA_E_NULL;
   const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
   if (misaligned(e, es) || misaligned(e_other, es) || misaligned(de, es) || misaligned(affs, 4) || misaligned(labels, 4) ||
-      misaligned(wtab, 4) || misaligned(loss_out, 4) || misaligned(dloss, 4) || misaligned(workspace, 4))
+      misaligned(wtab, 4) || misaligned(loss_out, 4) || misaligned(dloss, 4) || misaligned(workspace, 8))
     return PEA_E_ALIGN;
   if (flags & ~(PEA_TGT_PADDING | PEA_TGT_BOTH_FOREGROUND | PEA_TGT_MASK_INSIDE | PEA_TGT_ACCUMULATE)) return PEA_E_DESC;
   const KParams P = make_params(desc);
@@ -1111,7 +1119,7 @@ int pea_affinity_fwd_bwd_labels_dual(const PeaDesc* desc, const PeaDesc* desc_cr
   const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
   if (misaligned(e, es) || misaligned(ema, es) || misaligned(de, es) || misaligned(affs, 4) || misaligned(labels, 4) ||
       misaligned(wtab, 4) || misaligned(loss_out, 4) || misaligned(loss_cross_out, 4) || misaligned(dloss, 4) ||
-      misaligned(dloss_cross, 4) || misaligned(workspace, 4))
+      misaligned(dloss_cross, 4) || misaligned(workspace, 8))
     return PEA_E_ALIGN;
   if (flags & ~(PEA_TGT_PADDING | PEA_TGT_BOTH_FOREGROUND | PEA_TGT_MASK_INSIDE)) return PEA_E_DESC;
   const KParams P = make_params(desc), P2 = make_params(desc_cross);
