@@ -42,8 +42,16 @@ def convert_consistency_flip(ema_embedding, rules):
 
 
 def label_pyramid(labels):
-    """the four nearest-neighbour downsampled label maps the data provider builds (scripts_cvppp/data/data_provider.py:199-208)"""
-    return [labels[:, ::2 ** j, ::2 ** j].contiguous() for j in range(1, 5)]
+    """the four nearest-neighbour downsampled label maps the data provider builds on the host with
+    cv2.resize(label, (0, 0), fx=fy=1/2 .. 1/16, interpolation=cv2.INTER_NEAREST) (scripts_cvppp/data/data_provider.py:199-208), on the
+    device: cv2's nearest rule is src = floor(dst / fx) = 2^j * dst with an output extent of cvRound(n * fx) (round half to even),
+    i.e. a strided slice trimmed to that extent (for the provider's 544 x 544 crops the slice itself)"""
+    out = []
+    for j in range(1, 5):
+        f = 2 ** j
+        ny, nx = round(labels.shape[-2] / f), round(labels.shape[-1] / f)  # Python's round() is round-half-to-even, like cvRound
+        out.append(labels[..., ::f, ::f][..., :ny, :nx].contiguous())
+    return out
 
 
 def make_optimizer(model, base_lr=1e-4):

@@ -34,3 +34,20 @@ def test_default_backbone_is_the_shipped_4p7m_parameter_net(pkg):
     assert 4.6e6 < n < 4.9e6  # "79.01 GMac, 4.7M" (comment at scripts_cvppp/model/unet2d_residual.py:365)
     e16, e8, e4, e2, e1, mask = net(torch.zeros(1, 3, 64, 96))
     assert [tuple(t.shape[1:]) for t in (e16, e8, e4, e2, e1, mask)] == [(16, 4, 6), (16, 8, 12), (16, 16, 24), (16, 32, 48), (16, 64, 96), (2, 64, 96)]
+
+
+def test_label_pyramid_follows_the_nearest_resize_rule(pkg):
+    """label_pyramid against a restatement of cv2.resize(.., fx=1/2^j, INTER_NEAREST) as the provider calls it
+    (scripts_cvppp/data/data_provider.py:199-208): dst extent cvRound(n * fx), src index floor(dst / fx); cv2 itself is not in this image"""
+    import numpy as np
+    import torch
+    rng = np.random.default_rng(3)
+    for (h, w) in ((544, 544), (530, 500), (72, 88)):
+        lab = rng.integers(0, 9, size=(2, h, w)).astype(np.int32)
+        pyr = pkg.label_pyramid(torch.from_numpy(lab))
+        for j, got in enumerate(pyr, start=1):
+            f = 2 ** j
+            ny, nx = int(np.rint(h / f)), int(np.rint(w / f))          # np.rint: round half to even, as cvRound
+            iy = np.minimum(np.floor(np.arange(ny) * f).astype(int), h - 1)
+            ix = np.minimum(np.floor(np.arange(nx) * f).astype(int), w - 1)
+            assert np.array_equal(got.numpy(), lab[:, iy][:, :, ix]), (h, w, j)
