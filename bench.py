@@ -44,6 +44,8 @@ CONFIGS = {
                   ndim=3, B=1, D=16, dims=(24, 1024, 1024), stencil="n26", K=26, f16=False),
     "c5": dict(what="BASELINE configs[4]: D=64 embedding_loss fwd+bwd, f16 storage / f32 accumulate, offsets[:8]", ndim=2, B=8, D=64, dims=(544, 544),
                shifts=[1, 3, 5, 9, 27], K=8, f16=True),
+    "c5f32": dict(what="the shape of BASELINE configs[4] with f32 storage (comparison line: D=64 on the LDS-DMA cross kernels)", ndim=2, B=8, D=64,
+                  dims=(544, 544), shifts=[1, 3, 5, 9, 27], K=8, f16=False),
 }
 
 
