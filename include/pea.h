@@ -171,6 +171,13 @@ int pea_cross_supported(const PeaDesc *desc, int backward);
  * Returns PEA_E_UNSUPPORTED when two pea_affinity_bwd calls (and an add) must be used instead. */
 int pea_affinity_bwd_dual(const PeaDesc *desc, const void *e, const void *ema, const float *g, const float *g_cross,
                           const float *dloss, const float *dloss_cross, void *de, void *stream);
+/* The same with the 1 / norm planes of the two operands ([B,Z,Y,X] each: the plane pea_affinity_fwd_ex wrote for the self loss,
+ * and the SECOND plane of the pair it wrote for the cross loss): 2D, D = 16, f32, axis-aligned stencils then run as ONE launch of
+ * the LDS-DMA cross kernel with a second phase (the second operand's one-sided cross, role-A pairs added into the same registers);
+ * NULL planes or any other shape: the tiled two-phase kernel of pea_affinity_bwd_dual. */
+int pea_affinity_bwd_dual_ex(const PeaDesc *desc, const void *e, const void *ema, const float *g, const float *g_cross,
+                             const float *inv_norm, const float *inv_norm_other, const float *dloss, const float *dloss_cross,
+                             void *de, void *stream);
 
 /* buf[0..n) *= scale[0] in place (dtype PEA_F32 / PEA_F16; f32 buffers 16-byte aligned).  `scale` is a DEVICE scalar
  * (autograd's grad_output): the kernel reads it and returns without touching buf when it is exactly 1, which is

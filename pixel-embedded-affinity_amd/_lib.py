@@ -24,7 +24,7 @@ FLAG_RELU_AFFS, FLAG_ONE_MINUS, FLAG_HALF_SHIFT, FLAG_CLAMP01, FLAG_ACCUMULATE_D
 TGT_PADDING, TGT_BOTH_FOREGROUND, TGT_MASK_INSIDE, TGT_ACCUMULATE = 1, 2, 4, 8
 
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",
-           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_ex", "pea_affinity_bwd_ex", "pea_inv_norm", "pea_cross_supported", "pea_affinity_bwd_dual", "pea_scale_inplace", "pea_scale_inplace_multi", "pea_fill_border_relu", "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd",
+           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_ex", "pea_affinity_bwd_ex", "pea_inv_norm", "pea_cross_supported", "pea_affinity_bwd_dual", "pea_affinity_bwd_dual_ex", "pea_scale_inplace", "pea_scale_inplace_multi", "pea_fill_border_relu", "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd",
            "pea_bwd_head_workspace_bytes", "pea_affinity_bwd_head",
            "pea_targets_workspace_bytes", "pea_gen_targets", "pea_stitch_add", "pea_stitch_finalize",
            "pea_label_weights", "pea_affinity_fwd_bwd_labels", "pea_affinity_fwd_bwd_labels_dual")
@@ -107,6 +107,8 @@ def lib():
     L.pea_cross_supported.argtypes = [dp, ctypes.c_int]
     L.pea_inv_norm.restype = ctypes.c_int
     L.pea_inv_norm.argtypes = [dp, vp, vp, vp]
+    L.pea_affinity_bwd_dual_ex.restype = ctypes.c_int
+    L.pea_affinity_bwd_dual_ex.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pea_affinity_bwd_dual.restype = ctypes.c_int
     L.pea_affinity_bwd_dual.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pea_scale_inplace.restype = ctypes.c_int

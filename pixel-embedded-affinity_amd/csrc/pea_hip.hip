@@ -250,7 +250,7 @@ bool try_bwd_xdma(const KParams& P, const float* x, const float* inv, const floa
   {                                                                                                    \
     constexpr auto kern = k_bwd_xdma<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, XP_, kAuxNT, ZP_>;            \
     allow_lds<kern>(lds);                                                                              \
-    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, dx, HeadArgs{}, OtherArgs{});     \
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, dx, HeadArgs{}, OtherArgs{}, DualArgs{}); \
   }
   const bool crop = P.border != PEA_BORDER_CIRCULAR;
   if constexpr (D_T == 16) {
@@ -280,7 +280,7 @@ bool try_bwd_xdma_head(const KParams& P, const float* x, const float* inv, const
   const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
   constexpr auto kern = k_bwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, kXP, kAuxNT, 0, kHeadFuseC>;
   allow_lds<kern>(lds);
-  hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, de, H, OtherArgs{});
+  hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, x, inv, g, dl, de, H, OtherArgs{}, DualArgs{});
   *ntiles_out = C.ntiles;
   return true;
 }
@@ -318,7 +318,25 @@ bool try_bwd_xdma_other(const KParams& P, const float* e, const float* e_other, 
   allow_lds<kern>(lds);
   OtherArgs O;
   O.own = e; O.own_inv = inv2; O.accumulate = accumulate ? 1 : 0;
-  hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, e_other, inv2 + (size_t)P.B * P.S, g, dl, de, HeadArgs{}, O);
+  hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, e_other, inv2 + (size_t)P.B * P.S, g, dl, de, HeadArgs{}, O, DualArgs{});
+  return true;
+}
+
+// the pair's backward in one launch on the cross kernels (k_bwd_xdma<.., DUAL>): 2D, D = 16, f32, circular border
+bool try_bwd_xdma_dual(const KParams& P, const float* e, const float* ema, const float* inv, const float* inv_other, const float* g,
+                       const float* g_cross, const float* dl, const float* dl_cross, float* de, hipStream_t s) {
+  if (!inv || !inv_other || env_int("PEA_BWD_XDMA", 1) == 0 || P.D != 16 || P.border != PEA_BORDER_CIRCULAR) return false;
+  if (misaligned(e, 16) || misaligned(ema, 16) || misaligned(inv, 16) || misaligned(inv_other, 16)) return false;
+  XParams C;
+  DualArgs Q;
+  size_t lds, lds2;
+  if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &C, &lds, 0) || C.npz > 0 || C.npx > kXP || C.npy > kXP) return false;
+  if (!plan_xdma(P, kXdmaTH, kXdmaTW, kXdmaPSU, &Q.C2, &lds2, 2)) return false;
+  Q.ema = ema; Q.inv_other = inv_other; Q.g_cross = g_cross; Q.dloss_cross = dl_cross;
+  const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  constexpr auto kern = k_bwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, kXP, kAuxNT, 0, 0, false, true>;
+  allow_lds<kern>(lds);
+  hipLaunchKernelGGL(kern, grid, blk, lds, s, P, C, e, inv, g, dl, de, HeadArgs{}, OtherArgs{}, Q);
   return true;
 }
 
@@ -1165,16 +1183,25 @@ int pea_scale_inplace_multi(void* const* bufs, const size_t* counts, int nbuf, i
 
 int pea_affinity_bwd_dual(const PeaDesc* desc, const void* e, const void* ema, const float* g, const float* g_cross,
                           const float* dloss, const float* dloss_cross, void* de, void* stream) {
+  return pea_affinity_bwd_dual_ex(desc, e, ema, g, g_cross, nullptr, nullptr, dloss, dloss_cross, de, stream);
+}
+
+int pea_affinity_bwd_dual_ex(const PeaDesc* desc, const void* e, const void* ema, const float* g, const float* g_cross,
+                             const float* inv_norm, const float* inv_norm_other, const float* dloss, const float* dloss_cross,
+                             void* de, void* stream) {
   const int rc = validate(desc);
   if (rc) return rc;
   if (!e || !ema || !g || !g_cross || !de) return PEA_E_NULL;
   const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
   if (misaligned(e, es) || misaligned(ema, es) || misaligned(de, es) || misaligned(g, 4) || misaligned(g_cross, 4) ||
-      misaligned(dloss, 4) || misaligned(dloss_cross, 4))
+      misaligned(dloss, 4) || misaligned(dloss_cross, 4) || misaligned(inv_norm, 4) || misaligned(inv_norm_other, 4))
     return PEA_E_ALIGN;
   const KParams P = make_params(desc);
   if ((P.D != 16 && P.D != 32) || env_int("PEA_FORCE_DIRECT", 0) != 0 || env_int("PEA_BWD_DUAL", 1) == 0) return PEA_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  if (desc->dtype == PEA_F32 && try_bwd_xdma_dual(P, (const float*)e, (const float*)ema, inv_norm, inv_norm_other, g, g_cross, dloss,
+                                                  dloss_cross, (float*)de, s))
+    return hip_rc();
   bool done;
 #define PEA_BD(T_, D_) try_bwd_dual<T_, D_>(P, (const T_*)e, (const T_*)ema, g, g_cross, dloss, dloss_cross, (T_*)de, s)
   if (P.D == 16) done = desc->dtype == PEA_F16 ? PEA_BD(__half, 16) : PEA_BD(float, 16);

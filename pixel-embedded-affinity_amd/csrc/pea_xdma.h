@@ -144,6 +144,128 @@ struct HeadArgs {
   float* dx;            // [B, HC, S]
   float* partials;      // [ntiles][D * HC + D]: per-tile shares of dW and db (pea_affinity_bwd_head reduces them)
 };
+// DUAL: the backward of the training loop's full-resolution PAIR in one launch (scripts_cvppp/main.py:284-293: embedding_loss and
+//   ema_embedding_loss of the same `embedding`, the second with the detached EMA operand): after the self loss' chunk loop the
+//   workgroup stages the SECOND operand's one-sided cross (plan_xdma mode 2) and adds the cross loss' role-A pairs into the same
+//   registers; one projection, one store of de.  280 B/px instead of the 408 of the two launches (no second read of e, no
+//   read-modify-write of de).  The two losses' grad_outputs scale the sums (G *= dl_self; the second phase's coefficients *= dl_cross).
+struct DualArgs {
+  XParams C2;               // plan_xdma(.., mode 2) of the cross loss' descriptor
+  const float* ema;         // [B, D, S] second operand
+  const float* inv_other;   // [B, S] its signed 1 / norm plane
+  const float* g_cross;     // [B, K, S] d loss_cross / d affs
+  const float* dloss_cross;
+};
+// second phase of k_bwd_xdma<.., DUAL>: role-A pairs of the second operand into G (D = 16: NP = 8 chunk pairs), 2D, no z
+template <int TH, int TW, int PSU, bool CROP, int XP>
+__device__ __forceinline__ void bwd_phase_role_a(const KParams& P, const XParams& C, char* lds, const rsrc_t xB, const rsrc_t iB,
+                                                 const rsrc_t gB, const float dlx, const int y0, const int x0, const unsigned ezo,
+                                                 const unsigned ecs, f2 (&G)[8]) {
+  constexpr int NT = TH * TW, PS = PSU * 256, NP = 8;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
+  const int py = y0 + ly, px = x0 + lx;
+  const bool live = py < P.Y && px < P.X;
+  const unsigned po4 = (unsigned)(py * P.X + px) * 4u;
+  lds_barrier();  // every wave is done with the first phase's last chunk: the ring is free
+  unsigned vo[2];
+  bool act[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int q = (s * (NT / 64) + wave) * 64 + lane;
+    int gy, gx;
+    if (q < C.QV) {
+      gy = y0 - C.hy0 + (q >> 3);
+      gx = x0 + 4 * (q & 7);
+    } else {
+      const int k = q - C.QV;
+      const int sh = C.SW == 64 ? 4 : 3;
+      const int cc = 4 * (k & ((1 << sh) - 1));
+      gy = y0 + (k >> sh);
+      gx = cc < C.split ? x0 + TW + cc : x0 - C.SW + cc;
+    }
+    act[s] = q < C.QA;
+    bool oky, okx;
+    gy = wrap1<CROP>(gy, P.Y, oky);
+    gx = wrap1<CROP>(gx, P.X, okx);
+    vo[s] = (act[s] && oky && okx) ? (unsigned)(gy * P.X + gx) * 4u : kOOB;
+  }
+  const int wbase = wave * 1024, w1 = wbase + (NT / 64) * 1024;
+  const int npc = 2 * ((__builtin_amdgcn_ballot_w64(act[0]) != 0) + (__builtin_amdgcn_ballot_w64(act[1]) != 0));
+#define PEA_X2WAIT1()                                                                            \
+  {                                                                                              \
+    if (npc == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
+    else if (npc == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                \
+  }
+#define PEA_X2DMA(rsrc, plane_byte, so)                                                                                          \
+  {                                                                                                                              \
+    if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, 0);    \
+    if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + w1), 16, vo[1], so, 0, 0);       \
+  }
+  PEA_X2DMA(iB, 4 * PS, ezo)
+  PEA_X2DMA(xB, 0, ezo)
+  PEA_X2DMA(xB, PS, ezo + ecs)
+  const unsigned pg = live ? po4 : kOOB;  // role A: g at the own pixel
+  float cx[XP], cy[XP];
+  int ax[XP], ay[XP];
+  const int vown = ((C.hy0 + ly) * TW + lx) * 4;
+  const int hrow = (C.QV * 4 + ly * C.SW) * 4;
+#pragma unroll
+  for (int k = 0; k < XP; ++k) {
+    cx[k] = bl32(gB, k < C.npx ? pg : kOOB, ezo + (unsigned)C.xgi[k] * ecs);
+    const int d = C.xd[k], c = lx + d;
+    ax[k] = (unsigned)c < (unsigned)TW ? vown + d * 4 : hrow + (c & C.xm[k]) * 4;
+    cy[k] = bl32(gB, k < C.npy ? pg : kOOB, ezo + (unsigned)C.ygi[k] * ecs);
+    ay[k] = vown + C.yd[k] * TW * 4;
+  }
+  PEA_X2DMA(xB, 2 * PS, ezo + 2u * ecs)
+  PEA_X2DMA(xB, 3 * PS, ezo + 3u * ecs)
+  PEA_X2WAIT1()
+#pragma unroll
+  for (int k = 0; k < XP; ++k) {
+    cx[k] *= fabsf(*(const float*)(lds + 4 * PS + ax[k])) * dlx;
+    cy[k] *= fabsf(*(const float*)(lds + 4 * PS + ay[k])) * dlx;
+    asm volatile("" : "+v"(cx[k]), "+v"(cy[k]));
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the inv plane is dead: buffer 2 may be filled
+  PEA_X2DMA(xB, 4 * PS, ezo + 4u * ecs)
+  PEA_X2DMA(xB, 5 * PS, ezo + 5u * ecs)
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int bo = (ps % 3) * 2 * PS;
+    f2 acc = G[ps];
+#pragma unroll
+    for (int k = 0; k < XP; ++k) {
+      f2 v;
+      v.x = *(const float*)(lds + bo + ax[k]);
+      v.y = *(const float*)(lds + bo + PS + ax[k]);
+      acc = __builtin_elementwise_fma((f2){cx[k], cx[k]}, v, acc);
+      if (k % 5 == 4) asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int k = 0; k < XP; ++k) {
+      f2 v;
+      v.x = *(const float*)(lds + bo + ay[k]);
+      v.y = *(const float*)(lds + bo + PS + ay[k]);
+      acc = __builtin_elementwise_fma((f2){cy[k], cy[k]}, v, acc);
+      if (k % 5 == 4) asm volatile("" ::: "memory");
+    }
+    asm volatile("" : "+v"(acc));
+    G[ps] = acc;
+    if (ps + 1 < NP) {
+      if (ps + 2 < NP) PEA_X2WAIT1()
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (ps + 3 < NP) {
+        PEA_X2DMA(xB, bo, ezo + (unsigned)(2 * ps + 6) * ecs)
+        PEA_X2DMA(xB, bo + PS, ezo + (unsigned)(2 * ps + 7) * ecs)
+      }
+    }
+  }
+#undef PEA_X2DMA
+#undef PEA_X2WAIT1
+}
+
 // OTHER: the cross loss with a detached second operand (ema_embedding_loss, scripts_cvppp/loss/loss_embedding_mse.py:79-95 with
 //   convert_consistency_flip's detach): role A only.  xt / invp are the SECOND operand and its 1 / norm plane (the neighbours);
 //   the own pixel and its 1 / norm come from O.own / O.own_inv (global loads, once per tile); O.accumulate: dx += instead of =
@@ -153,12 +275,13 @@ struct OtherArgs {
   const float* own_inv;  // [B, S] its signed 1 / norm plane
   int accumulate;
 };
-template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, int AUXS = kAuxNT, int ZP = 0, int HC = 0, bool OTHER = false>
+template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, int AUXS = kAuxNT, int ZP = 0, int HC = 0, bool OTHER = false, bool DUAL = false>
 __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const XParams C, const float* __restrict__ xt,
                                                          const float* __restrict__ invp, const float* __restrict__ gin,
                                                          const float* __restrict__ dloss, float* __restrict__ dx,
-                                                         const HeadArgs H, const OtherArgs O) {
+                                                         const HeadArgs H, const OtherArgs O, const DualArgs Q) {
   static_assert(!OTHER || (D_T <= 16 && ZP == 0 && HC == 0), "role-A instantiation: D <= 16, in-plane, no head epilogue");
+  static_assert(!DUAL || (D_T == 16 && ZP == 0 && HC == 0 && !OTHER), "pair instantiation: D = 16, in-plane");
   constexpr int NT = TH * TW, PS = PSU * 256, NP = D_T / 2;
   static_assert(TW == 32 && D_T % 2 == 0, "lane mapping / channel pairs");
   extern __shared__ f4 lds4[];
@@ -389,12 +512,19 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
 #undef PEA_XWAITZ
 #undef PEA_XZLOAD
 
+  if constexpr (DUAL) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) G[ps] = G[ps] * dl;
+    bwd_phase_role_a<TH, TW, PSU, CROP, XP>(P, Q.C2, lds, mkbuf(Q.ema + (size_t)b * D_T * S), mkbuf(Q.inv_other + (size_t)b * S),
+                                            mkbuf(Q.g_cross + (size_t)b * P.K * S), Q.dloss_cross ? Q.dloss_cross[0] : 1.f, y0, x0, ezo,
+                                            ecs, G);
+  }
   if (KEEP) {
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) proj = fmaf(eh[ps].x, G[ps].x, fmaf(eh[ps].y, G[ps].y, proj));
   }
   if (invo < 0.f) proj = 0.f;  // clamp branch of F.normalize
-  const float sc = dl * inv_own;
+  const float sc = DUAL ? inv_own : dl * inv_own;
   const float pn = proj * inv_own;  // !KEEP: ehat * proj = e * (inv_own * proj)
   if constexpr (HC == 0) {
     f2 old[OTHER ? NP : 1];

@@ -68,9 +68,6 @@ class _side_stream(object):
             self.main.wait_stream(self.side)  # the gradients / loss rows of the small scales are ready for what follows
 
 
-CROSS_PAIR = False  # see _TensorSection.forward
-
-
 class _TensorSection(torch.autograd.Function):
     """cvppp_loss_section's six losses as ONE autograd node on the tensor path: per loss one forward launch (saving g)
     and one backward launch whose dloss is the loss' weight; the EMA cross gradient is added to the self gradient with one
@@ -124,38 +121,30 @@ class _TensorSection(torch.autograd.Function):
                 _lib.check(rc, "pea_affinity_bwd_ex")
                 return de
 
-            # ---- full resolution: self + cross.  The two backwards run as one tiled launch with two LDS phases
-            #      (pea_affinity_bwd_dual: 246 us at B=8 x 544^2), else as two launches and an add.  CROSS_PAIR: the self backward
-            #      on the cross kernel (97 us) and the cross loss' role-A backward ADDING into the same buffer (150 us: it has to
-            #      read e and de again, 304 B/px) -- the same time for 200 B/px more traffic, so it is off
+            # ---- full resolution: self + cross; their backwards are ONE launch: the cross kernel with a second phase where the
+            #      shape allows (pea_affinity_bwd_dual_ex with the 1 / norm planes the two forwards wrote: 2D, D = 16, axis-aligned
+            #      stencil), else the tiled two-phase kernel, else two launches and an add
             jx = ncall - 1
             small = []
             fork = _side_stream(dev)
             with fork:  # the deep-supervision scales, on their own stream beside the full-resolution pair
                 for j in range(1, jx):
                     e_c = op._embedding_arg(embs[j], "embedding")
-                    d, g, _, inv = forward_one(j, e_c, None, False, 1 if CROSS_PAIR else 0)
+                    d, g, _, inv = forward_one(j, e_c, None, False, 0)
                     small.append(backward_one(j, d, e_c, None, g, inv))
             e0 = op._embedding_arg(embs[0], "embedding")
             ema_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e0.dtype)
-            d0, g0, pred, inv0 = forward_one(0, e0, None, True, 1 if CROSS_PAIR else 0)
-            dxx, gx, _, invx = forward_one(jx, e0, ema_c, False, 2 if CROSS_PAIR else 0)
-            de0 = None
-            if inv0 is not None and invx is not None:
+            d0, g0, pred, inv0 = forward_one(0, e0, None, True, 1)
+            dxx, gx, _, invx = forward_one(jx, e0, ema_c, False, 2 if inv0 is not None else 0)
+            de0 = torch.empty_like(e0)
+            rc = L.pea_affinity_bwd_dual_ex(ctypes.byref(d0), op._ptr(e0), op._ptr(ema_c), op._ptr(g0), op._ptr(gx), op._ptr(inv0),
+                                            op._ptr(None if invx is None else invx[1]), op._ptr(wdev[0:1]), op._ptr(wdev[jx:jx + 1]),
+                                            op._ptr(de0), op._stream())
+            if rc == _lib.E_UNSUPPORTED:
                 de0 = backward_one(0, d0, e0, None, g0, inv0)
-                dacc = copy.copy(dxx)
-                dacc.flags = dxx.flags | _lib.FLAG_ACCUMULATE_DE
-                if backward_one(jx, dacc, e0, ema_c, gx, invx, de0) is None:
-                    de0.add_(backward_one(jx, dxx, e0, ema_c, gx))
-            if de0 is None:
-                de0 = torch.empty_like(e0)
-                rc = L.pea_affinity_bwd_dual(ctypes.byref(d0), op._ptr(e0), op._ptr(ema_c), op._ptr(g0), op._ptr(gx), op._ptr(wdev[0:1]),
-                                             op._ptr(wdev[jx:jx + 1]), op._ptr(de0), op._stream())
-                if rc == _lib.E_UNSUPPORTED:
-                    de0 = backward_one(0, d0, e0, None, g0)
-                    de0.add_(backward_one(jx, dxx, e0, ema_c, gx))
-                else:
-                    _lib.check(rc, "pea_affinity_bwd_dual")
+                de0.add_(backward_one(jx, dxx, e0, ema_c, gx, invx))
+            else:
+                _lib.check(rc, "pea_affinity_bwd_dual_ex")
             grads.append(de0)
             grads.extend(small)
             fork.join()

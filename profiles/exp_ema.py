@@ -33,3 +33,10 @@ for _ in range(300): fwd(INV2)   # clocks settle
 torch.cuda.synchronize()
 print("cross : fwd %.1f  bwd %.1f  bwd accumulate %.1f" % (t(lambda: fwd(INV2)), t(lambda: bwd(desc, INV2)), t(lambda: bwd(dacc, INV2))))
 print("tiled : fwd %.1f  bwd %.1f" % (t(lambda: fwd(None)), t(lambda: bwd(desc, None))))
+# the pair's backward in one launch: cross kernel with the second phase against the tiled two-phase kernel
+G0 = torch.empty_like(G); INV0 = torch.empty(B, H, W, device=dev)
+assert L.pea_affinity_fwd_ex(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), P(G0), P(INV0), P(lossv), P(work), wsb, st) == 0
+assert fwd(INV2) == 0
+dual = lambda a, b: L.pea_affinity_bwd_dual_ex(ctypes.byref(desc), P(E), P(EO), P(G0), P(G), P(a), P(b), P(one), P(one), P(dE), st)
+selfb = lambda: L.pea_affinity_bwd_ex(ctypes.byref(desc), P(E), None, P(G0), P(INV0), P(one), P(dE), None, st)
+print("pair  : cross dual %.1f  tiled dual %.1f  (self backward alone %.1f)" % (t(lambda: dual(INV0, INV2[1])), t(lambda: dual(None, None)), t(selfb)))

@@ -289,3 +289,43 @@ def test_cross_loss_with_detached_second_operand_on_the_cross_kernels(pkg, dev, 
 
     l1, a1, g1 = run()
     assert relmax(g1, o_de) < GRAD_RTOL and np.abs(a1 - o_affs).max() < AFFS_ATOL
+
+
+@pytest.mark.parametrize("shape,shifts", [((2, 50, 100), [1, 3, 5, 9, 27]), ((1, 43, 96), [1, 3, 5, 9, 27]), ((2, 37, 72), [1, 3, 5, 9, 11])])
+def test_pair_backward_in_one_cross_launch(pkg, dev, orc, synth, shape, shifts):
+    """pea_affinity_bwd_dual_ex: the self loss' backward and the detached-EMA cross loss' role-A backward of the same embedding as
+    one launch of the cross kernel (second phase) -- against dl_self * oracle(self) + dl_cross * oracle(cross), and against the tiled
+    two-phase kernel the same entry point runs without the 1 / norm planes"""
+    B, H, W = shape
+    D = 16
+    offsets = pkg.multi_offset(shifts, 4)
+    K = len(offsets)
+    lamx = [3.0, 3.0] + [1.0] * (K - 2)
+    e, t, w, m = _inputs(synth, B, D, [1, H, W], K, 23, zero_px=True)
+    e, t, w, m = e[:, :, 0], t[:, :, 0], w[:, :, 0], m[:, :, 0]
+    eo = synth.synth_embedding((B, D, H * W), 978).reshape(B, D, H, W)
+    eo[0, :, 4, 6] = 0.0
+    op, L = pkg.affinity_op, pkg._lib.lib()
+    E, EO, T, Wt, M = cu(e, dev), cu(eo, dev), cu(t, dev), cu(w, dev), cu(m, dev)
+    d0 = op.make_desc(op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX), E)
+    dx = op.make_desc(op.AffinitySpec(2, offsets, lamx, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX), E)
+    P = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    affs, g0, gx = (torch.empty(B, K, H, W, device=dev) for _ in range(3))
+    inv0, inv2 = torch.empty(B, H, W, device=dev), torch.empty(2, B, H, W, device=dev)
+    lossv = torch.empty(1 + K, device=dev)
+    wsb = L.pea_workspace_bytes(ctypes.byref(d0))
+    work = torch.empty(max(wsb, 4) // 4, device=dev)
+    assert L.pea_affinity_fwd_ex(ctypes.byref(d0), P(E), None, P(T), P(Wt), P(M), P(affs), P(g0), P(inv0), P(lossv), P(work), wsb, st) == 0
+    assert L.pea_affinity_fwd_ex(ctypes.byref(dx), P(E), P(EO), P(T), P(Wt), P(M), None, P(gx), P(inv2), P(lossv), P(work), wsb, st) == 0
+    dl0, dlx = torch.full((), 0.6, device=dev), torch.full((), 1.7, device=dev)
+    de_c, de_t = torch.empty_like(E), torch.empty_like(E)
+    assert L.pea_affinity_bwd_dual_ex(ctypes.byref(d0), P(E), P(EO), P(g0), P(gx), P(inv0), P(inv2[1]), P(dl0), P(dlx), P(de_c), st) == 0
+    rc_t = L.pea_affinity_bwd_dual_ex(ctypes.byref(d0), P(E), P(EO), P(g0), P(gx), None, None, P(dl0), P(dlx), P(de_t), st)
+    assert rc_t in (0, pkg._lib.E_UNSUPPORTED)              # (the tiled pair kernel has no plan for the smallest images)
+    o_self, _ = orc.c_bwd(orc.desc_2d(e, offsets), e, None, t, w, m, dloss=0.6)
+    o_cross, _ = orc.c_bwd(orc.desc_2d(e, offsets, lamx), e, eo, t, w, m, dloss=1.7)
+    ref = o_self + o_cross
+    assert relmax(de_c.cpu().numpy(), ref) < GRAD_RTOL
+    if rc_t == 0:
+        assert relmax(de_t.cpu().numpy(), ref) < GRAD_RTOL and relmax(de_c.cpu().numpy(), de_t.cpu().numpy()) < 2e-5
