@@ -1311,8 +1311,6 @@ int pea_affinity_bwd_head(const PeaDesc* desc, const void* e, const float* g, co
   hipStream_t s = (hipStream_t)stream;
   HeadArgs H;
   H.x = x; H.W = W; H.de_add = de_add; H.dx = dx; H.partials = (float*)workspace;
-  if (env_int("PEA_DBG_NODW", 0)) H.partials = nullptr;
-  if (env_int("PEA_DBG_NODX", 0)) H.dx = nullptr;
   int ntiles = 0;
   if (!try_bwd_xdma_head(P, (const float*)e, inv_norm, g, dloss, (float*)de, H, s, &ntiles)) return PEA_E_UNSUPPORTED;
   const int rc = hip_rc();

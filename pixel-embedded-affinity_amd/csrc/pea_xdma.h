@@ -581,7 +581,6 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a), hdB, pe, ezo + (unsigned)c * ecs, AUXS);
       }
     }
-    if (!H.partials) return;  // dx only (uniform)
     // ---- dW / db share of this tile.  MFMA operand coordinates of a lane: row / column mi, k index mk; a k-step is 4 pixels
     lds_barrier();  // every wave is done with the ring
     float* tA = (float*)lds + wave * (2 * 16 * kRow);

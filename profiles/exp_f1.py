@@ -28,7 +28,5 @@ bwd = lambda: L.pea_affinity_bwd_ex(ctypes.byref(desc), P(E), None, P(G), P(INV)
 hb = lambda: L.pea_head_bwd(B, HC, D, H * W, P(hx), P(hw), P(dE), P(hdx), P(hdw), P(hdb), P(hwork), hws, st)
 fused = lambda de=None: L.pea_affinity_bwd_head(ctypes.byref(desc), P(E), P(G), P(INV), P(one), None, P(hx), P(hw), HC, P(hdx), P(hdw), P(hdb), P(de), P(fwork), fb, st)
 print("bwd %.1f  head_bwd %.1f" % (t(bwd), t(hb)))
-for env in ({}, {"PEA_DBG_NODW": "1"}, {"PEA_DBG_NODX": "1"}, {"PEA_DBG_NODW": "1", "PEA_DBG_NODX": "1"}):
-    for k in ("PEA_DBG_NODW", "PEA_DBG_NODX"): os.environ.pop(k, None)
-    os.environ.update(env)
-    print(env, "fused %.1f   fused+de %.1f" % (t(fused), t(lambda: fused(dE))))
+# (profiles/r2c_f1_fused_backward.txt also has the run with the epilogue's dx / dW halves switched off by a debug build)
+print("fused %.1f   fused+de %.1f" % (t(fused), t(lambda: fused(dE))))
