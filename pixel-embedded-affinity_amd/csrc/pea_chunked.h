@@ -86,6 +86,8 @@ __global__ __launch_bounds__(TH* TW, (DC > 16 ? 2 : 4)) void k_fwd_tiled_chunked
   U.tB = mkbuf(target + (size_t)b * P.tbs);
   U.wB = mkbuf(weight + (size_t)b * P.wbs);
   U.mB = mkbuf(mask ? mask + (size_t)b * P.mbs : nullptr);
+  U.ks = 0xffffffffu;  // no second resource here (plan_tiles keeps >= 2 GiB blocks away from this kernel)
+  U.aB1 = U.aB; U.gB1 = U.gB; U.tB1 = U.tB; U.wB1 = U.wB;
   U.kcs = (unsigned)P.S * 4u;
   U.kzo = (unsigned)z * YX * 4u;
   U.S32 = (unsigned)P.S;

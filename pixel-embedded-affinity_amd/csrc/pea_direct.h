@@ -29,6 +29,9 @@ struct KParams {
   float inv_n[PEA_MAX_K];   // 1 / N_i
   float gscale[PEA_MAX_K];  // 2 * lambda_i / N_i
   long long tbs, wbs, mbs;  // batch strides (elements) of target / weight / mask
+  int ksplit;               // offset channels >= ksplit are addressed through a second buffer resource based ksplit planes further:
+                            // K (no split) unless the [K, Z, Y, X] block of a batch item reaches 2 GiB (the raw-buffer range check
+                            // counts the scalar plane offset: pea_hip.hip plan_tiles); only k_fwd_tiled / k_bwd_tiled honour it
 };
 
 template <typename T>

@@ -66,6 +66,7 @@ KParams make_params(const PeaDesc* d) {
   P.B = d->B; P.D = d->D; P.Z = d->dims[0]; P.Y = d->dims[1]; P.X = d->dims[2]; P.K = d->K;
   P.S = P.Z * P.Y * P.X;
   P.border = d->border; P.flags = d->flags; P.eps = d->eps;
+  P.ksplit = ((long long)d->K * P.S * 4 >= (1LL << 31)) ? (d->K + 1) / 2 : d->K;
   P.chunks = (P.S + kBlock - 1) / kBlock;
   P.tiles = P.B * P.chunks;
   P.tiles_per_xcd = (P.tiles + kXcd - 1) / kXcd;
@@ -132,14 +133,20 @@ constexpr int kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup ma
 
 // Choose the "near" offsets (served from LDS): the largest in-plane radius whose halo'd region still fits the
 // LDS planes of this tile shape.  both_sides: the backward needs p - o as well as p + o.
-bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, TParams* Q) {
+bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, TParams* Q, bool ksplit_ok = false) {
   if (P.border == PEA_BORDER_REPLICATE) return false;  // direct kernels only (row a-15: an unused variant of the reference)
   if ((long long)P.Y * P.X >= (1LL << 29)) return false;                     // plane byte offsets stay below 2^31 (kOOB)
   // A raw buffer access is in range iff voffset < num_records - soffset (gfx9 range check: the scalar offset COUNTS), and the
   // kernels select the channel / offset plane with soffset under num_records = 2^31: the [D or K, Z, Y, X] block of one batch
   // item must stay below 2 GiB, or planes past it read zeros and drop their stores without any error (found by the
   // full-size K = 26 test: 26 x 24 x 1024^2 x 4 B = 2.6 GB).  Larger blocks take the direct kernels (64-bit pointers).
-  if ((long long)std::max(P.D, P.K) * P.S * 4 >= (1LL << 31)) return false;
+  // k_fwd_tiled / k_bwd_tiled (ksplit_ok) reach the upper offset channels through a second resource based KParams::ksplit planes
+  // further, so for them only each HALF of the K block has to stay below 2 GiB (the 26-neighbourhood of configs[3]: 2 x 1.3 GB).
+  if ((long long)P.D * P.S * 4 >= (1LL << 31)) return false;
+  if ((long long)P.K * P.S * 4 >= (1LL << 31)) {
+    if (!ksplit_ok || P.ksplit >= P.K) return false;
+    if ((long long)P.ksplit * P.S * 4 >= (1LL << 31) || (long long)(P.K - P.ksplit) * P.S * 4 >= (1LL << 31)) return false;
+  }
   const int NT = c.TH * c.TW;
   int radii[PEA_MAX_K], nr = 0;
   for (int i = 0; i < P.K; ++i)
@@ -445,7 +452,7 @@ template <typename T, int D_T, bool TRAIN>
 bool try_fwd_tiled(const KParams& P, const T* e, const T* eo, const float* t, const float* w, const uint8_t* m, float* affs,
                    float* gout, float* partials, float* inv_out, hipStream_t s, int* nparts) {
   TParams Q;
-  if (!plan_tiles(P, fwd_cfg<D_T>(0), false, &Q)) return false;
+  if (!plan_tiles(P, fwd_cfg<D_T>(0), false, &Q, true)) return false;
   if (eo == e) launch_fwd_cfg<T, D_T, TRAIN, true, 0>(P, Q, e, eo, t, w, m, affs, gout, partials, inv_out, s);
   else launch_fwd_cfg<T, D_T, TRAIN, false, 0>(P, Q, e, eo, t, w, m, affs, gout, partials, inv_out, s);
   *nparts = Q.ntiles;
@@ -560,7 +567,7 @@ template <typename T, int D_T, bool RA, bool RB>
 bool try_bwd_tiled(const KParams& P, const T* x, const T* nb, const float* g, const float* dl, T* dx, hipStream_t s) {
   TParams Q;
   // role A alone (a detached second operand's cross loss) reaches only p + o: a one-sided halo; role B needs p - o
-  if (!plan_tiles(P, bwd_cfg<D_T>(0), !(RA && !RB), &Q)) return false;
+  if (!plan_tiles(P, bwd_cfg<D_T>(0), !(RA && !RB), &Q, true)) return false;
   launch_bwd_cfg<T, D_T, RA, RB, 0>(P, Q, x, nb, g, dl, dx, s);
   return true;
 }

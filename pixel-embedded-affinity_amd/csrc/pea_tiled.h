@@ -275,6 +275,8 @@ __device__ __forceinline__ void lane_pixel(int& ly, int& lx) {
 // ---- forward helpers ------------------------------------------------------------------------------
 struct FwdU {  // uniform per-workgroup state
   rsrc_t aB, gB, tB, wB, mB;
+  rsrc_t aB1, gB1, tB1, wB1;  // the same tensors based `ks` offset planes further (KParams::ksplit): channels >= ks go through these
+  unsigned ks;
   unsigned kzo, kcs, S32;  // byte offset of plane z / stride of one offset channel (f32); elements per channel
   bool has_a, has_g, has_m;
   unsigned af;  // activation flags of the affs output (act_affs)
@@ -291,8 +293,10 @@ __device__ __forceinline__ void fwd_load_twm(Twm<KN>& r, const FwdU U, const Off
 #pragma unroll
   for (int u = 0; u < KN; ++u) {
     const unsigned i = ent[min(k0 + u, n - 1)].i;
-    r.t[u] = bl32<true>(U.tB, pb, U.kzo + i * U.kcs);
-    r.w[u] = bl32<true>(U.wB, pb, U.kzo + i * U.kcs);
+    const bool hi = i >= U.ks;  // uniform
+    const unsigned so = U.kzo + (hi ? i - U.ks : i) * U.kcs;
+    r.t[u] = bl32<true>(hi ? U.tB1 : U.tB, pb, so);
+    r.w[u] = bl32<true>(hi ? U.wB1 : U.wB, pb, so);
     r.m[u] = U.has_m ? bl8<true>(U.mB, pm, (U.kzo >> 2) + i * U.S32) : 1.f;
   }
 }
@@ -302,12 +306,13 @@ __device__ __forceinline__ void fwd_load_twm(Twm<KN>& r, const FwdU U, const Off
 template <bool TRAIN>
 __device__ __forceinline__ void fwd_finish(const FwdU U, int K, float* s_part, const OffEnt e, float a, bool valid, float t,
                                            float w, float m, unsigned pb) {
-  const unsigned so = U.kzo + (unsigned)e.i * U.kcs;
-  if (U.has_a) bs32<true>(U.aB, act_affs(a, U.af), pb, so);
+  const bool hi = (unsigned)e.i >= U.ks;  // uniform
+  const unsigned so = U.kzo + (hi ? (unsigned)e.i - U.ks : (unsigned)e.i) * U.kcs;
+  if (U.has_a) bs32<true>(hi ? U.aB1 : U.aB, act_affs(a, U.af), pb, so);
   if (TRAIN) {
     const float r = a * m - t * m;
     const float wr = valid ? w * r : 0.f;
-    if (U.has_g) bs32(U.gB, e.gscale * wr * m, pb, so);
+    if (U.has_g) bs32(hi ? U.gB1 : U.gB, e.gscale * wr * m, pb, so);
     const float red = wave_sum63(wr * r);
     if ((threadIdx.x & 63) == 63) s_part[(threadIdx.x >> 6) * K + e.i] = red;
   }
@@ -345,6 +350,14 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled(const 
   U.tB = mkbuf(target + (size_t)b * P.tbs);
   U.wB = mkbuf(weight + (size_t)b * P.wbs);
   U.mB = mkbuf(mask ? mask + (size_t)b * P.mbs : nullptr);
+  U.ks = (unsigned)P.ksplit;
+  {
+    const size_t ko = (size_t)min(P.ksplit, P.K - 1) * S;  // (ksplit == K: never selected, any valid base will do)
+    U.aB1 = mkbuf(affs ? affs + (size_t)b * P.K * S + ko : nullptr);
+    U.gB1 = mkbuf(gout ? gout + (size_t)b * P.K * S + ko : nullptr);
+    U.tB1 = mkbuf(target + (size_t)b * P.tbs + ko);
+    U.wB1 = mkbuf(weight + (size_t)b * P.wbs + ko);
+  }
   U.kcs = (unsigned)P.S * 4u;
   U.kzo = (unsigned)z * YX * 4u;
   U.S32 = (unsigned)P.S;
@@ -724,6 +737,9 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_bwd_tiled(const 
   const unsigned YX = (unsigned)(P.Y * P.X);
   const rsrc_t xB = mkbuf(xt + (size_t)b * D_T * S), nB = mkbuf(nbt + (size_t)b * D_T * S);
   const rsrc_t dB = mkbuf(dx + (size_t)b * D_T * S), gB = mkbuf(gin + (size_t)b * P.K * S);
+  // offset channels >= ksplit: a second resource based ksplit planes further (KParams::ksplit; == K when there is no split)
+  const rsrc_t gB1 = mkbuf(gin + (size_t)b * P.K * S + (size_t)min(P.ksplit, P.K - 1) * S);
+  const unsigned ksp = (unsigned)P.ksplit;
   const unsigned ecs = (unsigned)P.S * (unsigned)sizeof(T);
   const unsigned ezo = (unsigned)z * YX * (unsigned)sizeof(T);
   const unsigned kcs = (unsigned)P.S * 4u;
@@ -749,7 +765,8 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_bwd_tiled(const 
       const int yy_ = wrap1<CROP>(py + sg_ * ent_oy(en_), P.Y, oky_);                                          \
       const int xx_ = wrap1<CROP>(px + sg_ * ent_ox(en_), P.X, okx_);                                          \
       const bool ok_ = live && oky_ && okx_ && ((k0) + u < Q.n_near);                                          \
-      gn[u][r] = bl32(gB, ok_ ? (sg_ > 0 ? po : (unsigned)(yy_ * P.X + xx_)) * 4u : kOOB, kzo + (unsigned)en_.i * kcs); \
+      gn[u][r] = bl32((unsigned)en_.i >= ksp ? gB1 : gB, ok_ ? (sg_ > 0 ? po : (unsigned)(yy_ * P.X + xx_)) * 4u : kOOB,     \
+                      kzo + ((unsigned)en_.i >= ksp ? (unsigned)en_.i - ksp : (unsigned)en_.i) * kcs);                     \
     }                                                                                                          \
   }
 
@@ -786,7 +803,8 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_bwd_tiled(const 
     const unsigned qo_ = (unsigned)(yy_ * P.X + xx_);                                                         \
     const unsigned vo_ = ok_ ? qo_ * (unsigned)sizeof(T) : kOOB;                                              \
     _Pragma("unroll") for (int c = 0; c < D_T; ++c) fv[c] = bl_emb<T>(nB, vo_, zc_ * YX * (unsigned)sizeof(T) + c * ecs); \
-    fg = bl32(gB, ok_ ? (sg_ > 0 ? po : qo_) * 4u : kOOB, (sg_ > 0 ? kzo : zc_ * YX * 4u) + (unsigned)fe_.i * kcs); \
+    fg = bl32((unsigned)fe_.i >= ksp ? gB1 : gB, ok_ ? (sg_ > 0 ? po : qo_) * 4u : kOOB,                        \
+              (sg_ > 0 ? kzo : zc_ * YX * 4u) + ((unsigned)fe_.i >= ksp ? (unsigned)fe_.i - ksp : (unsigned)fe_.i) * kcs); \
   }
 #define PEA_BWD_FAR(fv, fg)                                                       \
   {                                                                               \
