@@ -1094,3 +1094,44 @@ def test_affs_activations_match_reference_golden(pkg, dev):
     a = col.numpy()
     assert a.shape == (2, len(offsets), 40, 72) and a.flags["C_CONTIGUOUS"] and np.abs(a[1] - g["relu_ours"][0]).max() < AFFS_ATOL
     assert np.abs(col.mutex_input(0) - g["mutex_ours"][0]).max() < AFFS_ATOL
+
+
+def test_degenerate_inputs_vs_oracle(pkg, dev, orc, synth):
+    """the corners of the domain: an all-zero mask (no pixel carries loss: loss and gradient exactly 0), all-zero weights, a single
+    offset, an offset as long as the image (torch.roll folds it to 0: a = 1 wherever the embedding is not zero), the smallest
+    images (every kernel family has to refuse them down to the direct kernels), an all-zero embedding (clamp branch everywhere)"""
+    crit = pkg.WeightedMSE()
+
+    def run(e, t, w, m, offsets):
+        x = cu(e, dev).requires_grad_(True)
+        loss, affs, parts = pkg.embedding_loss(x, cu(t, dev), cu(w, dev), cu(m, dev), crit, offsets)
+        loss.backward()
+        d = orc.desc_2d(e, offsets)
+        o_affs, o_loss = orc.c_fwd(d, e, None, t, w, m)
+        o_grad, _ = orc.c_bwd(d, e, None, t, w, m)
+        return loss.item(), affs.cpu().numpy(), x.grad.cpu().numpy(), o_loss[0], o_affs, o_grad
+
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], neighbor=4)
+    B, D, H, W = 2, 16, 64, 96
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, seed=808)
+    # all-zero mask / all-zero weights: nothing to learn from
+    for tt, ww, mm in ((t, w, np.zeros_like(m)), (t, np.zeros_like(w), m)):
+        l, a, g, ol, oa, og = run(e, tt, ww, mm, offsets)
+        assert l == 0.0 and ol == 0.0 and not g.any() and not og.any() and np.abs(a - oa).max() < AFFS_ATOL
+    # all-zero embedding: every pixel takes the clamp branch of F.normalize; affs are 0, the gradient is finite
+    l, a, g, ol, oa, og = run(np.zeros_like(e), t, w, m, offsets)
+    assert not a.any() and np.isfinite(g).all() and abs(l - ol) <= LOSS_RTOL * abs(ol) and np.abs(g - og).max() <= GRAD_RTOL * np.abs(og).max() + 1e-6
+    # a single offset, and one as long as the image (folds to the zero offset)
+    for offs in ([[-1, 0]], [[0, -W]], [[-H, 0], [0, -1]]):
+        K = len(offs)
+        l, a, g, ol, oa, og = run(e, t[:, :K], w[:, :K], m[:, :K], offs)
+        assert np.abs(a - oa).max() < AFFS_ATOL and abs(l - ol) <= LOSS_RTOL * abs(ol) + 1e-12
+        assert np.abs(g - og).max() <= GRAD_RTOL * np.abs(og).max() + 1e-6   # (+ floor: a folded offset's gradient is rounding noise)
+    assert np.abs(run(e, t[:, :1], w[:, :1], m[:, :1], [[0, -W]])[1] - 1.0).max() < 1e-5
+    # the smallest images
+    for (h, wd) in ((2, 4), (3, 5), (1, 8), (8, 1)):
+        offs = [[-1, 0], [0, -1]]
+        e2, t2, w2, m2 = synth.synth_inputs_2d(1, D, h, wd, offs, seed=900 + h)
+        l, a, g, ol, oa, og = run(e2, t2, w2, m2, offs)
+        assert np.abs(a - oa).max() < AFFS_ATOL and abs(l - ol) <= LOSS_RTOL * abs(ol) + 1e-12
+        assert np.abs(g - og).max() <= GRAD_RTOL * np.abs(og).max() + 1e-6   # (+ floor: a folded offset's gradient is rounding noise)
