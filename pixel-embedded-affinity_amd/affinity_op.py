@@ -95,8 +95,23 @@ def make_desc(spec, e, tstride=0, wstride=0, mstride=0):
         return d
     if len(_DESC_CACHE) > 512:
         _DESC_CACHE.clear()
+        _CROSS_OK.clear()  # (keyed by the identity of descriptors that are about to go away)
     d = _DESC_CACHE[key] = _build_desc(spec, e, tstride, wstride, mstride)
     return d
+
+
+_CROSS_OK = {}
+
+
+def cross_supported(d, mode):
+    """pea_cross_supported(desc, mode), remembered per memoised descriptor (the host-side plan behind it costs a few microseconds)"""
+    key = (id(d), mode)
+    r = _CROSS_OK.get(key)
+    if r is None:
+        if len(_CROSS_OK) > 2048:
+            _CROSS_OK.clear()
+        r = _CROSS_OK[key] = bool(_lib.lib().pea_cross_supported(ctypes.byref(d), mode))
+    return r
 
 
 def _build_desc(spec, e, tstride, wstride, mstride):
@@ -124,8 +139,33 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """the current HIP stream of the current device as a void*.  torch.cuda.current_stream() builds a Stream object through
+    ~35 us of Python (device-index parsing); the raw handle is one C call -- the Python path of a training step is ~160 us of
+    host time against ~215 us of GPU time, so this matters for staying GPU-bound on a busy host"""
+    if _RAW_STREAM is not None:
+        return ctypes.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _on_device(object):
+    """`with torch.cuda.device(dev)` without its cost when dev is already the current device (the one-process-per-GPU case)"""
+    __slots__ = ("_ctx",)
+
+    def __init__(self, dev):
+        self._ctx = None if dev.index is None or dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self._ctx is not None:
+            return self._ctx.__exit__(*a)
+        return False
 
 
 def _affs_shape(e, K):
@@ -139,7 +179,7 @@ def affinity_infer(e, e_other, spec):
         e_other = _embedding_arg(e_other, "ema_embedding").to(e.dtype)
         if e_other.shape != e.shape:
             raise ValueError("ema_embedding shape %s != embedding shape %s" % (tuple(e_other.shape), tuple(e.shape)))
-    with torch.cuda.device(e.device):
+    with _on_device(e.device):
         d = make_desc(spec, e)
         affs = torch.empty(_affs_shape(e, spec.K), dtype=torch.float32, device=e.device)
         _lib.check(_lib.lib().pea_affinity_infer(ctypes.byref(d), _ptr(e.detach()), _ptr(None if e_other is None else e_other.detach()),
@@ -176,7 +216,7 @@ class FusedAffinityMSE(torch.autograd.Function):
                 raise RuntimeError("all operands must live on %s" % e_c.device)
         want_e = e.requires_grad
         want_o = e_other is not None and e_other.requires_grad
-        with torch.cuda.device(e_c.device):
+        with _on_device(e_c.device):
             d = make_desc(spec, e_c, ts, ws, ms)
             L = _lib.lib()
             affs = torch.empty(kshape, dtype=torch.float32, device=e_c.device)
@@ -188,9 +228,9 @@ class FusedAffinityMSE(torch.autograd.Function):
             # 1 / norm of e, 4 bytes per pixel: what the cross backward (self loss, axis-aligned stencil) stages next to e;
             # with a detached second operand two planes (e, e_other) where the role-A cross kernels cover the shape
             inv = None
-            if want_e and o_c is None and L.pea_cross_supported(ctypes.byref(d), 1):
+            if want_e and o_c is None and cross_supported(d, 1):
                 inv = torch.empty((e_c.shape[0],) + tuple(e_c.shape[2:]), dtype=torch.float32, device=e_c.device)
-            elif want_e and not want_o and L.pea_cross_supported(ctypes.byref(d), 2):
+            elif want_e and not want_o and cross_supported(d, 2):
                 inv = torch.empty((2, e_c.shape[0]) + tuple(e_c.shape[2:]), dtype=torch.float32, device=e_c.device)
             _lib.check(L.pea_affinity_fwd_ex(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(target), _ptr(weight), _ptr(mask),
                                              _ptr(affs), _ptr(g), _ptr(inv), _ptr(loss_vec), _ptr(work), wsb, _stream()),
@@ -211,7 +251,7 @@ class FusedAffinityMSE(torch.autograd.Function):
             return None, None, None, None, None, None
         if e_c.shape[1] not in SPECIALISED_TRAIN_D and ctx.spec.border == _lib.BORDER_REPLICATE:
             raise NotImplementedError("the replicate-border backward needs D in %s (got %d)" % (SPECIALISED_TRAIN_D, e_c.shape[1]))
-        with torch.cuda.device(e_c.device):
+        with _on_device(e_c.device):
             L = _lib.lib()
             dl = dloss.to(device=e_c.device, dtype=torch.float32).contiguous()
             de = torch.empty_like(e_c) if want_e else None
@@ -245,7 +285,7 @@ class AffinityMap(torch.autograd.Function):
             raise NotImplementedError("an activation of the affs output is inference-only: apply it to the map yourself")
         if e_c.shape[1] not in SPECIALISED_TRAIN_D and ctx.spec.border == _lib.BORDER_REPLICATE:
             raise NotImplementedError("the replicate-border backward needs D in %s (got %d)" % (SPECIALISED_TRAIN_D, e_c.shape[1]))
-        with torch.cuda.device(e_c.device):
+        with _on_device(e_c.device):
             d = make_desc(ctx.spec, e_c)
             da = d_affs.to(torch.float32).contiguous()
             de = torch.empty_like(e_c) if want_e else None
@@ -362,7 +402,7 @@ class LabelsAffinityMSE(torch.autograd.Function):
             raise LabelsStepUnsupported("an offset is as long as the image: the labels-in kernels would fold it (torch.roll) where "
                                         "gen_affs_ours masks it out; use gen_targets + the tensor API")
         kshape = _affs_shape(e_c, spec.K)
-        with torch.cuda.device(e_c.device):
+        with _on_device(e_c.device):
             d = make_desc(spec, e_c)
             L = _lib.lib()
             affs = torch.empty(kshape if need_affs else (0,), dtype=torch.float32, device=e_c.device)
@@ -393,7 +433,7 @@ class LabelsAffinityMSE(torch.autograd.Function):
             raise RuntimeError("the labels-in step hands its gradient buffer to the first backward; for a second backward "
                                "over a retained graph use gen_targets + embedding_loss")
         de, ctx.de_unit = ctx.de_unit, None
-        with torch.cuda.device(de.device):
+        with _on_device(de.device):
             dl = dloss.to(device=de.device, dtype=torch.float32).contiguous()
             _lib.check(_lib.lib().pea_scale_inplace(_ptr(de), ctx.desc.dtype, de.numel(), _ptr(dl), _stream()), "pea_scale_inplace")
         return de, None, None, None, None, None

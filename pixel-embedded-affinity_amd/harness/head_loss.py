@@ -22,7 +22,7 @@ import ctypes
 import torch
 
 from .. import _lib
-from ..affinity_op import (AffinitySpec, LossList, _affs_shape, _batch_strided, _ptr, _require_gpu, _stream, make_desc)
+from ..affinity_op import (AffinitySpec, LossList, _affs_shape, _batch_strided, _on_device, _ptr, _require_gpu, _stream, make_desc)
 from ..model.head import head_supported
 
 
@@ -44,7 +44,7 @@ class HeadAffinityMSE(torch.autograd.Function):
         bc = None if bias is None else bias.detach().contiguous()
         B, S = xc.shape[0], xc[0, 0].numel()
         L = _lib.lib()
-        with torch.cuda.device(xc.device):
+        with _on_device(xc.device):
             e = torch.empty((B, D) + tuple(xc.shape[2:]), dtype=torch.float32, device=xc.device)
             _lib.check(L.pea_head_fwd(B, C, D, S, _ptr(xc), _ptr(wc), _ptr(bc), _ptr(e), _stream()), "pea_head_fwd")
             kshape = _affs_shape(e, spec.K)
@@ -78,7 +78,7 @@ class HeadAffinityMSE(torch.autograd.Function):
         D, C = wc.shape
         B, S = xc.shape[0], xc[0, 0].numel()
         L = _lib.lib()
-        with torch.cuda.device(xc.device):
+        with _on_device(xc.device):
             dx = torch.empty_like(xc) if ctx.needs_input_grad[0] else None
             dW = torch.empty((D, C), dtype=torch.float32, device=xc.device)
             db = torch.empty(D, dtype=torch.float32, device=xc.device) if ctx.has_bias else None

@@ -80,7 +80,7 @@ class _TensorSection(torch.autograd.Function):
         L = _lib.lib()
         ncall = len(specs)
         kmax = max(sp.K for sp in specs)
-        with torch.cuda.device(dev):
+        with op._on_device(dev):
             wdev = _weights_on(dev, weights)
             rows = torch.empty((ncall, 1 + kmax), dtype=torch.float32, device=dev)
             grads, pred = [], None
@@ -167,7 +167,7 @@ def _section_backward(ctx, dtotal):
     grads, ctx.grads = ctx.grads, None
     L = _lib.lib()
     dev = grads[0].device
-    with torch.cuda.device(dev):
+    with op._on_device(dev):
         # one launch rescales every gradient by grad_output (and returns untouched when that is exactly 1)
         dl = dtotal.to(device=dev, dtype=torch.float32).contiguous()
         bufs = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
@@ -411,7 +411,7 @@ class _LabelsSection(torch.autograd.Function):
         tables = label_cfg.tables  # precomputed by *_label_weight_tables (off the critical path), or None
         ncall = len(specs)
         kmax = max(sp.K for sp in specs)
-        with torch.cuda.device(dev):
+        with op._on_device(dev):
             wdev = _weights_on(dev, weights)
             rows = torch.empty((ncall, 1 + kmax), dtype=torch.float32, device=dev)
 
@@ -522,7 +522,7 @@ def cvppp_label_weight_tables(labels, label_downs, offsets, nb_half, dis_mode='o
         lab = op._labels_int32(lab)
         like = torch.empty((lab.shape[0], 16) + tuple(lab.shape[1:]), device="meta")  # geometry only
         d = op.make_desc(specs[j], like)
-        with torch.cuda.device(lab.device):
+        with op._on_device(lab.device):
             cb = L.pea_targets_workspace_bytes(ctypes.byref(d))
             counts = torch.empty(max(cb, 4) // 4, dtype=torch.int32, device=lab.device)
             wtab = torch.empty(lab.shape[0] * specs[j].K * 2, dtype=torch.float32, device=lab.device)

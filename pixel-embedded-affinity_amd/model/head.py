@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
-from ..affinity_op import _ptr, _require_gpu, _stream
+from ..affinity_op import _on_device, _ptr, _require_gpu, _stream
 
 
 def head_supported(C, D):
@@ -39,7 +39,7 @@ class EmbeddingHead(torch.autograd.Function):
         wc = weight.detach().reshape(D, C).contiguous()
         bc = None if bias is None else bias.detach().contiguous()
         B, S = xc.shape[0], xc[0, 0].numel()
-        with torch.cuda.device(xc.device):
+        with _on_device(xc.device):
             e = torch.empty((B, D) + tuple(xc.shape[2:]), dtype=torch.float32, device=xc.device)
             _lib.check(_lib.lib().pea_head_fwd(B, C, D, S, _ptr(xc), _ptr(wc), _ptr(bc), _ptr(e), _stream()), "pea_head_fwd")
         ctx.save_for_backward(xc, wc)
@@ -53,7 +53,7 @@ class EmbeddingHead(torch.autograd.Function):
         D, C = wc.shape
         B, S = xc.shape[0], xc[0, 0].numel()
         L = _lib.lib()
-        with torch.cuda.device(xc.device):
+        with _on_device(xc.device):
             dec = de.to(torch.float32).contiguous()
             dx = torch.empty_like(xc) if ctx.needs_input_grad[0] else None
             dW = torch.empty((D, C), dtype=torch.float32, device=xc.device)
