@@ -97,6 +97,8 @@ class _TensorSection(torch.autograd.Function):
                 if m is not None:
                     if m.dtype == torch.bool:
                         m = m.view(torch.uint8)
+                    elif m.dtype != torch.uint8:  # the reference packs the deep-supervision masks as float thirds of `downN`
+                        m = m.to(torch.uint8)      # (runs on the stream of this loss: the side stream for the small scales)
                     m, ms = op._batch_strided(m, "mask", torch.uint8, kshape)
                 d = op.make_desc(spec, e_c, ts, ws, ms)
                 wsb = L.pea_workspace_bytes(ctypes.byref(d))
@@ -260,7 +262,7 @@ def cvppp_loss_section(embedding, emds, ema_embedding, target, weightmap, affs_m
         for j, down in enumerate(downs):
             k = nb_half * (4 - j)
             m = down[:, 2 * k:3 * k]
-            tensors.append((down[:, 0:k], down[:, k:2 * k], m if m.dtype in (torch.uint8, torch.bool) else m.to(torch.uint8)))
+            tensors.append((down[:, 0:k], down[:, k:2 * k], m))  # (a float mask third is converted where its loss is launched: side stream)
         loss, pred, losses = _TensorSection.apply(specs, weights, ema_embedding, tensors, embedding, *emds)
         return loss, pred, _section_parts(losses, weights, self_emb, cross_emb)
     loss, pred, parts = cvppp_loss_section_composed(embedding, emds, ema_embedding, target, weightmap, affs_mask, downs, criterion,
