@@ -15,6 +15,7 @@ masks and class-balance weights are evaluated from the int32 label pyramid insid
 traffic is the images and five label maps instead of ~40 MB of target / weight / mask tensors per image.
 The second forward runs under no_grad: its output is detached by convert_consistency_flip, so the graph the reference
 builds for it is never used (BatchNorm statistics update the same way)."""
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -29,16 +30,19 @@ def convert_consistency_flip(ema_embedding, rules):
     out = ema_embedding.detach().clone()
     if rules is None:
         return out
+    # one host copy of the whole table, cast the way the reference does (rules.data.cpu().numpy().astype(np.uint8), :37)
+    r = (rules.detach().cpu().numpy() if torch.is_tensor(rules) else np.asarray(rules)).astype(np.uint8)
+    parts = []
     for b in range(out.shape[0]):
         t = out[b]
-        if rules[b][2] > 0.5:
+        if r[b][2]:
             t = t.transpose(-1, -2)
-        if rules[b][1] > 0.5:
+        if r[b][1]:
             t = t.flip(-2)
-        if rules[b][0] > 0.5:
+        if r[b][0]:
             t = t.flip(-1)
-        out[b] = t
-    return out
+        parts.append(t)
+    return torch.stack(parts, dim=0)  # (a transposed view cannot be written back over its own storage)
 
 
 def label_pyramid(labels):

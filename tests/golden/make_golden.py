@@ -333,6 +333,17 @@ def case_activation(name, seed, B, D, H, W, shifts):
     save(name, e=e, offsets=np.array(offsets, np.int32), half_clamp_cos=half_clamp, relu_ours=relu.numpy(), mutex_ours=(1.0 - relu).numpy())
 
 
+def case_flip(name, seed):
+    """convert_consistency_flip (scripts_cvppp/data/data_consistency.py:34-45): the per-sample inverse of the EMA branch's flips /
+    transpose; all eight rule combinations on a square map with distinct values"""
+    refflip = load("ref_consistency", "scripts_cvppp/data/data_consistency.py")
+    rng = np.random.default_rng(seed)
+    rules = np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], np.float32)
+    gt = rng.standard_normal((8, 3, 6, 6)).astype(np.float32)
+    out = refflip.convert_consistency_flip(T(gt), T(rules)).numpy()
+    save(name, gt=gt, rules=rules, out=out)
+
+
 def case_full_summary(name, seed, B, D, H, W):
     """One full-size CVPPP case (B x 16 x 544 x 544, K=10): too big to store, so inputs are a closed-form
     function of the index (no RNG) and only summary statistics + samples of the outputs are kept."""
@@ -384,6 +395,7 @@ if __name__ == "__main__":
         case_stitch_weight("gstitch_weight_18x160x160", (18, 160, 160))
         case_section("gsection_cvppp", 92, B=2, D=16, H=48, W=64)
         case_activation("gact_2d", 93, B=1, D=16, H=40, W=72, shifts=[1, 3, 9])
+        case_flip("gflip_rules", 94)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "model":  # only the backbone layout fixtures
         case_model("gmodel_resunet2d", 81, (2, 3, 48, 64), [4, 8, 12, 16, 20], 16)
@@ -438,3 +450,4 @@ if __name__ == "__main__":
     case_stitch_weight("gstitch_weight_18x160x160", (18, 160, 160))
     case_section("gsection_cvppp", 92, B=2, D=16, H=48, W=64)
     case_activation("gact_2d", 93, B=1, D=16, H=40, W=72, shifts=[1, 3, 9])
+    case_flip("gflip_rules", 94)

@@ -51,3 +51,17 @@ def test_label_pyramid_follows_the_nearest_resize_rule(pkg):
             iy = np.minimum(np.floor(np.arange(ny) * f).astype(int), h - 1)
             ix = np.minimum(np.floor(np.arange(nx) * f).astype(int), w - 1)
             assert np.array_equal(got.numpy(), lab[:, iy][:, :, ix]), (h, w, j)
+
+
+def test_convert_consistency_flip_matches_reference_golden(pkg):
+    """harness/train_step.convert_consistency_flip against the reference's function run on all eight rule combinations
+    (tests/golden/make_golden.py case_flip: scripts_cvppp/data/data_consistency.py:34-45); the result is detached"""
+    import numpy as np
+    import torch
+    from conftest import load_golden
+    g = load_golden("gflip_rules")
+    x = torch.from_numpy(g["gt"]).requires_grad_(True)
+    for rules in (torch.from_numpy(g["rules"]), g["rules"].tolist()):
+        out = pkg.convert_consistency_flip(x, rules)
+        assert not out.requires_grad and np.array_equal(out.numpy(), g["out"])
+    assert np.array_equal(pkg.convert_consistency_flip(x, None).numpy(), g["gt"])
