@@ -320,6 +320,45 @@ def case_section(name, seed, B, D, H, W):
          pred=torch.relu(pred).detach().numpy(), **out)
 
 
+def case_section_3d(name, seed, B, D, Z, Y, X, mode):
+    """the loss section of scripts_ac3ac4/main.py:219-237, run by the reference's own functions in that order: the full-resolution
+    self + EMA cross loss (norm1 or norm5), four norm1 losses on the deep-supervision heads paired emd1<->down4 .. emd4<->down1,
+    loss.backward(), then the border fill of the three shift-1 channels and relu on pred"""
+    rng = np.random.default_rng(seed)
+    K = 3 if mode == 1 else 12
+    dims = [(Z, Y, X)] + [(max(Z >> 0, 1), Y >> j, X >> j) for j in range(1, 5)]   # the heads keep z, halve y / x (superhuman U-Net)
+    emb = rng.standard_normal((B, D) + dims[0]).astype(np.float32)
+    ema = rng.standard_normal((B, D) + dims[0]).astype(np.float32)
+    target = (rng.random((B, K) + dims[0]) < 0.7).astype(np.float32)
+    weight = (0.5 + rng.random((B, K) + dims[0])).astype(np.float32)
+    # emd1 .. emd4: coarsest first (model_superhuman.py returns them in that order); downN = [target(3) | weight(3)] at scale N
+    emds = [rng.standard_normal((B, D) + dims[4 - j]).astype(np.float32) for j in range(4)]
+    downs = [np.concatenate([(rng.random((B, 3) + dims[j]) < 0.7).astype(np.float32), (0.5 + rng.random((B, 3) + dims[j])).astype(np.float32)], axis=1)
+             for j in range(1, 5)]     # down1 .. down4
+    et, emt = T(emb).requires_grad_(True), [T(e).requires_grad_(True) for e in emds]
+    f_self = ref3d.embedding_loss_norm1 if mode == 1 else ref3d.embedding_loss_norm5
+    f_ema = ref3d.ema_embedding_loss_norm1 if mode == 1 else ref3d.ema_embedding_loss_norm5
+    l0, pred = f_self(et, T(target), T(weight), criterion, affs0_weight=1)
+    lx, _ = f_ema(et, T(ema), T(target), T(weight), criterion, affs0_weight=1)
+    ls = []
+    for emd, down in zip(emt, [T(d) for d in downs[::-1]]):   # emd1 <-> down4, ..., emd4 <-> down1 (main.py:225-228)
+        l, _ = ref3d.embedding_loss_norm1(emd, down[:, :3], down[:, 3:], criterion, affs0_weight=1)
+        ls.append(l)
+    loss = l0 + lx + ls[0] + ls[1] + ls[2] + ls[3]
+    loss.backward()
+    pred = pred.clone()
+    shift = 1
+    pred[:, 1, :, :shift, :] = pred[:, 1, :, shift:shift * 2, :]
+    pred[:, 2, :, :, :shift] = pred[:, 2, :, :, shift:shift * 2]
+    pred[:, 0, :shift, :, :] = pred[:, 0, shift:shift * 2, :, :]
+    pred = torch.relu(pred)
+    out = {"emd%d" % (j + 1): emds[j] for j in range(4)}
+    out.update({"down%d" % (j + 1): downs[j] for j in range(4)})
+    out.update({"grad_emd%d" % (j + 1): emt[j].grad.numpy() for j in range(4)})
+    save(name, emb=emb, ema=ema, target=target, weight=weight, mode=np.int32(mode), total=np.float32(loss.item()),
+         grad_emb=et.grad.numpy(), pred=pred.detach().numpy(), **out)
+
+
 def case_activation(name, seed, B, D, H, W, shifts):
     """the affinity maps of the reference's experimental loss (scripts_cvppp/loss/loss_embedding.py:33-46): CosineSimilarity
     (eps 1e-6) -> (a + 1) / 2 -> clamp; and the shipped hand-off statements on the shipped map: relu (inference.py:193), 1 - relu (seg_mutex.py:5)"""
@@ -396,6 +435,8 @@ if __name__ == "__main__":
         case_section("gsection_cvppp", 92, B=2, D=16, H=48, W=64)
         case_activation("gact_2d", 93, B=1, D=16, H=40, W=72, shifts=[1, 3, 9])
         case_flip("gflip_rules", 94)
+        case_section_3d("gsection_ac3ac4_norm5", 95, B=1, D=16, Z=5, Y=32, X=48, mode=5)
+        case_section_3d("gsection_ac3ac4_norm1", 96, B=2, D=16, Z=4, Y=32, X=48, mode=1)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "model":  # only the backbone layout fixtures
         case_model("gmodel_resunet2d", 81, (2, 3, 48, 64), [4, 8, 12, 16, 20], 16)
@@ -451,3 +492,5 @@ if __name__ == "__main__":
     case_section("gsection_cvppp", 92, B=2, D=16, H=48, W=64)
     case_activation("gact_2d", 93, B=1, D=16, H=40, W=72, shifts=[1, 3, 9])
     case_flip("gflip_rules", 94)
+    case_section_3d("gsection_ac3ac4_norm5", 95, B=1, D=16, Z=5, Y=32, X=48, mode=5)
+    case_section_3d("gsection_ac3ac4_norm1", 96, B=2, D=16, Z=4, Y=32, X=48, mode=1)

@@ -1135,3 +1135,26 @@ def test_degenerate_inputs_vs_oracle(pkg, dev, orc, synth):
         l, a, g, ol, oa, og = run(e2, t2, w2, m2, offs)
         assert np.abs(a - oa).max() < AFFS_ATOL and abs(l - ol) <= LOSS_RTOL * abs(ol) + 1e-12
         assert np.abs(g - og).max() <= GRAD_RTOL * np.abs(og).max() + 1e-6   # (+ floor: a folded offset's gradient is rounding noise)
+
+
+@pytest.mark.parametrize("name,path", [("gsection_ac3ac4_norm5", "one_node"), ("gsection_ac3ac4_norm5", "composed"),
+                                       ("gsection_ac3ac4_norm1", "one_node"), ("gsection_ac3ac4_norm1", "composed")])
+def test_ac3ac4_loss_section_matches_reference_golden(pkg, dev, name, path):
+    """the loss section of the 3D training loop against the reference's own functions called in scripts_ac3ac4/main.py:219-237's
+    order (tests/golden/make_golden.py case_section_3d): total, the border-filled relu'd pred, the five gradients -- pins the
+    emd1 <-> down4 .. emd4 <-> down1 pairing to a run of the reference"""
+    g = load_golden(name)
+    crit = pkg.WeightedMSE()
+    emb = cu(g["emb"], dev).requires_grad_(True)
+    emds = [cu(g["emd%d" % j], dev).requires_grad_(True) for j in range(1, 5)]
+    downs = [cu(g["down%d" % j], dev) for j in range(1, 5)]
+    fn = pkg.ac3ac4_loss_section if path == "one_node" else pkg.ac3ac4_loss_section_composed
+    loss, pred = fn(emb, emds, cu(g["ema"], dev), cu(g["target"], dev), cu(g["weight"], dev), downs, crit,
+                    embedding_mode=int(g["mode"]), affs0_weight=1)
+    loss.backward()
+    pred = pkg.finish_pred_3d_(pred.clone())
+    assert abs(loss.item() - float(g["total"])) <= 1e-5 * abs(float(g["total"]))
+    assert np.abs(pred.cpu().numpy() - g["pred"]).max() < AFFS_ATOL
+    assert relmax(emb.grad.cpu().numpy(), g["grad_emb"]) < GRAD_RTOL
+    for j in range(1, 5):
+        assert relmax(emds[j - 1].grad.cpu().numpy(), g["grad_emd%d" % j]) < GRAD_RTOL, j
