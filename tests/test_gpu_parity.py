@@ -1158,3 +1158,19 @@ def test_ac3ac4_loss_section_matches_reference_golden(pkg, dev, name, path):
     assert relmax(emb.grad.cpu().numpy(), g["grad_emb"]) < GRAD_RTOL
     for j in range(1, 5):
         assert relmax(emds[j - 1].grad.cpu().numpy(), g["grad_emd%d" % j]) < GRAD_RTOL, j
+
+
+def test_validation_section_matches_reference_golden(pkg, dev):
+    """cvppp_validation_section (scripts_cvppp/inference.py:179-193) on the inputs of gsection_cvppp: the unweighted sum of the five
+    self losses the reference's functions produced, and relu(pred); the test-mode branch = relu(embedding2affs)"""
+    g = load_golden("gsection_cvppp")
+    offsets = g["offsets"].tolist()
+    crit = pkg.WeightedMSE()
+    embs = [cu(g["emb%d" % j], dev) for j in range(5)]
+    downs = [torch.cat([cu(g["t%d" % j], dev), cu(g["w%d" % j], dev), cu(g["m%d" % j], dev).float()], dim=1) for j in range(1, 5)]
+    loss, pred = pkg.cvppp_validation_section(embs[0], embs[1:], cu(g["t0"], dev), cu(g["w0"], dev), cu(g["m0"], dev), downs, crit, offsets, 2)
+    want = float(g["losses"][:5].sum())
+    assert abs(loss.item() - want) <= 1e-5 * abs(want)
+    assert np.abs(pred.cpu().numpy() - g["pred"]).max() < AFFS_ATOL
+    none, pred_t = pkg.cvppp_validation_section(embs[0], embs[1:], None, None, None, None, crit, offsets, 2, test_mode=True)
+    assert none is None and np.abs(pred_t.cpu().numpy() - g["pred"]).max() < AFFS_ATOL
