@@ -13,6 +13,8 @@ Semantics kept from the reference (file:line there):
     (normaliser B*W, loss.py:113-115); any other callable gets `criterion(affs*mask, target*mask, weightmap)`
     per offset on a differentiable affinity map, exactly like the reference
   * `all_loss` is a list of K floats; here it is filled lazily from a device tensor (no K host syncs)
+  * `mask` is the 0 / 1 map gen_affs_ours produces (any dtype; the reference multiplies by mask.float(), :21): the fused path
+    stores it as one byte per pixel, so values other than 0 and 1 are not supported there (pass a foreign criterion for those)
 """
 import torch
 
