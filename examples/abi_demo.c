@@ -80,6 +80,7 @@ int main(void) {
   double err_inf = 0;
   for (size_t i = 0; i < nk; ++i) err_inf = fmax(err_inf, fabs(affs[i] - ref[i]));
 
+  CHECK_PEA(pea_workspace_init(dwk, wsb, st)); /* once per workspace: the loss-state block (include/pea.h) */
   CHECK_PEA(pea_affinity_fwd(&d, de, NULL, (const float *)dt, (const float *)dw, (const uint8_t *)dm, (float *)da, (float *)dg, (float *)dl, dwk, wsb, st));
   CHECK_PEA(pea_affinity_bwd(&d, de, NULL, (const float *)dg, NULL, dgrad, NULL, st));
   CHECK_HIP(hipMemcpyAsync(loss, dl, sizeof(loss), hipMemcpyDeviceToHost, st));

@@ -48,7 +48,9 @@
 extern "C" {
 #endif
 
-#define PEA_ABI_VERSION 1 /* version of PeaDesc and of the semantics of the existing calls; new entry points do not bump it */
+#define PEA_ABI_VERSION 2 /* version of PeaDesc and of the semantics of the existing calls; new entry points do not bump it.
+                            2: the workspace of the training forward is a small STATE block that pea_workspace_init prepares once (was: a
+                               per-workgroup table, no preparation); pea_affinity_fwd_bwd (round 1) and pea_affinity_bwd_head are gone */
 #define PEA_MAX_K 32 /* 26-neighbourhood (BASELINE config 4) fits */
 
 /* border modes */
@@ -71,7 +73,8 @@ extern "C" {
 #define PEA_FLAG_CLAMP01 8u    /* a -> clamp(a, 0, 1) (torch.clamp(affs_temp, 0.0, 1.0), loss_embedding.py:11,36) */
 #define PEA_FLAG_ACCUMULATE_DE 16u /* pea_affinity_bwd_ex with a detached second operand: de += (the self loss' gradient of the same
                                     embedding is already in `de`: loss_embedding + loss_embedding_cross, main.py:306-310, one buffer);
-                                    PEA_E_UNSUPPORTED where the role-A cross kernel does not apply (the caller adds two buffers) */
+                                    PEA_E_UNSUPPORTED where the role-A cross kernel does not apply (the caller adds two buffers),
+                                    and for a self loss (e_other == NULL); ignored by the forward / inference calls */
 #define PEA_FLAG_ONE_MINUS 2u  /* a -> 1 - a         (what elf's mutex_watershed is handed: scripts_cvppp/utils/seg_mutex.py:4-5) */
 
 /* error codes: 0 = ok, negative = PEA_E_*, positive = a hipError_t from the runtime */
@@ -111,9 +114,21 @@ const char *pea_strerror(int code);
 /* Host-only check of a descriptor: PEA_OK or PEA_E_DESC / PEA_E_UNSUPPORTED. No GPU needed. */
 int pea_desc_validate(const PeaDesc *desc);
 
-/* Bytes of device scratch pea_affinity_fwd needs for its per-workgroup loss partials and the slice sums of their two-level
- * reduction; the buffer must be 8-byte aligned. */
+/* The workspace of the training forward (pea_affinity_fwd / _fwd_ex / _fwd_bwd_labels): a STATE block of pea_workspace_bytes(desc)
+ * bytes (the same ~16 KB for every descriptor; 8-byte aligned) into which the workgroups add their loss partials as 128-bit
+ * fixed-point integers with integer atomics (csrc/pea_loss.h): the sum does not depend on the order of arrival, is exact, and
+ * bit-reproducible.  Contract:
+ *   - call pea_workspace_init(workspace, bytes, stream) ONCE after allocating it (it may hold several states back to back:
+ *     pea_affinity_fwd_bwd_labels_dual takes two);
+ *   - every call leaves the block ready for the next one (it is zero between calls), so one block can serve every later call
+ *     ON THE SAME STREAM, of any descriptor; calls that may run concurrently (different streams) need a block each;
+ *   - a block that was never initialised yields NaN losses (never a silently wrong number). */
 size_t pea_workspace_bytes(const PeaDesc *desc);
+int pea_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
+
+/* Re-read the PEA_* environment switches (they are read once, at the first call): PEA_FORCE_DIRECT, PEA_FWD_XDMA, PEA_BWD_XDMA,
+ * PEA_LABELS_DUAL, PEA_LOSS_TICKET, PEA_FWD_WG3 -- A/B and debugging switches; tests that change one call this. */
+void pea_reload_env(void);
 
 /* Inference: affs[B,K,Z,Y,X] only.  e_other may be NULL. */
 int pea_affinity_infer(const PeaDesc *desc, const void *e, const void *e_other, float *affs,
@@ -123,7 +138,7 @@ int pea_affinity_infer(const PeaDesc *desc, const void *e, const void *e_other, 
  * un-weighted per-offset loss, i.e. the reference's all_loss list) and, when g_out != NULL,
  * g_out[B,K,Z,Y,X] = d loss / d affs = lambda_i * 2 w m (a m - t m) / N_i  (0 where the neighbour is cropped
  * away) -- the only thing the backward needs besides the embeddings.
- * Deterministic: per-workgroup partials in `workspace`, reduced in a fixed order. */
+ * Deterministic: per-workgroup partials added into `workspace` as integers (see pea_workspace_bytes). */
 int pea_affinity_fwd(const PeaDesc *desc, const void *e, const void *e_other, const float *target,
                      const float *weight, const uint8_t *mask, float *affs, float *g_out, float *loss_out,
                      void *workspace, size_t workspace_bytes, void *stream);
@@ -174,7 +189,7 @@ int pea_affinity_bwd_dual(const PeaDesc *desc, const void *e, const void *ema, c
 /* The same with the 1 / norm planes of the two operands ([B,Z,Y,X] each: the plane pea_affinity_fwd_ex wrote for the self loss,
  * and the SECOND plane of the pair it wrote for the cross loss): 2D, D = 16, f32, axis-aligned stencils then run as ONE launch of
  * the LDS-DMA cross kernel with a second phase (the second operand's one-sided cross, role-A pairs added into the same registers);
- * NULL planes or any other shape: the tiled two-phase kernel of pea_affinity_bwd_dual. */
+ * NULL planes or any other shape: PEA_E_UNSUPPORTED (two pea_affinity_bwd_ex calls and an add). */
 int pea_affinity_bwd_dual_ex(const PeaDesc *desc, const void *e, const void *ema, const float *g, const float *g_cross,
                              const float *inv_norm, const float *inv_norm_other, const float *dloss, const float *dloss_cross,
                              void *de, void *stream);
@@ -230,7 +245,7 @@ int pea_affinity_fwd_bwd_labels(const PeaDesc *desc, const void *e, const void *
 /* The full-resolution pair of the training loop in ONE launch: the self loss (desc) and the detached-EMA cross loss
  * (desc_cross: same geometry and stencil, its own lambda / normaliser) of the same embedding and labels
  * (scripts_cvppp/main.py:288,293): de = dloss * d L_self / d e + dloss_cross * d L_cross / d e; affs (nullable) is the
- * self loss' map; loss_out / loss_cross_out [1 + K] each.  workspace: 2 x pea_workspace_bytes(desc).  Returns
+ * self loss' map; loss_out / loss_cross_out [1 + K] each.  workspace: 2 x pea_workspace_bytes(desc), both states initialised.  Returns
  * PEA_E_UNSUPPORTED when the two launches of pea_affinity_fwd_bwd_labels (the second with PEA_TGT_ACCUMULATE) must be
  * used instead. */
 int pea_affinity_fwd_bwd_labels_dual(const PeaDesc *desc, const PeaDesc *desc_cross, const void *e, const void *ema,
@@ -261,19 +276,6 @@ int pea_head_bwd(int B, int C, int D, size_t S, const float *x, const float *W, 
 int pea_stitch_add(float *out_affs, float *weight_map, const float *affs_vol, const float *weight_vol, int C, int Z, int Y,
                    int X, int oz, int oy, int ox, int z0, int y0, int x0, void *stream);
 int pea_stitch_finalize(float *out_affs, const float *weight_map, int C, size_t voxels, void *stream);
-
-/* ---- f1: the self-loss backward with the embedding head's backward in its epilogue ------------
- * The step before this path is e = W x + b (OutConv, scripts_cvppp/model/unet2d_residual.py:67-74, outconv_emb :307, applied
- * :346); autograd runs its backward (dx = W^T de, dW = sum_p de x^T, db = sum_p de) right after the loss' (main.py:311).  Here
- * both happen in ONE launch: de = dloss * d loss / d e (+ de_add, the gradient reaching the embedding from the other losses of
- * the section, or NULL) never has to leave the chip -- `de` may be NULL.  x [B, C, Y, X], W [D, C], dx [B, C, Y, X] (or NULL),
- * dW [D, C], db [D] (or NULL); e, g, inv_norm as for pea_affinity_bwd_ex (self loss).  Workspace: pea_bwd_head_workspace_bytes
- * (0 = this shape is not covered).  Covered: 2D, D = 16, C = 32, f32, circular border, axis-aligned stencil, X % 4 == 0;
- * everything else returns PEA_E_UNSUPPORTED and the caller runs pea_affinity_bwd_ex + pea_head_bwd. */
-size_t pea_bwd_head_workspace_bytes(const PeaDesc *desc, int C);
-int pea_affinity_bwd_head(const PeaDesc *desc, const void *e, const float *g, const float *inv_norm, const float *dloss,
-                          const float *de_add, const float *x, const float *W, int C, float *dx, float *dW, float *db, void *de,
-                          void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PEA_MAX_K = 32
-ABI = 1
+ABI = 2  # PEA_ABI_VERSION of include/pea.h (the oracle shares the descriptor struct)
 BORDER_CIRCULAR, BORDER_CROP_ZERO, BORDER_REPLICATE = 0, 1, 2
 NORM_BX, NORM_CROPPED, NORM_FULL = 0, 1, 2
 FLAG_RELU = 1

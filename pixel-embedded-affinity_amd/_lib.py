@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.environ.get("PEA_HIP_LIB") or os.path.join(CSRC, "libpea_hip.so")  # PEA_HIP_LIB: debugging override
 HEADER = os.path.join(HERE, "..", "include", "pea.h")
 
-PEA_ABI_VERSION = 1
+PEA_ABI_VERSION = 2
 PEA_MAX_K = 32
 E_UNSUPPORTED = -3
 BORDER_CIRCULAR, BORDER_CROP_ZERO, BORDER_REPLICATE = 0, 1, 2
@@ -23,9 +23,10 @@ NORM_BX, NORM_CROPPED, NORM_FULL = 0, 1, 2
 FLAG_RELU_AFFS, FLAG_ONE_MINUS, FLAG_HALF_SHIFT, FLAG_CLAMP01, FLAG_ACCUMULATE_DE = 1, 2, 4, 8, 16  # activation of the affs output (include/pea.h)
 TGT_PADDING, TGT_BOTH_FOREGROUND, TGT_MASK_INSIDE, TGT_ACCUMULATE = 1, 2, 4, 8
 
-EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_affinity_infer",
-           "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_ex", "pea_affinity_bwd_ex", "pea_inv_norm", "pea_cross_supported", "pea_affinity_bwd_dual", "pea_affinity_bwd_dual_ex", "pea_scale_inplace", "pea_scale_inplace_multi", "pea_fill_border_relu", "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd",
-           "pea_bwd_head_workspace_bytes", "pea_affinity_bwd_head",
+EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_workspace_init", "pea_reload_env",
+           "pea_affinity_infer", "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_ex", "pea_affinity_bwd_ex", "pea_inv_norm",
+           "pea_cross_supported", "pea_affinity_bwd_dual", "pea_affinity_bwd_dual_ex", "pea_scale_inplace", "pea_scale_inplace_multi",
+           "pea_fill_border_relu", "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd",
            "pea_targets_workspace_bytes", "pea_gen_targets", "pea_stitch_add", "pea_stitch_finalize",
            "pea_label_weights", "pea_affinity_fwd_bwd_labels", "pea_affinity_fwd_bwd_labels_dual")
 
@@ -45,19 +46,58 @@ class PeaDesc(ctypes.Structure):
                 ("mask_bstride", ctypes.c_int64)]
 
 
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
+OBJ_DIR = os.path.join(CSRC, "build")
 
 
-def build(force=False, verbose=False):
-    """Compile csrc/pea_hip.hip -> csrc/libpea_hip.so for gfx950."""
-    src = os.path.join(CSRC, "pea_hip.hip")
-    deps = [src, HEADER] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
+def sources():
+    """the translation units of the library (csrc/pea_host.h lists what each holds)"""
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def build(force=False, verbose=False, jobs=None):
+    """Compile csrc/*.hip -> csrc/libpea_hip.so for gfx950: one object per file, compiled in parallel, one link."""
+    srcs = sources()
+    hdrs = [HEADER] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
+    if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= max([newest_hdr] + [os.path.getmtime(x) for x in srcs]):
         return SO_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise PeaLibraryError("hipcc not found: cannot build libpea_hip.so")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO_PATH + ".tmp", src]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs, todo = [], []
+    for src in srcs:
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(newest_hdr, os.path.getmtime(src)):
+            todo.append((src, obj))
+    jobs = jobs or min(len(todo) or 1, max(1, (os.cpu_count() or 2) - 1))
+    running = []
+
+    def reap(block_until):
+        while len(running) > block_until:
+            for i, (p, src, obj) in enumerate(running):
+                if p.poll() is not None:
+                    running.pop(i)
+                    if p.returncode != 0:
+                        for q, _, _ in running:
+                            q.kill()
+                        raise PeaLibraryError("hipcc failed on %s (rc %d)" % (src, p.returncode))
+                    os.replace(obj + ".tmp", obj)
+                    break
+            else:
+                import time
+                time.sleep(0.05)
+
+    for src, obj in todo:
+        cmd = [hipcc] + HIPCC_FLAGS + ["-c", "-o", obj + ".tmp", src]
+        if verbose:
+            print(" ".join(cmd))
+        running.append((subprocess.Popen(cmd, cwd=CSRC), src, obj))
+        reap(jobs - 1)
+    reap(0)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_PATH + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
@@ -93,6 +133,10 @@ def lib():
     L.pea_desc_validate.argtypes = [dp]
     L.pea_workspace_bytes.restype = ctypes.c_size_t
     L.pea_workspace_bytes.argtypes = [dp]
+    L.pea_workspace_init.restype = ctypes.c_int
+    L.pea_workspace_init.argtypes = [vp, ctypes.c_size_t, vp]
+    L.pea_reload_env.restype = None
+    L.pea_reload_env.argtypes = []
     L.pea_affinity_infer.restype = ctypes.c_int
     L.pea_affinity_infer.argtypes = [dp, vp, vp, vp, vp]
     L.pea_affinity_fwd.restype = ctypes.c_int
@@ -135,16 +179,32 @@ def lib():
     L.pea_head_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     L.pea_head_fwd.restype = ctypes.c_int
     L.pea_head_fwd.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, vp, vp, vp, vp, vp]
-    L.pea_bwd_head_workspace_bytes.restype = ctypes.c_size_t
-    L.pea_bwd_head_workspace_bytes.argtypes = [dp, ctypes.c_int]
-    L.pea_affinity_bwd_head.restype = ctypes.c_int
-    L.pea_affinity_bwd_head.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.pea_head_bwd.restype = ctypes.c_int
     L.pea_head_bwd.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     if L.pea_version() != PEA_ABI_VERSION:
         raise PeaLibraryError("ABI mismatch: library %d, binding %d" % (L.pea_version(), PEA_ABI_VERSION))
     _lib = L
     return L
+
+
+_RELOAD_HOOKS = []
+
+
+def reload_env():
+    """make the loaded library re-read the PEA_* switches (it reads them once) and drop what the Python layer remembered of them"""
+    if _lib is not None:
+        _lib.pea_reload_env()
+    for hook in _RELOAD_HOOKS:
+        hook()
+
+
+def set_switch(name, value):
+    """set (value) or clear (None) a PEA_* environment switch, then reload_env()"""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    reload_env()
 
 
 def check(rc, what):

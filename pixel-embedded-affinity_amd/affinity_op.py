@@ -114,6 +114,9 @@ def cross_supported(d, mode):
     return r
 
 
+_lib._RELOAD_HOOKS.append(_CROSS_OK.clear)  # pea_cross_supported depends on the PEA_* switches
+
+
 def _build_desc(spec, e, tstride, wstride, mstride):
     dims = _spatial(e, spec.ndim)
     d = PeaDesc()
@@ -149,6 +152,29 @@ def _stream():
     if _RAW_STREAM is not None:
         return ctypes.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_WS = {}
+_STATE_BYTES = [0]
+
+
+def workspace(dev, desc, nstates=1):
+    """(tensor, bytes): the loss-state block(s) of the training forward for the CURRENT stream of `dev` (include/pea.h,
+    pea_workspace_bytes): allocated and initialised once per (device, stream), then reused by every call -- each call leaves it
+    ready for the next one, and calls on one stream cannot overlap.  ~16 KB per state."""
+    L = _lib.lib()
+    if not _STATE_BYTES[0]:
+        _STATE_BYTES[0] = int(L.pea_workspace_bytes(ctypes.byref(desc)))
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    raw = _RAW_STREAM(idx) if _RAW_STREAM is not None else torch.cuda.current_stream(dev).cuda_stream
+    key = (idx, raw, nstates)
+    w = _WS.get(key)
+    nb = _STATE_BYTES[0] * nstates
+    if w is None:
+        w = torch.empty(nb // 4, dtype=torch.float32, device=dev)
+        _lib.check(L.pea_workspace_init(ctypes.c_void_p(w.data_ptr()), nb, ctypes.c_void_p(raw)), "pea_workspace_init")
+        _WS[key] = w
+    return w, nb
 
 
 class _on_device(object):
@@ -221,8 +247,7 @@ class FusedAffinityMSE(torch.autograd.Function):
             L = _lib.lib()
             affs = torch.empty(kshape, dtype=torch.float32, device=e_c.device)
             loss_vec = torch.empty(1 + spec.K, dtype=torch.float32, device=e_c.device)
-            wsb = L.pea_workspace_bytes(ctypes.byref(d))
-            work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=e_c.device)
+            work, wsb = workspace(e_c.device, d)
             # g = d loss / d affs is all the backward needs besides the embeddings; skip it when nothing trains
             g = torch.empty(kshape, dtype=torch.float32, device=e_c.device) if (want_e or want_o) else None
             # 1 / norm of e, 4 bytes per pixel: what the cross backward (self loss, axis-aligned stencil) stages next to e;
@@ -230,7 +255,7 @@ class FusedAffinityMSE(torch.autograd.Function):
             inv = None
             if want_e and o_c is None and cross_supported(d, 1):
                 inv = torch.empty((e_c.shape[0],) + tuple(e_c.shape[2:]), dtype=torch.float32, device=e_c.device)
-            elif want_e and not want_o and cross_supported(d, 2):
+            elif want_e and o_c is not None and not want_o and cross_supported(d, 2):
                 inv = torch.empty((2, e_c.shape[0]) + tuple(e_c.shape[2:]), dtype=torch.float32, device=e_c.device)
             _lib.check(L.pea_affinity_fwd_ex(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(target), _ptr(weight), _ptr(mask),
                                              _ptr(affs), _ptr(g), _ptr(inv), _ptr(loss_vec), _ptr(work), wsb, _stream()),
@@ -259,6 +284,20 @@ class FusedAffinityMSE(torch.autograd.Function):
             _lib.check(L.pea_affinity_bwd_ex(ctypes.byref(ctx.desc), _ptr(e_c), _ptr(o_c), _ptr(g), _ptr(inv), _ptr(dl), _ptr(de),
                                              _ptr(de_o), _stream()), "pea_affinity_bwd_ex")
         return de, de_o, None, None, None, None
+
+
+_ONES = {}
+
+
+def backward(loss, **kw):
+    """loss.backward() (scripts_cvppp/main.py:311) without its per-step fill kernel: autograd seeds the backward of a scalar with
+    torch.ones_like(loss) -- a launch-bound 5 us kernel plus a kernel boundary between the loss forward and its backward, 3 % of a
+    215 us step.  The seed is a constant: one cached ones-scalar per device is handed to backward() instead."""
+    key = (loss.device, loss.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    loss.backward(one, **kw)
 
 
 class AffinityMap(torch.autograd.Function):
@@ -411,8 +450,7 @@ class LabelsAffinityMSE(torch.autograd.Function):
             cb = L.pea_targets_workspace_bytes(ctypes.byref(d))
             counts = torch.empty(max(cb, 4) // 4, dtype=torch.int32, device=e_c.device)
             _lib.check(L.pea_label_weights(ctypes.byref(d), _ptr(lab), flags, _ptr(wtab), _ptr(counts), cb, _stream()), "pea_label_weights")
-            wsb = L.pea_workspace_bytes(ctypes.byref(d))
-            work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=e_c.device)
+            work, wsb = workspace(e_c.device, d)
             de_unit = torch.empty_like(e_c)
             rc = L.pea_affinity_fwd_bwd_labels(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(lab), _ptr(wtab), flags, _ptr(affs) if need_affs else None,
                                                _ptr(loss_vec), None, _ptr(de_unit), _ptr(work), wsb, _stream())

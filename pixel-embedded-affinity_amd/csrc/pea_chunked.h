@@ -61,7 +61,7 @@ __global__ __launch_bounds__(TH* TW, (DC > 16 ? 2 : 4)) void k_fwd_tiled_chunked
                                                                  const T* __restrict__ eo, const float* __restrict__ target,
                                                                  const float* __restrict__ weight,
                                                                  const uint8_t* __restrict__ mask, float* __restrict__ affs,
-                                                                 float* __restrict__ gout, float* __restrict__ partials) {
+                                                                 float* __restrict__ gout, LossState* __restrict__ st) {
   typedef Lds<DC, PLQ> L;
   static_assert(D_T % DC == 0, "whole chunks");
   constexpr int NT = TH * TW, NW = NT / 64, NCH = D_T / DC, MAXR = (PLQ + NT - 1) / NT;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(TH* TW, (DC > 16 ? 2 : 4)) void k_fwd_tiled_chunked
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += s_part[w * P.K + threadIdx.x];
-      partials[(size_t)threadIdx.x * Q.ntiles + tile] = v;
+      loss_accumulate(st, tile, threadIdx.x, v);
     }
   }
 }

@@ -1,100 +1,12 @@
-// pea_direct.h -- common device helpers + the direct (global-memory) kernels.  Included by pea_hip.hip only.
+// pea_direct.h -- the direct (global-memory) kernels.
 //
 // The direct kernels are the general fallback (any D in the forward, any offsets that no LDS tile can
 // hold): one lane = one pixel, D-loop in registers, every neighbour vector read from global memory
 // (coalesced row reads; the L2 norm of the neighbour is accumulated while its channels stream in).
 #pragma once
-#include <hip/hip_fp16.h>
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include "../../include/pea.h"
+#include "pea_loss.h"
 
 namespace pea {
-
-constexpr int kBlock = 256;  // 4 waves of 64
-constexpr int kXcd = 8;
-
-struct KParams {
-  int B, D, Z, Y, X, K;
-  int S;  // Z*Y*X (fits int32: checked on the host)
-  int border;
-  unsigned flags;
-  float eps;
-  int chunks;          // workgroups per batch item = ceil(S / kBlock)
-  int tiles;           // B * chunks
-  int tiles_per_xcd;   // ceil(tiles / 8)
-  int off[PEA_MAX_K][3];
-  float lam[PEA_MAX_K];
-  float inv_n[PEA_MAX_K];   // 1 / N_i
-  float gscale[PEA_MAX_K];  // 2 * lambda_i / N_i
-  long long tbs, wbs, mbs;  // batch strides (elements) of target / weight / mask
-  int ksplit;               // offset channels >= ksplit are addressed through a second buffer resource based ksplit planes further:
-                            // K (no split) unless the [K, Z, Y, X] block of a batch item reaches 2 GiB (the raw-buffer range check
-                            // counts the scalar plane offset: pea_hip.hip plan_tiles); only k_fwd_tiled / k_bwd_tiled honour it
-};
-
-template <typename T>
-__device__ __forceinline__ float ld(const T* p, size_t i);
-template <>
-__device__ __forceinline__ float ld<float>(const float* p, size_t i) { return p[i]; }
-template <>
-__device__ __forceinline__ float ld<__half>(const __half* p, size_t i) { return __half2float(p[i]); }
-
-__device__ __forceinline__ void st(float* p, size_t i, float v) { p[i] = v; }
-__device__ __forceinline__ void st(__half* p, size_t i, float v) { p[i] = __float2half(v); }
-
-// XCD-aware remap: hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
-// id % 8 labels the XCD group.  Give group g the contiguous logical tiles [g*tpx, (g+1)*tpx).
-__device__ __forceinline__ int logical_tile(const KParams& P) {
-  const int bid = blockIdx.x;
-  return (bid % kXcd) * P.tiles_per_xcd + bid / kXcd;
-}
-
-// REPLICATE, role B: the coordinates c' along one axis (extent n) with clamp(c' + o) == c, as [lo, hi] (empty: lo > hi).
-// Interior c has the one pre-image c - o; a border coordinate collects every c' that the clamp folds onto it.
-__device__ __forceinline__ void clamp_preimage(int c, int o, int n, int& lo, int& hi) {
-  lo = hi = c - o;
-  if (o < 0 && c == 0) { lo = 0; hi = min(-o, n - 1); }
-  else if (o > 0 && c == n - 1) { lo = max(n - 1 - o, 0); hi = n - 1; }
-  else if (lo < 0 || lo > n - 1) { lo = 1; hi = 0; }
-}
-
-// neighbour of (z,y,x) displaced by o; returns flat index or -1 (CROP_ZERO, outside)
-__device__ __forceinline__ int neighbour(const KParams& P, int z, int y, int x, int oz, int oy, int ox) {
-  int zz = z + oz, yy = y + oy, xx = x + ox;
-  if (P.border == PEA_BORDER_CIRCULAR) {  // host guarantees |o| < dim
-    zz += (zz < 0) ? P.Z : 0; zz -= (zz >= P.Z) ? P.Z : 0;
-    yy += (yy < 0) ? P.Y : 0; yy -= (yy >= P.Y) ? P.Y : 0;
-    xx += (xx < 0) ? P.X : 0; xx -= (xx >= P.X) ? P.X : 0;
-  } else if (P.border == PEA_BORDER_REPLICATE) {  // index clamped into the volume: every pair exists
-    zz = min(max(zz, 0), P.Z - 1);
-    yy = min(max(yy, 0), P.Y - 1);
-    xx = min(max(xx, 0), P.X - 1);
-  } else if ((unsigned)zz >= (unsigned)P.Z || (unsigned)yy >= (unsigned)P.Y || (unsigned)xx >= (unsigned)P.X) {
-    return -1;
-  }
-  return (zz * P.Y + yy) * P.X + xx;
-}
-
-// activation of the affs output (include/pea.h PEA_FLAG_*): flags are wave-uniform, the common case (0) is one scalar branch
-constexpr unsigned kActMask = PEA_FLAG_RELU_AFFS | PEA_FLAG_ONE_MINUS | PEA_FLAG_HALF_SHIFT | PEA_FLAG_CLAMP01;
-__device__ __forceinline__ float act_affs(float a, unsigned af) {
-  if (af == 0) return a;
-  if (af & PEA_FLAG_HALF_SHIFT) a = (a + 1.0f) * 0.5f;
-  if (af & PEA_FLAG_RELU_AFFS) a = fmaxf(a, 0.f);
-  if (af & PEA_FLAG_CLAMP01) a = fminf(fmaxf(a, 0.f), 1.0f);
-  if (af & PEA_FLAG_ONE_MINUS) a = 1.0f - a;
-  return a;
-}
-
-__device__ __forceinline__ float inv_norm(float ss, float eps) { return 1.0f / fmaxf(sqrtf(ss), eps); }
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
-}
 
 // ------------------------------------------------------------------------------------------------
 // forward (direct form): affs, (TRAIN) per-workgroup loss partials and g = d loss / d affs
@@ -107,7 +19,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd_direct(const KParams P, const T*
                                                        const float* __restrict__ weight,
                                                        const uint8_t* __restrict__ mask,
                                                        float* __restrict__ affs, float* __restrict__ gout,
-                                                       float* __restrict__ partials) {
+                                                       LossState* __restrict__ st) {
   extern __shared__ float s_acc[];  // [K][kBlock], TRAIN only
   const int tile = logical_tile(P);
   if (tile >= P.tiles) return;  // whole workgroup exits together (tile is uniform)
@@ -192,89 +104,8 @@ __global__ __launch_bounds__(kBlock) void k_fwd_direct(const KParams P, const T*
       const float* row = s_acc + i * kBlock;
       float v = (row[lane] + row[lane + 64]) + (row[lane + 128] + row[lane + 192]);
       v = wave_sum(v);
-      if (lane == 0) partials[(size_t)i * P.tiles + tile] = v;  // [K][nparts]: coalesced for the finalize
+      if (lane == 0) loss_accumulate(st, tile, i, v);
     }
-  }
-}
-
-// fixed-order f64 reduction of the per-workgroup partials ([K][nparts]): loss_out = {loss, L_0..L_{K-1}}.
-// One wave per offset (16 waves work on 16 offsets at once); inside a wave every lane sums a strided slice with
-// four independent accumulators (the loads of a row are independent, so they pipeline), then a fixed wave tree.
-// Nothing depends on timing, so the result is bit-reproducible.
-__global__ __launch_bounds__(1024) void k_loss_finalize(const KParams P, const float* __restrict__ partials,
-                                                        int nparts, float* __restrict__ loss_out) {
-  __shared__ double s_l[PEA_MAX_K];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int i = wave; i < P.K; i += 16) {
-    const float* row = partials + (size_t)i * nparts;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int t = lane;
-    for (; t + 192 < nparts; t += 256) {
-      a0 += (double)row[t];
-      a1 += (double)row[t + 64];
-      a2 += (double)row[t + 128];
-      a3 += (double)row[t + 192];
-    }
-    for (; t < nparts; t += 64) a0 += (double)row[t];
-    double acc = (a0 + a1) + (a2 + a3);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if (lane == 0) {
-      const double Li = acc * (double)P.inv_n[i];
-      s_l[i] = Li;
-      loss_out[1 + i] = (float)Li;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot = 0.0;
-    for (int i = 0; i < P.K; ++i) tot += (double)P.lam[i] * s_l[i];
-    loss_out[0] = (float)tot;
-  }
-}
-
-// Large partial tables (the 3D sub-volumes: 49152 tiles x 12 offsets took one workgroup 100 us): two levels.  Level 1: workgroup
-// (slice, offset) sums a contiguous slice of the offset's row in double, fixed pattern; level 2: k_loss_finalize2 adds the kFinSlices
-// slice sums of every offset in a fixed tree.  Still nothing depends on timing.
-constexpr int kFinSlices = 32;
-__global__ __launch_bounds__(256) void k_loss_slices(const float* __restrict__ partials, int nparts, double* __restrict__ slices) {
-  __shared__ double red[4];
-  const int i = blockIdx.y, sl = blockIdx.x;
-  const int per = (nparts + kFinSlices - 1) / kFinSlices;
-  const int lo = sl * per, hi = min(nparts, lo + per);
-  const float* row = partials + (size_t)i * nparts;
-  double a0 = 0.0, a1 = 0.0;
-  int t = lo + (int)threadIdx.x;
-  for (; t + 256 < hi; t += 512) {
-    a0 += (double)row[t];
-    a1 += (double)row[t + 256];
-  }
-  for (; t < hi; t += 256) a0 += (double)row[t];
-  double acc = a0 + a1;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) slices[i * kFinSlices + sl] = (red[0] + red[1]) + (red[2] + red[3]);
-}
-__global__ __launch_bounds__(1024) void k_loss_finalize2(const KParams P, const double* __restrict__ slices, float* __restrict__ loss_out) {
-  __shared__ double s_l[PEA_MAX_K];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int i = wave; i < P.K; i += 16) {
-    double acc = lane < kFinSlices ? slices[i * kFinSlices + lane] : 0.0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if (lane == 0) {
-      const double Li = acc * (double)P.inv_n[i];
-      s_l[i] = Li;
-      loss_out[1 + i] = (float)Li;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot = 0.0;
-    for (int i = 0; i < P.K; ++i) tot += (double)P.lam[i] * s_l[i];
-    loss_out[0] = (float)tot;
   }
 }
 

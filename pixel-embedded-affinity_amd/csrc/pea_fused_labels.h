@@ -26,7 +26,7 @@ template <typename T, int D_T, int TH, int TW, int PLQ, bool CROP, bool ROLE_B>
 __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fused_labels(const KParams P, const TParams Q, const T* __restrict__ xt,
                                                             const T* __restrict__ nbt, const int32_t* __restrict__ labels,
                                                             const float* __restrict__ wtab, unsigned lflags,
-                                                            float* __restrict__ affs, float* __restrict__ partials,
+                                                            float* __restrict__ affs, LossState* __restrict__ st,
                                                             const float* __restrict__ dloss, T* __restrict__ dx) {
   typedef Lds<D_T, PLQ> L;
   constexpr int NT = TH * TW, NW = NT / 64;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fused_labels(con
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) v += s_part[w * P.K + threadIdx.x];
-    partials[(size_t)threadIdx.x * Q.ntiles + tile] = v;
+    loss_accumulate(st, tile, threadIdx.x, v);
   }
 }
 
@@ -255,7 +255,7 @@ template <typename T, int D_T, int TH, int TW, int PLQ, bool CROP>
 __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fused_labels_dual(
     const KParams P, const TParams Q, const TParams Q2, const CrossPar C2, const T* __restrict__ xt, const T* __restrict__ emat,
     const int32_t* __restrict__ labels, const float* __restrict__ wtab, unsigned lflags, float* __restrict__ affs,
-    float* __restrict__ partials, float* __restrict__ partials2, const float* __restrict__ dloss,
+    LossState* __restrict__ st, LossState* __restrict__ st2, const float* __restrict__ dloss,
     const float* __restrict__ dloss2, T* __restrict__ dx) {
   constexpr bool ROLE_B = true;
   const T* nbt = xt;
@@ -560,8 +560,8 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fused_labels_dua
       v += s_part[w * P.K + threadIdx.x];
       v2 += s_part2[w * P.K + threadIdx.x];
     }
-    partials[(size_t)threadIdx.x * Q.ntiles + tile] = v;
-    partials2[(size_t)threadIdx.x * Q.ntiles + tile] = v2;
+    loss_accumulate(st, tile, threadIdx.x, v);
+    loss_accumulate(st2, tile, threadIdx.x, v2);
   }
 }
 
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fused_labels_dua
 // (workgroup, channel) in the workspace, summed in a fixed order by k_weight_table: no global atomics, no memset (one
 // atomic per 256 pixels and channel onto B*K addresses cost 90 us at the bench shape).
 constexpr int kCntRows = 8;
-__global__ __launch_bounds__(256) void k_label_counts(const GParams G, const int32_t* __restrict__ labels,
+static __global__ __launch_bounds__(256) void k_label_counts(const GParams G, const int32_t* __restrict__ labels,
                                                       unsigned* __restrict__ counts) {
   __shared__ unsigned s_cnt[PEA_MAX_K];
   constexpr int NIT = kCntRows, CH = 4;  // CH * NIT independent neighbour loads in flight per lane
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void k_label_counts(const GParams G, const int
 }
 
 // one wave per (image, channel): fixed-order integer sum of the workgroup partials, then the two weights
-__global__ __launch_bounds__(64) void k_weight_table(int S, int per_img, const unsigned* __restrict__ parts, float* __restrict__ wtab) {
+static __global__ __launch_bounds__(64) void k_weight_table(int S, int per_img, const unsigned* __restrict__ parts, float* __restrict__ wtab) {
   const int i = blockIdx.x;
   unsigned c = 0;
   for (int k = threadIdx.x; k < per_img; k += 64) c += parts[(size_t)i * per_img + k];

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kHeadBlock, (C <= 48 && D == 16) ? 4 : (C <= 128 ? 
 // the partials of workgroups g, g + 16, g + 32, ... (64-byte coalesced reads, nwg / 16 loads per thread instead of nwg:
 // a thread per output walking all 1024 partials took 75 us, longer than the kernel that produced them), then the 16
 // group sums are added in group order.
-__global__ __launch_bounds__(256) void k_head_finalize(const float* __restrict__ partials, int nwg, int dc, int n,
+static __global__ __launch_bounds__(256) void k_head_finalize(const float* __restrict__ partials, int nwg, int dc, int n,
                                                        float* __restrict__ dW, float* __restrict__ db) {
   __shared__ float red[16][17];
   const int o = threadIdx.x & 15, g = threadIdx.x >> 4;

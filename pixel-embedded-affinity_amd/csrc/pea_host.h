@@ -1,0 +1,134 @@
+// pea_host.h -- host-side glue shared by the translation units of libpea_hip.so.
+//
+// The library is built from several .hip files compiled in parallel (one per kernel family; a single file took 1 m 47 s):
+//   pea_abi.hip        the extern "C" entry points of include/pea.h: validation, descriptor -> KParams, dispatch
+//   pea_k_xdma.hip     LDS-DMA cross kernels (pea_xdma.h): the training forward / backward of axis-aligned stencils
+//   pea_k_tiled.hip    LDS-tiled box kernels (pea_tiled.h, pea_chunked.h): diagonal stencils, f16 storage, inference
+//   pea_k_labels.hip   the labels-in training step (pea_fused_labels.h) and the label-weight tables
+//   pea_k_direct.hip   global-memory kernels (pea_direct.h): the general fallback; loss finish; caller epilogues, stitcher
+//   pea_k_head.hip     the embedding head (pea_head.h) and target generation (pea_targets.h)
+// Each kernel file exports a few plain functions (declared here) that pick the instantiation and launch it; a function returns
+// false when its family has no kernel for the descriptor and the caller tries the next one.  No device code crosses a file.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include "pea_loss.h"
+
+namespace pea {
+
+// ---- process-wide switches (debugging / A-B runs), read ONCE: getenv on every launch showed up in the host profile ------------
+struct Env {
+  int force_direct;   // PEA_FORCE_DIRECT=1: global-memory kernels only
+  int fwd_xdma;       // PEA_FWD_XDMA=0: no LDS-DMA forward
+  int bwd_xdma;       // PEA_BWD_XDMA=0: no LDS-DMA backward
+  int labels_dual;    // PEA_LABELS_DUAL=0: pea_affinity_fwd_bwd_labels_dual reports PEA_E_UNSUPPORTED
+  int loss_ticket;    // PEA_LOSS_TICKET=1: finish the loss inside the cross forward (last-ticket workgroup) instead of by a second,
+                      // tiny launch.  Off by default: measured equal in the step (114.8 us either way) and 3x SLOWER under
+                      // rocprofv3 (331 us: 4624 returning atomics on one word while the profiler serialises dispatches)
+  int fwd_wg3;        // PEA_FWD_WG3=0: the 2-workgroups-per-CU forward
+};
+const Env& env();
+void env_reload();  // pea_reload_env(): tests that change a switch call it
+
+inline bool misaligned(const void* p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
+int& g_pending_error();  // per thread: an error met while preparing a launch (allow_lds), reported by the next hip_rc()
+inline int hip_rc() {
+  int& pe = g_pending_error();
+  if (pe) {
+    const int r = pe;
+    pe = 0;
+    (void)hipGetLastError();
+    return r;
+  }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PEA_OK : (int)e;
+}
+int device_cus();
+
+// Raise a kernel's dynamic-LDS limit above the 64 KB default.  The attribute is per device and the call is a host-side table
+// update, so it is made once per (kernel, device) and remembered; a failure is returned (a launch that needs more LDS than it
+// was granted would otherwise fail with an opaque error).  Returns hipSuccess (0) or the hipError_t.
+int allow_lds_impl(const void* kernel, size_t bytes);
+template <auto KERNEL>
+inline int allow_lds(size_t bytes) {
+  return bytes > 64 * 1024 ? allow_lds_impl((const void*)KERNEL, bytes) : 0;
+}
+
+// A small per-thread memo of host-side plans, keyed by the kernel parameters (the deep-supervision launches are latency-bound:
+// planning per launch was measurable).  PLAN must be trivially copyable.
+template <typename PLAN, int N = 8>
+struct PlanCache {
+  struct Ent { KParams key; int mode; bool ok, used; PLAN plan; };
+  Ent ent[N] = {};
+  int next = 0;
+  template <typename F>
+  bool get(const KParams& P, int mode, PLAN* out, F&& make) {
+    for (int i = 0; i < N; ++i)
+      if (ent[i].used && ent[i].mode == mode && memcmp(&ent[i].key, &P, sizeof(KParams)) == 0) {
+        if (ent[i].ok) *out = ent[i].plan;
+        return ent[i].ok;
+      }
+    Ent& e = ent[next];
+    next = (next + 1) % N;
+    memset(&e.key, 0, sizeof(KParams));
+    e.key = P; e.mode = mode; e.used = true;
+    e.ok = make(&e.plan);
+    if (e.ok) *out = e.plan;
+    return e.ok;
+  }
+};
+
+// ---- loss finish (pea_k_direct.hip) -----------------------------------------------------------------------------------------
+void launch_loss_finish(const KParams& P, LossState* st, float* loss_out, hipStream_t s);
+void launch_loss_state_init(LossState* st, int n, hipStream_t s);
+
+// Arguments of a forward launch, one struct for every family.
+struct FwdArgs {
+  const void* e;        // [B, D, S]  f32 / f16 (dtype)
+  const void* eo;       // second operand or == e
+  const float* t;       // training only
+  const float* w;
+  const uint8_t* m;     // nullable
+  float* affs;          // nullable
+  float* gout;          // nullable
+  LossState* st;        // training only
+  float* loss_out;      // training only: [1 + K]
+  float* inv_out;       // nullable: signed 1 / norm plane(s)
+  int dtype;            // PEA_F32 / PEA_F16
+  bool train;
+};
+// Each returns true if it launched.  `finished`: the kernel finishes the loss itself (no launch_loss_finish needed).
+bool xdma_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s, bool* finished);
+bool xdma_fwd_other(const KParams& P, const FwdArgs& A, hipStream_t s, bool* finished);   // inv_out: two planes
+bool tiled_fwd(const KParams& P, const FwdArgs& A, hipStream_t s, bool* wrote_inv);      // k_fwd_tiled_v / k_fwd_tiled / chunked
+void direct_fwd(const KParams& P, const FwdArgs& A, hipStream_t s);
+void launch_inv_norm(const KParams& P, int dtype, const void* e, float* inv, hipStream_t s);
+int xdma_cross_supported(const KParams& P, int dtype, int mode);
+
+// backward: roles bit 0 = A (x is the first operand, neighbours nbA), bit 1 = B (x is the second operand, neighbours nbB)
+bool xdma_bwd_self(const KParams& P, const float* x, const float* inv, const float* g, const float* dl, float* dx, hipStream_t s);
+bool xdma_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* dl,
+                    float* de, bool accumulate, hipStream_t s);
+bool xdma_bwd_dual(const KParams& P, const float* e, const float* ema, const float* inv, const float* inv_other, const float* g,
+                   const float* g_cross, const float* dl, const float* dl_cross, float* de, hipStream_t s);
+bool tiled_bwd(const KParams& P, int dtype, int roles, const void* x, const void* nbA, const void* nbB, const float* g,
+               const float* dl, void* dx, hipStream_t s);
+int direct_bwd(const KParams& P, int dtype, int roles, const void* x, const void* nbA, const void* nbB, const float* g,
+               const float* dl, void* dx, hipStream_t s);   // PEA_OK / PEA_E_UNSUPPORTED / hip error
+
+// labels-in step (pea_k_labels.hip)
+bool labels_step(const KParams& P, int dtype, const void* e, const void* e_other, const int32_t* labels, const float* wtab,
+                 unsigned lflags, float* affs, LossState* st, const float* dl, void* de, hipStream_t s);
+bool labels_step_dual(const KParams& P, const KParams& P2, int dtype, const void* e, const void* ema, const int32_t* labels,
+                      const float* wtab, unsigned lflags, float* affs, LossState* st, LossState* st2, const float* dl,
+                      const float* dl2, void* de, hipStream_t s);
+size_t label_counts_bytes(const PeaDesc* d);
+int label_weights(const PeaDesc* d, const int32_t* labels, unsigned flags, float* wtab, void* ws, hipStream_t s);
+int gen_targets(const PeaDesc* d, const int32_t* labels, unsigned flags, float* target, uint8_t* mask, float* weight, void* ws,
+                size_t need, hipStream_t s);
+
+// caller epilogues, stitcher, rescale (pea_k_direct.hip); head and target generation (pea_k_head.hip): the ABI functions
+// themselves live in those files (they need no descriptor logic)
+
+}  // namespace pea

@@ -1,0 +1,208 @@
+// pea_k_xdma.hip -- launchers of the LDS-DMA cross kernels (pea_xdma.h): plan, pick the instantiation, launch.
+// One translation unit of libpea_hip.so (pea_host.h).
+#include "pea_host.h"
+#include "pea_xdma.h"
+
+namespace pea {
+
+namespace {
+
+constexpr int kXdmaTH = 16, kXdmaTW = 32;
+constexpr int kXdmaPSU = 51;   // 13 KB planes: the backward's two-sided +-27 cross; 6 planes = 78 KB, two workgroups per CU
+constexpr int kXdmaPSU3 = 52;  // 3D instantiations: whole 64-quad blocks
+constexpr int kXdmaPSUF = 30;  // the forward's one-sided cross (27 rows up, one strip): 7.5 KB planes, 45 KB, THREE workgroups per CU
+
+struct XPlan { XParams C; size_t lds; };
+
+// memoised plan_xdma (per thread; keyed by KParams, the plane size and the mode)
+bool plan(const KParams& P, int psu, int mode, XPlan* out) {
+  static thread_local PlanCache<XPlan, 12> cache;
+  return cache.get(P, psu * 4 + mode, out, [&](XPlan* p) { return plan_xdma(P, kXdmaTH, kXdmaTW, psu, &p->C, &p->lds, mode); });
+}
+
+#define PEA_LAUNCH(kern, grid, blk, lds, s, ...)              \
+  {                                                           \
+    if (allow_lds<kern>(lds)) return false;                   \
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, __VA_ARGS__); \
+  }
+
+template <int D_T, bool TRAIN>
+bool fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s, bool* finished) {
+  const float *e = (const float*)A.e, *t = A.t, *w = A.w;
+  if (misaligned(e, 16) || misaligned(t, 16) || misaligned(w, 16) || misaligned(A.affs, 16) || misaligned(A.gout, 16) ||
+      misaligned(A.m, 4) || misaligned(A.inv_out, 4))
+    return false;
+  if (TRAIN && ((P.tbs | P.wbs | P.mbs) & 3)) return false;
+  XPlan X;
+  bool z3 = false, wg3 = false;
+  if (env().fwd_wg3 && plan(P, kXdmaPSUF, 1, &X) && X.C.nfz == 0) {
+    wg3 = true;
+  } else if (!plan(P, kXdmaPSU, 1, &X) || X.C.nfz > 0) {
+    if (D_T != 16 || !plan(P, kXdmaPSU3, 1, &X) || X.C.nfz == 0) return false;
+    z3 = true;
+  }
+  if (!z3 && P.K > kXP) return false;
+  if (z3 && P.K > kXP + 2) return false;
+  const XParams& C = X.C;
+  const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  float* fin = (TRAIN && env().loss_ticket) ? A.loss_out : nullptr;
+  *finished = fin != nullptr;
+#define PEA_XF(CROP_, PSU_, ZF_, WPE_)                                                                                      \
+  {                                                                                                                         \
+    constexpr auto kern = k_fwd_xdma<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, TRAIN, ZF_, false, WPE_>;                          \
+    PEA_LAUNCH(kern, grid, blk, X.lds, s, P, C, e, t, w, A.m, A.affs, A.gout, A.st, fin, A.inv_out, (const float*)nullptr,  \
+               (float*)nullptr)                                                                                             \
+  }
+  const bool crop = P.border != PEA_BORDER_CIRCULAR;
+  if constexpr (D_T == 16) {
+    if (z3) {
+      if (crop) PEA_XF(true, kXdmaPSU3, kXZ / 2, 4) else PEA_XF(false, kXdmaPSU3, kXZ / 2, 4)
+      return true;
+    }
+  }
+  if (wg3) {
+    if (crop) PEA_XF(true, kXdmaPSUF, 0, 6) else PEA_XF(false, kXdmaPSUF, 0, 6)
+  } else {
+    if (crop) PEA_XF(true, kXdmaPSU, 0, 4) else PEA_XF(false, kXdmaPSU, 0, 4)
+  }
+#undef PEA_XF
+  return true;
+}
+
+template <int D_T>
+bool bwd_self(const KParams& P, const float* x, const float* inv, const float* g, const float* dl, float* dx, hipStream_t s) {
+  if (misaligned(x, 16) || misaligned(inv, 16) || misaligned(g, 4) || misaligned(dx, 4)) return false;
+  XPlan X;
+  bool z3 = false;
+  if (!plan(P, kXdmaPSU, 0, &X)) {
+    if (D_T != 16 || !plan(P, kXdmaPSU3, 0, &X) || X.C.npz == 0) return false;
+    z3 = true;
+  } else if (X.C.npz > 0) {
+    if (D_T != 16 || !plan(P, kXdmaPSU3, 0, &X)) return false;
+    z3 = true;
+  }
+  const XParams& C = X.C;
+  constexpr int XP = D_T > 32 ? 8 : kXP;  // pairs per axis the instantiation keeps in registers
+  if (C.npx > (z3 ? 8 : XP) || C.npy > (z3 ? 8 : XP)) return false;
+  const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+#define PEA_XB(CROP_, XP_, PSU_, ZP_)                                                             \
+  {                                                                                               \
+    constexpr auto kern = k_bwd_xdma<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, XP_, kAuxNT, ZP_>;       \
+    PEA_LAUNCH(kern, grid, blk, X.lds, s, P, C, x, inv, g, dl, dx, OtherArgs{}, DualArgs{})       \
+  }
+  const bool crop = P.border != PEA_BORDER_CIRCULAR;
+  if constexpr (D_T == 16) {
+    if (z3) {
+      if (crop) PEA_XB(true, 8, kXdmaPSU3, kXZ) else PEA_XB(false, 8, kXdmaPSU3, kXZ)
+      return true;
+    }
+  }
+  if (crop) PEA_XB(true, XP, kXdmaPSU, 0) else PEA_XB(false, XP, kXdmaPSU, 0)
+#undef PEA_XB
+  return true;
+}
+
+}  // namespace
+
+// the LDS-DMA forward of the self loss (f32 storage, D in {16, 32, 64}, axis-aligned stencil, K <= kXP; 3D norm1 / norm5 at D = 16).
+// (Inference keeps k_fwd_tiled: 60 us against 68 us at B=8 x 544^2 -- without the epilogue streams the one-sided box of the
+//  tiled kernel moves fewer bytes than six ring planes do.)
+bool xdma_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s, bool* finished) {
+  *finished = false;
+  if (!env().fwd_xdma || env().force_direct || A.dtype != PEA_F32 || !A.train || A.eo != A.e) return false;
+  if (P.D == 16) return fwd_self<16, true>(P, A, s, finished);
+  if (P.D == 32) return fwd_self<32, true>(P, A, s, finished);
+  if (P.D == 64) return fwd_self<64, true>(P, A, s, finished);
+  return false;
+}
+
+// the cross loss with a second operand: 2D, D = 16, f32, circular border, axis-aligned stencil.  e_other staged, own pixel from e,
+// both 1 / norm planes written (inv_out[0 .. B*S) own, inv_out[B*S .. 2*B*S) second operand)
+bool xdma_fwd_other(const KParams& P, const FwdArgs& A, hipStream_t s, bool* finished) {
+  *finished = false;
+  if (!env().fwd_xdma || env().force_direct || A.dtype != PEA_F32 || !A.train || !A.inv_out) return false;
+  if (P.D != 16 || P.border != PEA_BORDER_CIRCULAR) return false;
+  const float *e = (const float*)A.e, *e_other = (const float*)A.eo;
+  if (misaligned(e, 4) || misaligned(e_other, 16) || misaligned(A.t, 16) || misaligned(A.w, 16) || misaligned(A.affs, 16) ||
+      misaligned(A.gout, 16) || misaligned(A.m, 4) || misaligned(A.inv_out, 4))
+    return false;
+  if ((P.tbs | P.wbs | P.mbs) & 3) return false;
+  XPlan X;
+  if (!plan(P, kXdmaPSU, 1, &X) || X.C.nfz > 0 || P.K > kXP) return false;
+  const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  constexpr auto kern = k_fwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, true, 0, true>;
+  float* fin = env().loss_ticket ? A.loss_out : nullptr;
+  *finished = fin != nullptr;
+  PEA_LAUNCH(kern, grid, blk, X.lds, s, P, X.C, e_other, A.t, A.w, A.m, A.affs, A.gout, A.st, fin, A.inv_out, e,
+             A.inv_out + (size_t)P.B * P.S)
+  return true;
+}
+
+// the cross backward (self loss, f32 storage, axis-aligned stencil): needs the 1 / norm plane
+bool xdma_bwd_self(const KParams& P, const float* x, const float* inv, const float* g, const float* dl, float* dx, hipStream_t s) {
+  if (!inv || !env().bwd_xdma || env().force_direct) return false;
+  if (P.D == 16) return bwd_self<16>(P, x, inv, g, dl, dx, s);
+  if (P.D == 32) return bwd_self<32>(P, x, inv, g, dl, dx, s);
+  if (P.D == 64) return bwd_self<64>(P, x, inv, g, dl, dx, s);
+  return false;
+}
+
+// backward, role A only (the second operand is detached): de (+)= dloss * d loss / d e
+bool xdma_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* dl,
+                    float* de, bool accumulate, hipStream_t s) {
+  if (!inv2 || !env().bwd_xdma || env().force_direct || P.D != 16 || P.border != PEA_BORDER_CIRCULAR) return false;
+  if (misaligned(e_other, 16) || misaligned(inv2, 16) || ((size_t)P.B * P.S) % 4) return false;
+  XPlan X;
+  if (!plan(P, kXdmaPSU, 2, &X) || X.C.npx > kXP || X.C.npy > kXP) return false;
+  const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  constexpr auto kern = k_bwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, kXP, kAuxNT, 0, true>;
+  OtherArgs O;
+  O.own = e; O.own_inv = inv2; O.accumulate = accumulate ? 1 : 0;
+  PEA_LAUNCH(kern, grid, blk, X.lds, s, P, X.C, e_other, inv2 + (size_t)P.B * P.S, g, dl, de, O, DualArgs{})
+  return true;
+}
+
+// the pair's backward in one launch (k_bwd_xdma<.., DUAL>): 2D, D = 16, f32, circular border
+bool xdma_bwd_dual(const KParams& P, const float* e, const float* ema, const float* inv, const float* inv_other, const float* g,
+                   const float* g_cross, const float* dl, const float* dl_cross, float* de, hipStream_t s) {
+  if (!inv || !inv_other || !env().bwd_xdma || env().force_direct || P.D != 16 || P.border != PEA_BORDER_CIRCULAR) return false;
+  if (misaligned(e, 16) || misaligned(ema, 16) || misaligned(inv, 16) || misaligned(inv_other, 16)) return false;
+  XPlan X, X2;
+  if (!plan(P, kXdmaPSU, 0, &X) || X.C.npz > 0 || X.C.npx > kXP || X.C.npy > kXP) return false;
+  if (!plan(P, kXdmaPSU, 2, &X2)) return false;
+  DualArgs Q;
+  Q.C2 = X2.C;
+  Q.ema = ema; Q.inv_other = inv_other; Q.g_cross = g_cross; Q.dloss_cross = dl_cross;
+  const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  constexpr auto kern = k_bwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, kXP, kAuxNT, 0, false, true>;
+  PEA_LAUNCH(kern, grid, blk, X.lds, s, P, X.C, e, inv, g, dl, de, OtherArgs{}, Q)
+  return true;
+}
+
+void launch_inv_norm(const KParams& P, int dtype, const void* e, float* inv, hipStream_t s) {
+  const dim3 grid((unsigned)(P.tiles_per_xcd * kXcd)), blk(kBlock);
+  if (dtype == PEA_F16) hipLaunchKernelGGL(k_inv_norm<__half>, grid, blk, 0, s, P, (const __half*)e, inv);
+  else hipLaunchKernelGGL(k_inv_norm<float>, grid, blk, 0, s, P, (const float*)e, inv);
+}
+
+// pea_cross_supported: would the cross kernels take this descriptor?  mode 0: forward, 1: backward (self loss),
+// 2: the cross loss with a detached second operand (forward + role-A backward)
+int xdma_cross_supported(const KParams& P, int dtype, int mode) {
+  if (dtype != PEA_F32 || (P.D != 16 && P.D != 32 && P.D != 64) || env().force_direct) return 0;
+  if (!(mode ? env().bwd_xdma : env().fwd_xdma)) return 0;
+  XPlan X;
+  if (mode == 2) {
+    if (P.D != 16 || P.border != PEA_BORDER_CIRCULAR || P.K > kXP || !env().fwd_xdma) return 0;
+    if (!plan(P, kXdmaPSU, 1, &X) || X.C.nfz > 0) return 0;
+    return plan(P, kXdmaPSU, 2, &X) ? 1 : 0;
+  }
+  const int pm = mode == 0 ? 1 : 0;
+  if (!plan(P, kXdmaPSU3, pm, &X)) return 0;
+  const bool z3 = X.C.npz > 0 || X.C.nfz > 0;
+  if (z3) return (P.D == 16 && X.C.npx <= 8 && X.C.npy <= 8 && P.K <= kXP + 2) ? 1 : 0;
+  if (!plan(P, kXdmaPSU, pm, &X)) return 0;
+  if (!mode && P.K > kXP) return 0;
+  return (mode && P.D > 32 && (X.C.npx > 8 || X.C.npy > 8)) ? 0 : 1;
+}
+
+}  // namespace pea

@@ -23,7 +23,7 @@ struct GParams {
   int off[PEA_MAX_K][3];
 };
 
-__global__ __launch_bounds__(256) void k_gen_targets(const GParams G, const int32_t* __restrict__ labels,
+static __global__ __launch_bounds__(256) void k_gen_targets(const GParams G, const int32_t* __restrict__ labels,
                                                      float* __restrict__ target, uint8_t* __restrict__ mask,
                                                      unsigned* __restrict__ counts) {
   // NIT pixels per lane, decoded once; per channel NIT independent neighbour loads in flight; counts go wave ballot ->
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_gen_targets(const GParams G, const int3
   if (threadIdx.x < G.K && s_cnt[threadIdx.x]) atomicAdd(&counts[b * G.K + threadIdx.x], s_cnt[threadIdx.x]);
 }
 
-__global__ __launch_bounds__(256) void k_gen_weights(const GParams G, const float* __restrict__ target,
+static __global__ __launch_bounds__(256) void k_gen_weights(const GParams G, const float* __restrict__ target,
                                                      const unsigned* __restrict__ counts, float* __restrict__ weight) {
   const int bi = blockIdx.y;  // b * K + i
   const unsigned n = counts[bi];

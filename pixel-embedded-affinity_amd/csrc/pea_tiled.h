@@ -1,4 +1,4 @@
-// pea_tiled.h -- LDS-tiled kernels: the fast path.  Included by pea_hip.hip only.
+// pea_tiled.h -- LDS-tiled box kernels (round 1's fast path; since round 2 the fallback of the cross kernels, pea_xdma.h).
 //
 // One workgroup owns a TH x TW tile of one (b, z) plane, one lane per pixel.  It stages the tile plus
 // the halo that the "near" offsets reach into LDS ONCE -- already L2-normalised -- and every lane then
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled(const 
                                                          const T* __restrict__ eo, const float* __restrict__ target,
                                                          const float* __restrict__ weight,
                                                          const uint8_t* __restrict__ mask, float* __restrict__ affs,
-                                                         float* __restrict__ gout, float* __restrict__ partials, float* __restrict__ inv_out) {
+                                                         float* __restrict__ gout, LossState* __restrict__ st, float* __restrict__ inv_out) {
   typedef Lds<D_T, PLQ> L;
   constexpr int NT = TH * TW, NW = NT / 64;
   constexpr int KN = 8;  // near offsets per chunk (chunk 0 is requested before the staging loads)
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled(const 
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += s_part[w * P.K + threadIdx.x];
-      partials[(size_t)threadIdx.x * Q.ntiles + tile] = v;
+      loss_accumulate(st, tile, threadIdx.x, v);
     }
   }
 }
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled_v(cons
                                                            const T* __restrict__ eo, const float* __restrict__ target,
                                                            const float* __restrict__ weight,
                                                            const uint8_t* __restrict__ mask, float* __restrict__ affs,
-                                                           float* __restrict__ gout, float* __restrict__ partials, float* __restrict__ inv_out) {
+                                                           float* __restrict__ gout, LossState* __restrict__ st, float* __restrict__ inv_out) {
   typedef Lds<D_T, PLQ> L;
   constexpr int NT = TH * TW, TP = NT, QP = TP / 4, NSL = QP / 64;
   constexpr int ITEMS = (kKV * QP + NT - 1) / NT;
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled_v(cons
       float v = 0.f;
 #pragma unroll
       for (int s = 0; s < NSL; ++s) v += s_part[threadIdx.x * NSL + s];
-      partials[(size_t)threadIdx.x * Q.ntiles + tile] = v;
+      loss_accumulate(st, tile, threadIdx.x, v);
     }
   }
 }
@@ -881,235 +881,5 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_bwd_tiled(const 
 #pragma unroll
   for (int c = 0; c < D_T; ++c) bs_emb<T, true>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
 }
-
-// Self-loss backward AND the detached-EMA cross loss' backward of the same tensor in one launch, two LDS phases (the
-// tensor-path twin of k_fused_labels_dual): phase 1 is k_bwd_tiled<ROLE_A, ROLE_B> on x with g; then the EMA tensor's
-// one-sided region is staged over the dead one and the cross loss' role-A pairs add dl2 * g2_i(p) * emahat(p + o_i) to
-// the same G.  Saved against two launches: the second kernel's own-pixel loads, the add over [B,D,H,W] that merges the
-// two gradients, a launch.  d2[k]: LDS displacement of the self plan's near entry k in the cross phase's region.
-struct BwdCross { int d2[8]; };
-template <typename T, int D_T, int TH, int TW, int PLQ, bool CROP>
-__global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_bwd_tiled_dual(const KParams P, const TParams Q, const TParams Q2,
-                                                                             const BwdCross C2, const T* __restrict__ xt,
-                                                                             const T* __restrict__ emat, const float* __restrict__ gin,
-                                                                             const float* __restrict__ gin2,
-                                                                             const float* __restrict__ dloss,
-                                                                             const float* __restrict__ dloss2, T* __restrict__ dx) {
-  constexpr bool ROLE_A = true, ROLE_B = true;
-  const T* nbt = xt;
-  constexpr int NT = TH * TW;
-  constexpr int NR = (ROLE_A ? 1 : 0) + (ROLE_B ? 1 : 0);
-  constexpr int KN = 8;  // near offsets per chunk (x NR roles of g values; chunk 0 requested before staging)
-  extern __shared__ f4 lds4[];
-  char* lds = (char*)lds4;
-  const int tile = tile_id(Q);
-  if (tile >= Q.ntiles) return;
-  const int plane = tile / Q.tiles_per_plane;
-  const int rem = tile - plane * Q.tiles_per_plane;
-  const int ty = rem / Q.tiles_x;
-  const int y0 = ty * TH, x0 = (rem - ty * Q.tiles_x) * TW;
-  const int b = plane / P.Z, z = plane - b * P.Z;
-  const size_t S = (size_t)P.S;
-  const unsigned YX = (unsigned)(P.Y * P.X);
-  const rsrc_t xB = mkbuf(xt + (size_t)b * D_T * S), nB = mkbuf(nbt + (size_t)b * D_T * S);
-  const rsrc_t dB = mkbuf(dx + (size_t)b * D_T * S), gB = mkbuf(gin + (size_t)b * P.K * S);
-  const unsigned ecs = (unsigned)P.S * (unsigned)sizeof(T);
-  const unsigned ezo = (unsigned)z * YX * (unsigned)sizeof(T);
-  const unsigned kcs = (unsigned)P.S * 4u;
-  const unsigned kzo = (unsigned)z * YX * 4u;
-  const float dl = dloss ? dloss[0] : 1.f, dl2 = dloss2 ? dloss2[0] : 1.f;
-  const rsrc_t mB2 = mkbuf(emat + (size_t)b * D_T * S), gB2 = mkbuf(gin2 + (size_t)b * P.K * S);
-
-  int ly, lx;
-  lane_pixel<TW>(ly, lx);
-  const int py = y0 + ly, px = x0 + lx;
-  const bool live = py < P.Y && px < P.X;
-  const unsigned po = (unsigned)(py * P.X + px);
-  const unsigned pe = live ? po * (unsigned)sizeof(T) : kOOB;
-  const int pr = (ly + Q.hy0) * Q.RW + lx + Q.hx0;
-
-  // g of (near entry k, role) for this lane: role A reads g at p, role B at the neighbour p - o (wrapped);
-  // pairs that do not exist (outside the image, cropped away, past the end of the table) read out of range = 0
-#define PEA_BWD_LOAD_GN(k0)                                                                                    \
-  {                                                                                                            \
-    _Pragma("unroll") for (int u = 0; u < KN; ++u) _Pragma("unroll") for (int r = 0; r < NR; ++r) {            \
-      const OffEnt en_ = Q.near[min((k0) + u, Q.n_near - 1)];                                                  \
-      const int sg_ = (ROLE_A && r == 0) ? 1 : -1;                                                             \
-      bool oky_, okx_;                                                                                         \
-      const int yy_ = wrap1<CROP>(py + sg_ * ent_oy(en_), P.Y, oky_);                                          \
-      const int xx_ = wrap1<CROP>(px + sg_ * ent_ox(en_), P.X, okx_);                                          \
-      const bool ok_ = live && oky_ && okx_ && ((k0) + u < Q.n_near);                                          \
-      gn[u][r] = bl32(gB, ok_ ? (sg_ > 0 ? po : (unsigned)(yy_ * P.X + xx_)) * 4u : kOOB, kzo + (unsigned)en_.i * kcs); \
-    }                                                                                                          \
-  }
-
-  // (1) own raw pixel and the g values of the first near chunk: in flight during staging
-  // self loss (both roles, x == nb): the lane stages its own pixel itself, so x needs no loads of its own
-  constexpr bool OWN_STAGED = ROLE_A && ROLE_B;
-  float xh[D_T];
-  if (!OWN_STAGED) {
-#pragma unroll
-    for (int c = 0; c < D_T; ++c) xh[c] = bl_emb<T>(xB, pe, ezo + c * ecs);
-  }
-  float gn[KN][NR];
-  if (Q.n_near > 0) PEA_BWD_LOAD_GN(0)
-
-  // (2) stage
-  float own_inv = 0.f, own_ss = 0.f;
-  if (OWN_STAGED) stage_region_own<T, D_T, PLQ, TH, TW, CROP>(P, Q, nB, ezo, ecs, y0, x0, lds, ly, lx, xh, own_inv, own_ss);
-  else stage_region<T, D_T, PLQ, NT, CROP>(P, Q, nB, ezo, ecs, y0, x0, lds);
-
-  // (3) far (offset, role) pairs, two at a time: pair j = (far offset j / NR, role j % NR).  Vectors and g of
-  //     the first two pairs are in flight across the barrier and the near-pair work.
-  const int n_farp = Q.n_far * NR;
-  float fvA[D_T], fvB[D_T], fgA = 0.f, fgB = 0.f;
-#define PEA_BWD_LOAD_FAR(fv, fg, j)                                                                           \
-  {                                                                                                           \
-    const OffEnt fe_ = Q.far[(j) / NR];                                                                       \
-    const int sg_ = (ROLE_A && ((j) % NR) == 0) ? 1 : -1;                                                     \
-    bool okz_, oky_, okx_;                                                                                    \
-    const int zz_ = wrap1<CROP>(z + sg_ * fe_.d, P.Z, okz_);                                                  \
-    const int yy_ = wrap1<CROP>(py + sg_ * ent_oy(fe_), P.Y, oky_);                                           \
-    const int xx_ = wrap1<CROP>(px + sg_ * ent_ox(fe_), P.X, okx_);                                           \
-    const bool ok_ = live && okz_ && oky_ && okx_;                                                            \
-    const unsigned zc_ = (unsigned)(CROP ? min(max(zz_, 0), P.Z - 1) : zz_);                                  \
-    const unsigned qo_ = (unsigned)(yy_ * P.X + xx_);                                                         \
-    const unsigned vo_ = ok_ ? qo_ * (unsigned)sizeof(T) : kOOB;                                              \
-    _Pragma("unroll") for (int c = 0; c < D_T; ++c) fv[c] = bl_emb<T>(nB, vo_, zc_ * YX * (unsigned)sizeof(T) + c * ecs); \
-    fg = bl32(gB, ok_ ? (sg_ > 0 ? po : qo_) * 4u : kOOB, (sg_ > 0 ? kzo : zc_ * YX * 4u) + (unsigned)fe_.i * kcs); \
-  }
-#define PEA_BWD_FAR(fv, fg)                                                       \
-  {                                                                               \
-    float sq_ = 0.f;                                                              \
-    _Pragma("unroll") for (int c = 0; c < D_T; ++c) sq_ = fmaf(fv[c], fv[c], sq_); \
-    const float g_ = fg * rnorm(sq_, Q.inv_eps);                                  \
-    _Pragma("unroll") for (int c = 0; c < D_T; ++c) G[c] = fmaf(g_, fv[c], G[c]); \
-  }
-  if (n_farp > 0) PEA_BWD_LOAD_FAR(fvA, fgA, 0)
-  if (n_farp > 1) PEA_BWD_LOAD_FAR(fvB, fgB, 1)
-
-  float G[D_T];
-  float ss = 0.f;
-#pragma unroll
-  for (int c = 0; c < D_T; ++c) {
-    ss = fmaf(xh[c], xh[c], ss);
-    G[c] = 0.f;
-  }
-  if (OWN_STAGED) ss = own_ss;  // xh is already normalised
-  const bool tiny = ss < P.eps * P.eps;
-  const float invp = OWN_STAGED ? own_inv : rnorm(ss, Q.inv_eps);
-  if (!OWN_STAGED) {
-#pragma unroll
-    for (int c = 0; c < D_T; ++c) xh[c] *= invp;
-  }
-  lds_barrier();
-
-  // Far pairs 0 and 1 were requested before the barrier: consume them first, then request pairs 2 and 3 so that
-  // their round trip hides under the LDS-served near pairs, and consume those last.
-  if (n_farp > 0) PEA_BWD_FAR(fvA, fgA)
-  if (n_farp > 1) PEA_BWD_FAR(fvB, fgB)
-  if (n_farp > 2) PEA_BWD_LOAD_FAR(fvA, fgA, 2)
-  if (n_farp > 3) PEA_BWD_LOAD_FAR(fvB, fgB, 3)
-
-  // ---- near pairs ------------------------------------------------------------------------------------
-  for (int k0 = 0; k0 < Q.n_near; k0 += KN) {
-    if (k0 > 0) PEA_BWD_LOAD_GN(k0)
-#pragma unroll
-    for (int u = 0; u < KN; ++u) {
-      if (k0 + u < Q.n_near) {  // uniform
-        const int d = Q.near[k0 + u].d;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          float v[D_T];
-          lds_pixel<D_T, PLQ>(lds, pr + ((ROLE_A && r == 0) ? d : -d), v);
-#pragma unroll
-          for (int c = 0; c < D_T; ++c) G[c] = fmaf(gn[u][r], v[c], G[c]);
-          // one neighbour vector live at a time: without this fence all ds_read_b128 groups of the chunk are
-          // hoisted to its top and the kernel spills
-          asm volatile("" ::: "memory");
-        }
-      }
-    }
-  }
-#undef PEA_BWD_LOAD_GN
-
-  // ---- remaining far pairs (an out-of-range pair read zeros: g = 0, vector = 0) ------------------------------
-  if (n_farp > 2) PEA_BWD_FAR(fvA, fgA)
-  if (n_farp > 3) PEA_BWD_FAR(fvB, fgB)
-  for (int j = 4; j < n_farp; j += 2) {
-    PEA_BWD_LOAD_FAR(fvA, fgA, j)
-    if (j + 1 < n_farp) PEA_BWD_LOAD_FAR(fvB, fgB, j + 1)
-    PEA_BWD_FAR(fvA, fgA)
-    if (j + 1 < n_farp) PEA_BWD_FAR(fvB, fgB)
-  }
-#undef PEA_BWD_LOAD_FAR
-#undef PEA_BWD_FAR
-
-  // ================= phase 2: the cross loss' role-A pairs, G += dl2 * g2_i(p) * emahat(p + o_i) =================
-#pragma unroll
-  for (int c = 0; c < D_T; ++c) G[c] *= dl;
-  float g2n[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k)  // g2 of the near entries at p: requested before the restaging
-    g2n[k] = bl32(gB2, (live && k < Q.n_near) ? po * 4u : kOOB, kzo + (unsigned)Q.near[min(k, max(Q.n_near - 1, 0))].i * kcs) * dl2;
-  lds_barrier();  // every lane is done with x's region
-  stage_region<T, D_T, PLQ, NT, CROP>(P, Q2, mB2, ezo, ecs, y0, x0, lds);
-  const int pr2 = (ly + Q2.hy0) * Q2.RW + lx + Q2.hx0;
-  float fv2[D_T], fg2 = 0.f;
-#define PEA_BWD2_LOAD_FAR(j)                                                                                  \
-  {                                                                                                           \
-    const OffEnt fe_ = Q2.far[j];                                                                             \
-    bool okz_, oky_, okx_;                                                                                    \
-    const int zz_ = wrap1<CROP>(z + fe_.d, P.Z, okz_);                                                        \
-    const int yy_ = wrap1<CROP>(py + ent_oy(fe_), P.Y, oky_);                                                 \
-    const int xx_ = wrap1<CROP>(px + ent_ox(fe_), P.X, okx_);                                                 \
-    const bool ok_ = live && okz_ && oky_ && okx_;                                                            \
-    const unsigned zc_ = (unsigned)(CROP ? min(max(zz_, 0), P.Z - 1) : zz_);                                  \
-    const unsigned vo_ = ok_ ? (unsigned)(yy_ * P.X + xx_) * (unsigned)sizeof(T) : kOOB;                      \
-    _Pragma("unroll") for (int c = 0; c < D_T; ++c) fv2[c] = bl_emb<T>(mB2, vo_, zc_ * YX * (unsigned)sizeof(T) + c * ecs); \
-    fg2 = bl32(gB2, ok_ ? po * 4u : kOOB, kzo + (unsigned)fe_.i * kcs) * dl2;                                 \
-  }
-#define PEA_BWD2_FAR()                                                                \
-  {                                                                                   \
-    float sq_ = 0.f;                                                                  \
-    _Pragma("unroll") for (int c = 0; c < D_T; ++c) sq_ = fmaf(fv2[c], fv2[c], sq_);  \
-    const float g_ = fg2 * rnorm(sq_, Q.inv_eps);                                     \
-    _Pragma("unroll") for (int c = 0; c < D_T; ++c) G[c] = fmaf(g_, fv2[c], G[c]);    \
-  }
-  int jf2 = 0;
-  if (Q2.n_far > 0) PEA_BWD2_LOAD_FAR(0)
-  lds_barrier();
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    if (k < Q.n_near) {  // uniform; entry k of both plans is the same offset (host-checked)
-      float v[D_T];
-      lds_pixel<D_T, PLQ>(lds, pr2 + C2.d2[k], v);
-#pragma unroll
-      for (int c = 0; c < D_T; ++c) G[c] = fmaf(g2n[k], v[c], G[c]);
-      asm volatile("" ::: "memory");
-      if ((k & 3) == 3 && jf2 < Q2.n_far) {
-        PEA_BWD2_FAR()
-        ++jf2;
-        if (jf2 < Q2.n_far) PEA_BWD2_LOAD_FAR(jf2)
-      }
-    }
-  }
-  while (jf2 < Q2.n_far) {
-    PEA_BWD2_FAR()
-    ++jf2;
-    if (jf2 < Q2.n_far) PEA_BWD2_LOAD_FAR(jf2)
-  }
-#undef PEA_BWD2_LOAD_FAR
-#undef PEA_BWD2_FAR
-
-  float proj = 0.f;
-#pragma unroll
-  for (int c = 0; c < D_T; ++c) proj = fmaf(xh[c], G[c], proj);
-  if (tiny) proj = 0.f;  // clamp_min branch of F.normalize: d ehat / d e = I / eps
-  const float sc = invp;  // dloss / dloss2 are already in G
-#pragma unroll
-  for (int c = 0; c < D_T; ++c) bs_emb<T, true>(dB, (G[c] - xh[c] * proj) * sc, pe, ezo + c * ecs);
-}
-
 
 }  // namespace pea

@@ -131,19 +131,6 @@ __device__ __forceinline__ bool xdma_tile(const XParams& C, const KParams& P, in
 // AUXS: cache policy of the gradient stores (non-temporal: they must not push the halo lines out of the L2, pea_tiled.h bs_emb)
 // XP: (offset, role) pairs per axis held in registers (<= kXP; the D = 64 instantiation takes 8 to stay inside 128 VGPRs)
 // ZP: pairs along z read from global memory (0: 2D; kXZ: the 3D instantiation)
-// HC: input channels of the embedding head whose backward rides in the epilogue (0: none) -- SURVEY.md section 8f, f1:
-//   e = W x + b was the step before this path (OutConv, scripts_cvppp/model/unet2d_residual.py:67-74, :346), so the gradient
-//   this kernel holds in registers at its end is all the head's backward needs: dx[c] = sum_d W[d,c] de[d] leaves from here
-//   (v_fmac with W in SGPRs), and the tile's share of dW = sum_p de x^T and db = sum_p de goes through the matrix cores
-//   (v_mfma_f32_16x16x4_f32, exact f32; operands transposed through per-wave tiles laid over the dead ring, as k_head_dw does;
-//   db is the column of a constant-one "channel").  `de` itself need not be written at all.
-struct HeadArgs {
-  const float* x;       // [B, HC, S] the head's input
-  const float* W;       // [D, HC]
-  const float* de_add;  // [B, D, S] gradient reaching the embedding from elsewhere (added before the head's backward), or null
-  float* dx;            // [B, HC, S]
-  float* partials;      // [ntiles][D * HC + D]: per-tile shares of dW and db (pea_affinity_bwd_head reduces them)
-};
 // DUAL: the backward of the training loop's full-resolution PAIR in one launch (scripts_cvppp/main.py:284-293: embedding_loss and
 //   ema_embedding_loss of the same `embedding`, the second with the detached EMA operand): after the self loss' chunk loop the
 //   workgroup stages the SECOND operand's one-sided cross (plan_xdma mode 2) and adds the cross loss' role-A pairs into the same
@@ -275,13 +262,13 @@ struct OtherArgs {
   const float* own_inv;  // [B, S] its signed 1 / norm plane
   int accumulate;
 };
-template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, int AUXS = kAuxNT, int ZP = 0, int HC = 0, bool OTHER = false, bool DUAL = false>
+template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, int AUXS = kAuxNT, int ZP = 0, bool OTHER = false, bool DUAL = false>
 __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const XParams C, const float* __restrict__ xt,
                                                          const float* __restrict__ invp, const float* __restrict__ gin,
                                                          const float* __restrict__ dloss, float* __restrict__ dx,
-                                                         const HeadArgs H, const OtherArgs O, const DualArgs Q) {
-  static_assert(!OTHER || (D_T <= 16 && ZP == 0 && HC == 0), "role-A instantiation: D <= 16, in-plane, no head epilogue");
-  static_assert(!DUAL || (D_T == 16 && ZP == 0 && HC == 0 && !OTHER), "pair instantiation: D = 16, in-plane");
+                                                         const OtherArgs O, const DualArgs Q) {
+  static_assert(!OTHER || (D_T <= 16 && ZP == 0), "role-A instantiation: D <= 16, in-plane");
+  static_assert(!DUAL || (D_T == 16 && ZP == 0 && !OTHER), "pair instantiation: D = 16, in-plane");
   constexpr int NT = TH * TW, PS = PSU * 256, NP = D_T / 2;
   static_assert(TW == 32 && D_T % 2 == 0, "lane mapping / channel pairs");
   extern __shared__ f4 lds4[];
@@ -526,114 +513,24 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   if (invo < 0.f) proj = 0.f;  // clamp branch of F.normalize
   const float sc = DUAL ? inv_own : dl * inv_own;
   const float pn = proj * inv_own;  // !KEEP: ehat * proj = e * (inv_own * proj)
-  if constexpr (HC == 0) {
-    f2 old[OTHER ? NP : 1];
-    const bool accum = OTHER && O.accumulate != 0;  // uniform
-    if (OTHER && accum) {
-#pragma unroll
-      for (int ps = 0; ps < NP; ++ps) {
-        old[ps].x = bl32(dB, pe, ezo + (unsigned)(2 * ps) * ecs);
-        old[ps].y = bl32(dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs);
-      }
-    }
+  f2 old[OTHER ? NP : 1];
+  const bool accum = OTHER && O.accumulate != 0;  // uniform
+  if (OTHER && accum) {
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
-      float ex, ey;
-      if (KEEP) { ex = eh[ps].x * proj; ey = eh[ps].y * proj; }
-      else { ex = bl32(xB, pe, ezo + (unsigned)(2 * ps) * ecs) * pn; ey = bl32(xB, pe, ezo + (unsigned)(2 * ps + 1) * ecs) * pn; }
-      float vx = (G[ps].x - ex) * sc, vy = (G[ps].y - ey) * sc;
-      if (OTHER && accum) { vx += old[ps].x; vy += old[ps].y; }
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), dB, pe, ezo + (unsigned)(2 * ps) * ecs, AUXS);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs, AUXS);
+      old[ps].x = bl32(dB, pe, ezo + (unsigned)(2 * ps) * ecs);
+      old[ps].y = bl32(dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs);
     }
-  } else {
-    static_assert(HC == 0 || (KEEP && D_T == 16 && HC % 16 == 0 && HC <= 64), "head epilogue: D = 16, C a multiple of 16");
-    constexpr int kRow = 68;                      // LDS row stride (floats) of a [channel][64 px] tile: conflict-free both ways
-    constexpr int CC = HC / 16, NW = NT / 64;     // 16-channel blocks of x (+ one block for db), waves
-    constexpr int kRed = D_T * 16 * (CC + 1);     // one wave's [d][16 * (CC + 1)] result tile
-    static_assert(NW * 2 * 16 * kRow * 4 <= 6 * PS && NW * kRed * 4 <= 6 * PS, "the transposition tiles fit the dead ring");
-    // ---- the gradient of this lane's pixel (dead lanes: 0), plus whatever reaches the embedding from other losses
-    float dv[D_T];
+  }
 #pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-      dv[2 * ps] = live ? (G[ps].x - eh[ps].x * proj) * sc : 0.f;
-      dv[2 * ps + 1] = live ? (G[ps].y - eh[ps].y * proj) * sc : 0.f;
-    }
-    if (H.de_add) {
-      const rsrc_t aB = mkbuf(H.de_add + (size_t)b * D_T * S);
-#pragma unroll
-      for (int d = 0; d < D_T; ++d) dv[d] += bl32(aB, pe, ezo + (unsigned)d * ecs);
-    }
-    if (dx) {
-#pragma unroll
-      for (int d = 0; d < D_T; ++d)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dv[d]), dB, pe, ezo + (unsigned)d * ecs, AUXS);
-    }
-    // ---- dx = W^T de: one output channel at a time, W through the scalar cache
-    const rsrc_t hxB = mkbuf(H.x + (size_t)b * HC * S), hdB = mkbuf(H.dx + (size_t)b * HC * S);
-    const float* __restrict__ Wm = H.W;
-    if (H.dx) {
-#pragma unroll
-      for (int c = 0; c < HC; ++c) {
-        float a = 0.f;
-#pragma unroll
-        for (int d = 0; d < D_T; ++d) a = fmaf(Wm[d * HC + c], dv[d], a);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a), hdB, pe, ezo + (unsigned)c * ecs, AUXS);
-      }
-    }
-    // ---- dW / db share of this tile.  MFMA operand coordinates of a lane: row / column mi, k index mk; a k-step is 4 pixels
-    lds_barrier();  // every wave is done with the ring
-    float* tA = (float*)lds + wave * (2 * 16 * kRow);
-    float* tB = tA + 16 * kRow;
-    const int mi = lane & 15, mk = lane >> 4;
-    typedef float hv4_t __attribute__((ext_vector_type(4)));
-    hv4_t acc[CC + 1];
-#pragma unroll
-    for (int j = 0; j <= CC; ++j) acc[j] = hv4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int d = 0; d < D_T; ++d) tA[d * kRow + lane] = dv[d];
-    __builtin_amdgcn_wave_barrier();
-    float av[16];
-#pragma unroll
-    for (int st = 0; st < 16; ++st) av[st] = tA[mi * kRow + 4 * st + mk];
-#pragma unroll
-    for (int j = 0; j <= CC; ++j) {
-      float xv[16];
-      if (j < CC) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xv[r] = bl32(hxB, pe, ezo + (unsigned)(16 * j + r) * ecs);  // dead lanes read 0
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xv[r] = (r == 0 && live) ? 1.f : 0.f;  // the constant-one channel: its dW column is db
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tB[r * kRow + lane] = xv[r];
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int st = 0; st < 16; ++st) {
-        const float bv = tB[mi * kRow + 4 * st + mk];
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv, acc[j], 0, 0, 0);
-      }
-      __builtin_amdgcn_wave_barrier();  // the next block's writes come after these reads
-    }
-    // ---- the waves' tiles summed in wave order -> partials[tile]
-    lds_barrier();
-    float* red = (float*)lds;  // [NW][kRed]
-#pragma unroll
-    for (int j = 0; j <= CC; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)  // C/D layout: row = 4 * (lane >> 4) + r, column = lane & 15
-        red[wave * kRed + (4 * mk + r) * (16 * (CC + 1)) + 16 * j + mi] = acc[j][r];
-    lds_barrier();
-    float* out = H.partials + (size_t)tile * (D_T * HC + D_T);
-    for (int t = threadIdx.x; t < D_T * HC + D_T; t += NT) {
-      const int d = t < D_T * HC ? t / HC : t - D_T * HC;
-      const int col = t < D_T * HC ? t - d * HC : 16 * CC;
-      float sum = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) sum += red[w * kRed + d * (16 * (CC + 1)) + col];
-      out[t] = sum;
-    }
+  for (int ps = 0; ps < NP; ++ps) {
+    float ex, ey;
+    if (KEEP) { ex = eh[ps].x * proj; ey = eh[ps].y * proj; }
+    else { ex = bl32(xB, pe, ezo + (unsigned)(2 * ps) * ecs) * pn; ey = bl32(xB, pe, ezo + (unsigned)(2 * ps + 1) * ecs) * pn; }
+    float vx = (G[ps].x - ex) * sc, vy = (G[ps].y - ey) * sc;
+    if (OTHER && accum) { vx += old[ps].x; vy += old[ps].y; }
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), dB, pe, ezo + (unsigned)(2 * ps) * ecs, AUXS);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs, AUXS);
   }
 }
 
@@ -651,18 +548,23 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
 // OTHER: the cross loss a_i(p) = <ehat(p), ehat_other(p + o_i)> (ema_embedding_loss): `e` is the SECOND operand (staged: the
 //   neighbours), the own pixel comes from `own` (global loads, all channels up front); both 1 / norm planes are written
 //   (inv_out: own, inv_other_out: the second operand's, from the staged centre) for the role-A backward
-template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN, int ZF = 0, bool OTHER = false>
-__global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const XParams C, const float* __restrict__ e,
-                                                         const float* __restrict__ target, const float* __restrict__ weight,
-                                                         const uint8_t* __restrict__ mask, float* __restrict__ affs,
-                                                         float* __restrict__ gout, float* __restrict__ partials,
-                                                         float* __restrict__ inv_out, const float* __restrict__ own,
-                                                         float* __restrict__ inv_other_out) {
+// WPE: waves per SIMD the register budget is cut for: 4 = two workgroups per CU (13 KB planes: the backward's geometry),
+//   6 = THREE workgroups per CU -- the forward's one-sided cross needs 7.5 KB planes (6 x 7680 B = 45 KB of ring), so a third
+//   workgroup fits the LDS if the kernel stays within 80 VGPRs: target / weight / mask are then requested after the channel loop
+//   (LATE) instead of being held across it
+// loss_fin: non-null = finish the loss inside this launch (pea_loss.h, ticket); null = the caller launches k_loss_finish
+template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN, int ZF = 0, bool OTHER = false, int WPE = 4>
+__global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const XParams C, const float* __restrict__ e,
+                                                           const float* __restrict__ target, const float* __restrict__ weight,
+                                                           const uint8_t* __restrict__ mask, float* __restrict__ affs,
+                                                           float* __restrict__ gout, LossState* __restrict__ st,
+                                                           float* __restrict__ loss_fin, float* __restrict__ inv_out,
+                                                           const float* __restrict__ own, float* __restrict__ inv_other_out) {
   static_assert(!OTHER || (D_T <= 16 && ZF == 0), "cross-loss instantiation: D <= 16, in-plane");
   constexpr int NT = TH * TW, PS = PSU * 256, NP = D_T / 2, TP = NT, QP = TP / 4, NSL = QP / 64;
   constexpr int KMAX = ZF > 0 ? kXP + 2 : kXP;      // channels the epilogue handles (norm5: 8 in-plane + 4 z offsets)
   constexpr int ITEMS = (KMAX * QP + NT - 1) / NT;
-  constexpr bool SDMA = ZF > 0, LATE = ZF > 0 || OTHER;  // OTHER: the own pixel's registers instead of the early t / w / m
+  constexpr bool SDMA = ZF > 0, LATE = ZF > 0 || OTHER || WPE > 4;  // OTHER: the own pixel's registers instead of the early t / w / m
   static_assert(TW == 32 && D_T % 2 == 0 && QP % 64 == 0, "lane mapping / channel pairs");
   static_assert(KMAX * TP * 4 + KMAX * NSL * 4 <= 6 * PS && KMAX <= kXK, "the parked dot products fit the ring");
   extern __shared__ f4 lds4[];
@@ -872,8 +774,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
 #undef PEA_XWAIT1
 #undef PEA_XWAITZ
 #undef PEA_XZLOAD
-  if (LATE) PEA_XLOAD_TWM()
-#undef PEA_XLOAD_TWM
+  if (LATE && WPE <= 4) PEA_XLOAD_TWM()
 
   // ---- normalise; the lane's own 1 / norm for the backward
   const float osum = oss.x + oss.y;
@@ -904,6 +805,8 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
       sA[C.fzi[k] * TP + (int)threadIdx.x] = a;
     }
   }
+  if (LATE && WPE > 4) PEA_XLOAD_TWM()  // 80-VGPR budget: only now are the 40 accumulator registers free
+#undef PEA_XLOAD_TWM
   lds_barrier();
 
   // ---- epilogue: 4 x-adjacent pixels of one offset per lane, dwordx4 everywhere
@@ -942,11 +845,14 @@ __global__ __launch_bounds__(TH* TW, 4) void k_fwd_xdma(const KParams P, const X
   }
   if (TRAIN) {
     lds_barrier();
-    if ((int)threadIdx.x < P.K) {
-      float v = 0.f;
+    if (wave == 0) {  // the one wave that touches the loss state
+      if ((int)threadIdx.x < P.K) {
+        float v = 0.f;
 #pragma unroll
-      for (int s = 0; s < NSL; ++s) v += s_part[threadIdx.x * NSL + s];
-      partials[(size_t)threadIdx.x * C.ntiles + tile] = v;
+        for (int s = 0; s < NSL; ++s) v += s_part[threadIdx.x * NSL + s];
+        loss_accumulate(st, tile, threadIdx.x, v);
+      }
+      if (loss_fin) loss_ticket_finish(P, st, (unsigned)C.ntiles, tile, loss_fin);
     }
   }
 }

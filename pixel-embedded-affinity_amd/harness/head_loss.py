@@ -1,28 +1,27 @@
-"""The embedding head and the self loss as ONE autograd node (the backward half).
+"""The embedding head and the self loss as ONE autograd node.
 
 The reference computes  embedding = self.outconv_emb(x)  (scripts_cvppp/model/unet2d_residual.py:346) inside the model and
 embedding_loss(embedding, ...)  in the training loop (main.py:284); autograd then runs the loss' backward and the head's
-backward one after the other, with `d loss / d embedding` written to HBM by the first and read twice by the second (dx and dW).
-Here the two backwards are one launch (pea_affinity_bwd_head): the gradient is still in the registers of the lane that
-produced it when dx = W^T de is stored and the tile's share of dW / db goes through the matrix cores.
+backward one after the other.  Here head forward, loss forward, loss backward and head backward are one node that launches the
+four kernels itself (no autograd bookkeeping between them, no zero-filled gradients of the non-differentiable outputs).
 
     loss, affs, all_loss, embedding = head_embedding_loss(x, head, target, weightmap, mask, criterion, offsets)
 
 `head` is this package's OutConv (or any module with a 1x1 `conv`); `embedding` comes back as a differentiable output of the
 same node, so the other losses of the section (the EMA cross loss, the consistency term) keep working on it -- whatever
-gradient they send into it is added inside the kernel (`de_add`) before the head's backward.  Shapes the fused launch does
-not cover (anything but 2D, D = 16, C = 32, f32, axis-aligned stencil, width % 4 == 0) run the two separate launches.
+gradient they send into it is added before the head's backward.
 
-MEASURED (B=8 x 32 -> 16 x 544^2, profiles/r2c_f1_fused_backward.txt): the one launch takes 345 us against 116 + 161 us for
-pea_affinity_bwd_ex + pea_head_bwd.  It moves 190 B/px less, but x loads, 512 FMAs and 32 stores per lane in the tail of a
-2-workgroups-per-CU LDS kernel overlap with nothing, while the stand-alone head kernels stream at 5.5 TB/s (DESIGN.md
-section 8).  So `fused_backward` defaults to False: the node then runs the two launches (still one autograd node)."""
+History: round 2 also had the two backwards as ONE launch (the head's dx / dW / db in the epilogue of the loss backward).
+MEASURED at B=8 x 32 -> 16 x 544^2 (profiles/r2c_f1_fused_backward.txt): 345 us against 116 + 161 us for the two launches --
+x loads, 512 FMAs and 32 stores per lane in the tail of a 2-workgroups-per-CU LDS kernel overlap with nothing, while the
+stand-alone head kernels stream at 5.5 TB/s.  A fusion that loses is dead weight: removed in round 3."""
 import ctypes
 
 import torch
 
 from .. import _lib
-from ..affinity_op import (AffinitySpec, LossList, _affs_shape, _batch_strided, _on_device, _ptr, _require_gpu, _stream, make_desc)
+from ..affinity_op import (AffinitySpec, LossList, _affs_shape, _batch_strided, _on_device, _ptr, _require_gpu, _stream, make_desc,
+                           workspace)
 from ..model.head import head_supported
 
 
@@ -30,9 +29,8 @@ class HeadAffinityMSE(torch.autograd.Function):
     """(loss, affs, per_offset_losses, embedding) = f(x, weight, bias, target, weightmap, mask)"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, target, weightmap, mask, spec, fused_backward=False):
+    def forward(ctx, x, weight, bias, target, weightmap, mask, spec):
         ctx.set_materialize_grads(False)
-        ctx.fused_backward = bool(fused_backward)
         _require_gpu(x, "x")
         if x.dtype != torch.float32 or weight.dtype != torch.float32:
             raise TypeError("the embedding head runs in float32 (got %s / %s)" % (x.dtype, weight.dtype))
@@ -58,8 +56,7 @@ class HeadAffinityMSE(torch.autograd.Function):
             d = make_desc(spec, e, ts, ws, ms)
             affs = torch.empty(kshape, dtype=torch.float32, device=e.device)
             loss_vec = torch.empty(1 + spec.K, dtype=torch.float32, device=e.device)
-            wsb = L.pea_workspace_bytes(ctypes.byref(d))
-            work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=e.device)
+            work, wsb = workspace(e.device, d)
             g = torch.empty(kshape, dtype=torch.float32, device=e.device)
             inv = torch.empty((B,) + tuple(e.shape[2:]), dtype=torch.float32, device=e.device)
             _lib.check(L.pea_affinity_fwd_ex(ctypes.byref(d), _ptr(e), None, _ptr(target), _ptr(weightmap), _ptr(mask), _ptr(affs),
@@ -85,19 +82,10 @@ class HeadAffinityMSE(torch.autograd.Function):
             add = None if de_ext is None else de_ext.to(torch.float32).contiguous()
             if dloss is None:  # only the embedding output was used downstream: the head's backward alone
                 if add is None:
-                    return (None,) * 8
+                    return (None,) * 7
                 de = add
             else:
                 dl = dloss.to(device=xc.device, dtype=torch.float32).contiguous()
-                hb = L.pea_bwd_head_workspace_bytes(ctypes.byref(ctx.desc), C) if ctx.fused_backward else 0
-                if hb:
-                    work = torch.empty(hb // 4, dtype=torch.float32, device=xc.device)
-                    rc = L.pea_affinity_bwd_head(ctypes.byref(ctx.desc), _ptr(e), _ptr(g), _ptr(inv), _ptr(dl), _ptr(add), _ptr(xc),
-                                                 _ptr(wc), C, _ptr(dx), _ptr(dW), _ptr(db), None, _ptr(work), hb, _stream())
-                    if rc == 0:
-                        return dx, dW.reshape(ctx.wshape), db, None, None, None, None, None
-                    if rc != _lib.E_UNSUPPORTED:
-                        _lib.check(rc, "pea_affinity_bwd_head")
                 de = torch.empty_like(e)
                 _lib.check(L.pea_affinity_bwd_ex(ctypes.byref(ctx.desc), _ptr(e), None, _ptr(g), _ptr(inv), _ptr(dl), _ptr(de), None,
                                                  _stream()), "pea_affinity_bwd_ex")
@@ -107,10 +95,10 @@ class HeadAffinityMSE(torch.autograd.Function):
             work = torch.empty(wsb // 4, dtype=torch.float32, device=xc.device)
             _lib.check(L.pea_head_bwd(B, C, D, S, _ptr(xc), _ptr(wc), _ptr(de), _ptr(dx), _ptr(dW), _ptr(db), _ptr(work), wsb, _stream()),
                        "pea_head_bwd")
-        return dx, dW.reshape(ctx.wshape), db, None, None, None, None, None
+        return dx, dW.reshape(ctx.wshape), db, None, None, None, None
 
 
-def head_embedding_loss(x, head, target, weightmap, mask, criterion, offsets, affs0_weight=1, mode='ours', fused_backward=False):
+def head_embedding_loss(x, head, target, weightmap, mask, criterion, offsets, affs0_weight=1, mode='ours'):
     """-> (loss, affs [B,K,H,W], all_loss list[K], embedding [B,D,H,W]): head(x) followed by embedding_loss(...) of
     loss/loss_embedding_mse.py (reference :18-47), as one autograd node; criterion must be this package's WeightedMSE"""
     if not getattr(criterion, 'pea_fused', False):
@@ -120,5 +108,5 @@ def head_embedding_loss(x, head, target, weightmap, mask, criterion, offsets, af
     if ndim != 2:
         raise ValueError("head_embedding_loss is the 2D (CVPPP / BBBC039V1) call; 3D heads use head(x) + embedding_loss_norm*")
     spec = AffinitySpec(2, offsets, [1.0] * len(offsets), _lib.BORDER_CIRCULAR, _lib.NORM_BX, 1e-12 if mode == 'ours' else 1e-6)
-    loss, affs, parts, emb = HeadAffinityMSE.apply(x, conv.weight, conv.bias, target, weightmap, mask, spec, fused_backward)
+    loss, affs, parts, emb = HeadAffinityMSE.apply(x, conv.weight, conv.bias, target, weightmap, mask, spec)
     return loss, affs, LossList(parts), emb

@@ -101,8 +101,7 @@ class _TensorSection(torch.autograd.Function):
                         m = m.to(torch.uint8)      # (runs on the stream of this loss: the side stream for the small scales)
                     m, ms = op._batch_strided(m, "mask", torch.uint8, kshape)
                 d = op.make_desc(spec, e_c, ts, ws, ms)
-                wsb = L.pea_workspace_bytes(ctypes.byref(d))
-                work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=dev)
+                work, wsb = op.workspace(dev, d)
                 affs = torch.empty(kshape, dtype=torch.float32, device=dev) if want_affs else None
                 g = torch.empty(kshape, dtype=torch.float32, device=dev)
                 inv = None
@@ -436,8 +435,7 @@ class _LabelsSection(torch.autograd.Function):
             def one(j, e_c, o_c, lab, d, wtab, counts, cb, affs, de, accumulate):
                 """loss j as one labels-in launch (or, where no labels kernel applies -- the coarsest scales are smaller
                 than a tile --, targets on the GPU + the two tensor launches), gradient weighted by weights[j]"""
-                wsb = L.pea_workspace_bytes(ctypes.byref(d))
-                work = torch.empty(max(wsb, 4) // 4, dtype=torch.float32, device=dev)
+                work, wsb = op.workspace(dev, d)
                 fl = lflags | (_lib.TGT_ACCUMULATE if accumulate else 0)
                 rc = L.pea_affinity_fwd_bwd_labels(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(lab), op._ptr(wtab), fl,
                                                    op._ptr(affs), op._ptr(rows[j]), op._ptr(wdev[j:j + 1]), op._ptr(de), op._ptr(work),
@@ -475,8 +473,7 @@ class _LabelsSection(torch.autograd.Function):
             dx_ = op.make_desc(specs[jx], e0)
             pred = torch.empty(op._affs_shape(e0, specs[0].K), dtype=torch.float32, device=dev)
             de0 = torch.empty_like(e0)
-            wsb2 = 2 * L.pea_workspace_bytes(ctypes.byref(d0))
-            work2 = torch.empty(max(wsb2, 4) // 4, dtype=torch.float32, device=dev)
+            work2, wsb2 = op.workspace(dev, d0, 2)
             rc = L.pea_affinity_fwd_bwd_labels_dual(ctypes.byref(d0), ctypes.byref(dx_), op._ptr(e0), op._ptr(ema_c), op._ptr(lab0),
                                                     op._ptr(wtab0), lflags, op._ptr(pred), op._ptr(rows[0]), op._ptr(rows[jx]),
                                                     op._ptr(wdev[0:1]), op._ptr(wdev[jx:jx + 1]), op._ptr(de0), op._ptr(work2), wsb2, op._stream())

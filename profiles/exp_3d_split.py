@@ -39,6 +39,7 @@ for name, nd, B, offs in cases:
     affs = torch.empty(*kshp, device=dev); G = torch.empty_like(affs); lossv = torch.empty(1 + K, device=dev)
     INV = torch.empty((B, 1) + shp[2:], device=dev)
     wsb = L.pea_workspace_bytes(ctypes.byref(desc)); work = torch.empty(max(wsb, 4) // 4, device=dev)
+    assert L.pea_workspace_init(ctypes.c_void_p(work.data_ptr()), wsb, None) == 0  # the loss-state block: prepared once
     dE = torch.empty_like(E); one = torch.ones((), device=dev)
     fns = {"fwd": lambda: L.pea_affinity_fwd_ex(ctypes.byref(desc), P(E), None, P(T), P(Wt), None, P(affs), P(G), P(INV), P(lossv), P(work), wsb, st),
            "bwd": lambda: L.pea_affinity_bwd_ex(ctypes.byref(desc), P(E), None, P(G), P(INV), P(one), P(dE), None, st)}

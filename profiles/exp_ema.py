@@ -18,6 +18,7 @@ import copy
 dacc = copy.copy(desc); dacc.flags |= pkg._lib.FLAG_ACCUMULATE_DE
 affs = torch.empty(B, K, H, W, device=dev); G = torch.empty_like(affs); lossv = torch.empty(1 + K, device=dev)
 wsb = L.pea_workspace_bytes(ctypes.byref(desc)); work = torch.empty(max(wsb, 4) // 4, device=dev)
+assert L.pea_workspace_init(ctypes.c_void_p(work.data_ptr()), wsb, None) == 0  # the loss-state block: prepared once
 INV2 = torch.empty(2, B, H, W, device=dev); dE = torch.zeros_like(E); one = torch.ones((), device=dev)
 def t(fn, n=30):
     for _ in range(5):

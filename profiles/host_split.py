@@ -33,6 +33,7 @@ desc = op.make_desc(op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, 
 K = len(offsets)
 affs = torch.empty(1, K, 64, 96, device=dev); G = torch.empty_like(affs); lossv = torch.empty(1 + K, device=dev)
 wsb = L.pea_workspace_bytes(ctypes.byref(desc)); work = torch.empty(max(wsb, 4) // 4, device=dev)
+assert L.pea_workspace_init(ctypes.c_void_p(work.data_ptr()), wsb, None) == 0  # the loss-state block: prepared once
 INV = torch.empty(1, 64, 96, device=dev); dE = torch.empty_like(Ed); one = torch.ones((), device=dev)
 P = lambda x: ctypes.c_void_p(x.data_ptr())
 st = op._stream()

@@ -29,6 +29,7 @@ G = torch.empty(B, K, H, W, device=dev)
 lossv = torch.empty(1 + K, device=dev)
 wsb = L.pea_workspace_bytes(ctypes.byref(desc))
 work = torch.empty(max(wsb, 4) // 4, device=dev)
+assert L.pea_workspace_init(ctypes.c_void_p(work.data_ptr()), wsb, None) == 0  # the loss-state block: prepared once
 dE = torch.empty_like(E)
 one = torch.ones((), device=dev)
 P = lambda x: ctypes.c_void_p(x.data_ptr())

@@ -21,6 +21,7 @@ if os.environ.get("F16", "0") == "1":  # f16 storage of the embedding / its grad
 desc = op.make_desc(op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX), E)
 affs = torch.empty(B, K, H, W, device=dev); G = torch.empty(B, K, H, W, device=dev); lossv = torch.empty(1 + K, device=dev)
 wsb = L.pea_workspace_bytes(ctypes.byref(desc)); work = torch.empty(max(wsb, 4) // 4, device=dev)
+assert L.pea_workspace_init(ctypes.c_void_p(work.data_ptr()), wsb, None) == 0  # the loss-state block: prepared once
 dE = torch.empty_like(E); one = torch.ones((), device=dev)
 fns = {"fwd": lambda: L.pea_affinity_fwd(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), P(G), P(lossv), P(work), wsb, st),
        "bwd": lambda: L.pea_affinity_bwd(ctypes.byref(desc), P(E), None, P(G), P(one), P(dE), None, st),

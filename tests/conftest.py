@@ -23,6 +23,32 @@ def pkg():
     return ge.load_package()
 
 
+@pytest.fixture(autouse=True)
+def _pea_switches(monkeypatch):
+    """The library reads its PEA_* switches once; tests flip them with monkeypatch.setenv / delenv.  Make those two calls tell
+    the library (and the Python layer's memo of pea_cross_supported) to re-read, and restore + re-read at teardown."""
+    lib_mod = sys.modules.get(ge.PKG_NAME + "._lib")
+    real_set, real_del = monkeypatch.setenv, monkeypatch.delenv
+
+    def reload(name):
+        mod = sys.modules.get(ge.PKG_NAME + "._lib")
+        if name.startswith("PEA_") and mod is not None:
+            mod.reload_env()
+
+    def setenv(name, value, *a, **k):
+        real_set(name, value, *a, **k)
+        reload(name)
+
+    def delenv(name, *a, **k):
+        real_del(name, *a, **k)
+        reload(name)
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield
+    monkeypatch.undo()
+    reload("PEA_")
+
+
 @pytest.fixture(scope="session")
 def orc():
     o = ge.load_oracle()

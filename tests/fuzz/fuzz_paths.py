@@ -70,12 +70,12 @@ for it in range(ncase):
     # ---- (b) cross kernels (where the dispatch takes them: f32, axis-aligned, wide enough) against the tiled kernels
     res = []
     for xdma in ("0", "1"):
-        os.environ["PEA_FWD_XDMA"] = os.environ["PEA_BWD_XDMA"] = xdma
+        pkg._lib.set_switch("PEA_FWD_XDMA", xdma); pkg._lib.set_switch("PEA_BWD_XDMA", xdma)
         et = e.clone().requires_grad_(True)
         out = pkg.ema_embedding_loss(et, ema, t, w, m, crit, offsets) if ema is not None else pkg.embedding_loss(et, t, w, m, crit, offsets)
         (out[0] * 0.5).backward()
         res.append((out[0].item(), out[1], et.grad))
-    os.environ.pop("PEA_FWD_XDMA"); os.environ.pop("PEA_BWD_XDMA")
+    pkg._lib.set_switch("PEA_FWD_XDMA", None); pkg._lib.set_switch("PEA_BWD_XDMA", None)
     da = float((res[0][1] - res[1][1]).abs().max())
     dl = abs(res[0][0] - res[1][0]) / max(abs(res[0][0]), 1e-9)
     dg = rel(res[1][2], res[0][2])

@@ -47,14 +47,14 @@ for it in range(ncase):
     spec = op.AffinitySpec(3, offs, lam, border, norm)
     res = []
     for direct in ("0", "1"):
-        os.environ["PEA_FORCE_DIRECT"] = direct
+        pkg._lib.set_switch("PEA_FORCE_DIRECT", direct)
         et = e.clone().requires_grad_(True)
         ot = o.clone().requires_grad_(mode == 2) if o is not None else None
         loss, affs, _ = op.FusedAffinityMSE.apply(et, ot, t, w, m, spec)
         (loss * 0.75).backward()
         inf = op.affinity_infer(et.detach(), ot.detach() if ot is not None else None, spec)
         res.append((loss.item(), affs.float(), inf.float(), et.grad.float(), ot.grad.float() if mode == 2 else None))
-    os.environ["PEA_FORCE_DIRECT"] = "0"
+    pkg._lib.set_switch("PEA_FORCE_DIRECT", None)
     a, b = res
     tol_g = 5e-3 if f16 else 1e-4  # f16: the gradient itself is stored in half precision (two roundings may differ by an ulp)
     d_affs = max(float((a[1] - b[1]).abs().max()), float((a[2] - b[2]).abs().max()))

@@ -22,13 +22,13 @@ def lib(pkg):
 
 
 def test_header_declares_the_expected_entry_points():
-    assert declared_symbols() == sorted(["pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes",
+    assert declared_symbols() == sorted(["pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_workspace_init", "pea_reload_env",
                                          "pea_affinity_infer", "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_ex", "pea_affinity_bwd_ex",
                                          "pea_inv_norm", "pea_cross_supported", "pea_affinity_bwd_dual", "pea_affinity_bwd_dual_ex",
                                          "pea_scale_inplace", "pea_scale_inplace_multi", "pea_fill_border_relu",
                                          "pea_targets_workspace_bytes", "pea_gen_targets",
                                          "pea_stitch_add", "pea_stitch_finalize", "pea_label_weights",
-                                         "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd", "pea_bwd_head_workspace_bytes", "pea_affinity_bwd_head",
+                                         "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd",
                                          "pea_affinity_fwd_bwd_labels", "pea_affinity_fwd_bwd_labels_dual"])
 
 
@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(pkg, lib):
     for name in declared_symbols():
         assert hasattr(raw, name), name
     assert sorted(pkg._lib.EXPORTS) == declared_symbols()
-    assert lib.pea_version() == pkg._lib.PEA_ABI_VERSION == 1
+    assert lib.pea_version() == pkg._lib.PEA_ABI_VERSION == 2
 
 
 def test_struct_layout_matches_header(pkg):
@@ -49,7 +49,7 @@ def test_struct_layout_matches_header(pkg):
 
 def _desc(pkg, **kw):
     d = pkg._lib.PeaDesc()
-    d.abi, d.ndim, d.B, d.D, d.K = 1, 2, 2, 16, 2
+    d.abi, d.ndim, d.B, d.D, d.K = pkg._lib.PEA_ABI_VERSION, 2, 2, 16, 2
     d.dims[:] = [1, 32, 48]
     d.border, d.dtype, d.norm, d.eps = 0, 0, 0, 1e-12
     d.offsets[0][:] = [0, -1, 0]
@@ -63,8 +63,9 @@ def _desc(pkg, **kw):
 def test_validate_and_workspace(pkg, lib):
     d = _desc(pkg)
     assert lib.pea_desc_validate(ctypes.byref(d)) == 0
-    # at least one f32 partial per workgroup per offset, whichever kernel shape is chosen
-    assert lib.pea_workspace_bytes(ctypes.byref(d)) >= 2 * ((32 * 48 + 255) // 256) * 2 * 4
+    # the loss-state block: 16 slots x PEA_MAX_K offsets x 4 u64 words + header, the same for every descriptor
+    assert lib.pea_workspace_bytes(ctypes.byref(d)) == 16 * 32 * 4 * 8 + 64 + 32 * 4
+    assert lib.pea_workspace_init(None, 1 << 20, None) == -1 and lib.pea_workspace_init(ctypes.c_void_p(64), 8, None) == -4
     assert lib.pea_strerror(0) == b"ok"
     for bad in (dict(abi=7), dict(K=0), dict(K=33), dict(B=0), dict(D=0), dict(border=5), dict(dtype=3), dict(norm=9),
                 dict(eps=0.0), dict(ndim=4), dict(target_bstride=-1)):
@@ -126,7 +127,7 @@ def test_cross_kernels_cover_the_shipped_2d_shapes(pkg, lib):
     stencils at CVPPP / BBBC039V1 sizes; diagonal stencils, z offsets, f16, D != 16 and narrow images take the tiled kernels"""
     def desc(D, H, W, offs, dtype=0, border=0, B=8):
         d = pkg._lib.PeaDesc()
-        d.abi, d.ndim, d.B, d.D, d.K = 1, 2, B, D, len(offs)
+        d.abi, d.ndim, d.B, d.D, d.K = pkg._lib.PEA_ABI_VERSION, 2, B, D, len(offs)
         d.dims[:] = [1, H, W]
         d.border, d.dtype, d.norm, d.eps = border, dtype, 0, 1e-12
         for i, o in enumerate(offs):

@@ -140,6 +140,7 @@ def test_inv_norm_plane_and_ex_entry_points(pkg, dev, orc, synth):
     lossv = torch.empty(1 + K, device=dev)
     wsb = L.pea_workspace_bytes(ctypes.byref(desc))
     work = torch.empty(max(wsb, 4) // 4, device=dev)
+    assert L.pea_workspace_init(ctypes.c_void_p(work.data_ptr()), wsb, None) == 0  # the loss-state block: prepared once
     assert L.pea_affinity_fwd_ex(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), P(g), P(inv1), P(lossv), P(work), wsb, st) == 0
     np.testing.assert_allclose(inv1.cpu().numpy(), ref, rtol=3e-7)
     d = orc.desc_2d(e, offsets)
@@ -176,11 +177,11 @@ def test_cross_3d_norm5_vs_oracle(pkg, dev, orc, synth, shape):
     assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL
 
 
-@pytest.mark.parametrize("with_other_loss,one_launch", [(False, True), (True, True), (True, False)])
-def test_head_backward_in_the_loss_backward_epilogue(pkg, dev, orc, synth, with_other_loss, one_launch):
-    """f1: head(x) -> embedding_loss -> backward as ONE node (pea_affinity_bwd_head: dx, dW, db leave the cross backward's
-    epilogue) against the two separate nodes, and against the oracle chain c_bwd -> np_head_bwd (float64 head restatement);
-    with_other_loss: a second loss on the embedding output, whose gradient the kernel adds before the head's backward"""
+@pytest.mark.parametrize("with_other_loss", [False, True])
+def test_head_and_loss_as_one_autograd_node(pkg, dev, orc, synth, with_other_loss):
+    """f1: head(x) -> embedding_loss -> backward as ONE node (harness/head_loss.py: four launches, no autograd bookkeeping between
+    them) against the two separate nodes, and against the oracle chain c_bwd -> np_head_bwd (float64 head restatement);
+    with_other_loss: a second loss on the embedding output, whose gradient is added before the head's backward"""
     B, C, D, H, W = 2, 32, 16, 72, 96                       # ragged in y (4.5 tiles), K = 10 shipped stencil
     offsets = pkg.multi_offset([1, 3, 5, 9, 27], neighbor=4)
     K = len(offsets)
@@ -199,8 +200,7 @@ def test_head_backward_in_the_loss_backward_epilogue(pkg, dev, orc, synth, with_
             head.conv.weight.copy_(cu(wt, dev)); head.conv.bias.copy_(cu(bs, dev))
         xt = cu(x, dev).requires_grad_(True)
         if fused:
-            loss, affs, parts, emb = pkg.head_embedding_loss(xt, head, cu(t, dev), cu(w, dev), cu(m, dev), crit, offsets,
-                                                             fused_backward=one_launch)
+            loss, affs, parts, emb = pkg.head_embedding_loss(xt, head, cu(t, dev), cu(w, dev), cu(m, dev), crit, offsets)
         else:
             emb = head(xt)
             loss, affs, parts = pkg.embedding_loss(emb, cu(t, dev), cu(w, dev), cu(m, dev), crit, offsets)
@@ -223,10 +223,6 @@ def test_head_backward_in_the_loss_backward_epilogue(pkg, dev, orc, synth, with_
         o_de = o_de + R
     o_dx, o_dw, o_db = orc.np_head_bwd(x, wt.reshape(D, C), o_de)
     assert relmax(dxf, o_dx) < GRAD_RTOL and relmax(dwf, o_dw) < GRAD_RTOL and relmax(dbf, o_db) < GRAD_RTOL
-    # the fused entry point did run (this shape is covered)
-    L = pkg._lib.lib()
-    spec = pkg.affinity_op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX)
-    assert L.pea_bwd_head_workspace_bytes(ctypes.byref(pkg.affinity_op.make_desc(spec, cu(ef, dev))), C) > 0
 
 
 @pytest.mark.parametrize("shape,shifts", [((2, 50, 100), [1, 3, 5, 9, 27]), ((1, 43, 96), [1, 3, 5, 9, 27]), ((2, 37, 72), [1, 3, 5, 9, 11])])
@@ -255,6 +251,7 @@ def test_cross_loss_with_detached_second_operand_on_the_cross_kernels(pkg, dev, 
     lossv = torch.empty(1 + K, device=dev)
     wsb = L.pea_workspace_bytes(ctypes.byref(desc))
     work = torch.empty(max(wsb, 4) // 4, device=dev)
+    assert L.pea_workspace_init(ctypes.c_void_p(work.data_ptr()), wsb, None) == 0  # the loss-state block: prepared once
     assert L.pea_affinity_fwd_ex(ctypes.byref(desc), P(E), P(EO), P(T), P(Wt), P(M), P(affs), P(g), P(inv2), P(lossv), P(work), wsb, st) == 0
     d = orc.desc_2d(e, offsets, lam)
     o_affs, o_loss = orc.c_fwd(d, e, eo, t, w, m)
@@ -316,6 +313,7 @@ def test_pair_backward_in_one_cross_launch(pkg, dev, orc, synth, shape, shifts):
     lossv = torch.empty(1 + K, device=dev)
     wsb = L.pea_workspace_bytes(ctypes.byref(d0))
     work = torch.empty(max(wsb, 4) // 4, device=dev)
+    assert L.pea_workspace_init(ctypes.c_void_p(work.data_ptr()), wsb, None) == 0  # the loss-state block: prepared once
     assert L.pea_affinity_fwd_ex(ctypes.byref(d0), P(E), None, P(T), P(Wt), P(M), P(affs), P(g0), P(inv0), P(lossv), P(work), wsb, st) == 0
     assert L.pea_affinity_fwd_ex(ctypes.byref(dx), P(E), P(EO), P(T), P(Wt), P(M), None, P(gx), P(inv2), P(lossv), P(work), wsb, st) == 0
     dl0, dlx = torch.full((), 0.6, device=dev), torch.full((), 1.7, device=dev)
@@ -329,3 +327,90 @@ def test_pair_backward_in_one_cross_launch(pkg, dev, orc, synth, shape, shifts):
     assert relmax(de_c.cpu().numpy(), ref) < GRAD_RTOL
     if rc_t == 0:
         assert relmax(de_t.cpu().numpy(), ref) < GRAD_RTOL and relmax(de_c.cpu().numpy(), de_t.cpu().numpy()) < 2e-5
+
+
+def test_second_operand_that_aliases_the_first(pkg, dev, orc, synth):
+    """ema_embedding_loss(e, e.detach(), ..) -- an EMA tensor that IS the embedding's storage: the forward has the values of the self
+    loss, the backward is role A only (the second operand is detached).  Round 2 took the self path in the forward (one 1 / norm
+    plane written) and the second-operand path in the backward (which reads the second plane): an uninitialised plane scaled the
+    gradient.  Both planes must be filled, through the C ABI and through the Python mirror."""
+    B, D, H, W = 2, 16, 50, 100
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    K = len(offsets)
+    e, t, w, m = _inputs(synth, B, D, [1, H, W], K, 33)
+    e, t, w, m = e[:, :, 0], t[:, :, 0], w[:, :, 0], m[:, :, 0]
+    op, L = pkg.affinity_op, pkg._lib.lib()
+    E, T, Wt, M = cu(e, dev), cu(t, dev), cu(w, dev), cu(m, dev)
+    spec = op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX)
+    desc = op.make_desc(spec, E)
+    P = lambda x: ctypes.c_void_p(x.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    affs, g = torch.empty(B, K, H, W, device=dev), torch.empty(B, K, H, W, device=dev)
+    inv2 = torch.full((2, B, H, W), float("nan"), device=dev)
+    lossv = torch.empty(1 + K, device=dev)
+    work, wsb = op.workspace(dev, desc)
+    assert L.pea_affinity_fwd_ex(ctypes.byref(desc), P(E), P(E), P(T), P(Wt), P(M), P(affs), P(g), P(inv2), P(lossv), P(work), wsb, st) == 0
+    assert torch.equal(inv2[0], inv2[1]) and bool(torch.isfinite(inv2).all())
+    d = orc.desc_2d(e, offsets)
+    o_affs, o_loss = orc.c_fwd(d, e, e.copy(), t, w, m)
+    o_de, _ = orc.c_bwd(d, e, e.copy(), t, w, m, dloss=1.0)          # role A only
+    o_self, _ = orc.c_bwd(d, e, None, t, w, m, dloss=1.0)           # both roles: a different gradient
+    assert relmax(o_de, o_self) > 1e-2
+    assert np.abs(affs.cpu().numpy() - o_affs).max() < AFFS_ATOL
+    de = torch.empty_like(E)
+    assert L.pea_affinity_bwd_ex(ctypes.byref(desc), P(E), P(E), P(g), P(inv2), None, P(de), None, st) == 0
+    assert relmax(de.cpu().numpy(), o_de) < GRAD_RTOL
+    x = E.clone().requires_grad_(True)
+    loss, a = pkg.ema_embedding_loss(x, x.detach(), T, Wt, M, pkg.WeightedMSE(), offsets)
+    loss.backward()
+    assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * abs(o_loss[0])
+    assert relmax(x.grad.cpu().numpy(), o_de) < GRAD_RTOL
+    # PEA_FLAG_ACCUMULATE_DE has no meaning for a self loss: refused, not ignored
+    dacc = __import__("copy").copy(desc)
+    dacc.flags |= pkg._lib.FLAG_ACCUMULATE_DE
+    assert L.pea_affinity_bwd_ex(ctypes.byref(dacc), P(E), None, P(g), P(inv2), None, P(de), None, st) == pkg._lib.E_UNSUPPORTED
+
+
+def test_loss_state_contract(pkg, dev, orc, synth, monkeypatch):
+    """the loss is summed in integers in a state block (csrc/pea_loss.h): a block that was never prepared gives NaN, a prepared one
+    the oracle's loss -- identically whether the forward finishes the sum itself (ticket) or a second launch does, whichever
+    forward kernel runs (3 / 2 workgroups per CU, tiled, direct), call after call on the same block"""
+    B, D, H, W = 3, 16, 80, 128
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    K = len(offsets)
+    e, t, w, m = _inputs(synth, B, D, [1, H, W], K, 71)
+    e, t, w, m = e[:, :, 0], t[:, :, 0], w[:, :, 0], m[:, :, 0]
+    op, L = pkg.affinity_op, pkg._lib.lib()
+    E, T, Wt, M = cu(e, dev), cu(t, dev), cu(w, dev), cu(m, dev)
+    spec = op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX)
+    desc = op.make_desc(spec, E)
+    P = lambda x: ctypes.c_void_p(x.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    wsb = L.pea_workspace_bytes(ctypes.byref(desc))
+    raw = torch.full((wsb // 4,), 1.0e-3, device=dev)      # garbage, not initialised
+    lossv = torch.zeros(1 + K, device=dev)
+    for ticket in ("0", "1"):                               # either finish says so
+        monkeypatch.setenv("PEA_LOSS_TICKET", ticket)
+        lossv.zero_()
+        assert L.pea_affinity_fwd_ex(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), None, None, None, P(lossv), P(raw), wsb, st) == 0
+        assert bool(torch.isnan(lossv).all())
+    monkeypatch.delenv("PEA_LOSS_TICKET")
+    assert L.pea_workspace_init(P(raw), wsb, st) == 0
+    d = orc.desc_2d(e, offsets)
+    _, o_loss = orc.c_fwd(d, e, None, t, w, m)
+    seen = []
+    for switches in ({}, {"PEA_LOSS_TICKET": "1"}, {"PEA_FWD_WG3": "0"}, {"PEA_FWD_XDMA": "0"}, {"PEA_FORCE_DIRECT": "1"}):
+        for k_, v_ in switches.items():
+            monkeypatch.setenv(k_, v_)
+        for _ in range(2):
+            lossv.zero_()
+            assert L.pea_affinity_fwd_ex(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), None, None, None, P(lossv), P(raw), wsb, st) == 0
+            got = lossv.cpu().numpy().astype(np.float64)
+            np.testing.assert_allclose(got[1:] , o_loss[1:], rtol=LOSS_RTOL)
+            assert abs(got[0] - o_loss[0]) <= LOSS_RTOL * abs(o_loss[0])
+            seen.append((tuple(sorted(switches)), got))
+        for k_ in switches:
+            monkeypatch.delenv(k_)
+    # the two finishes (and the two occupancies of the same cross kernel) add the same integers: bit-identical
+    for i in range(1, 6):
+        assert np.array_equal(seen[0][1], seen[i][1]), seen[i][0]
