@@ -68,19 +68,35 @@ def train_leg(pkg, dev, world, rank, dist, shared, fence, b=2, steps=8, warm=3):
     ts = importlib.import_module(ge.PKG_NAME + ".harness.train_step")
     synth = importlib.import_module(ge.PKG_NAME + ".utils.synth")
     torch.manual_seed(555)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    x = torch.randn(b, 3, H, W, generator=g, device=dev)
+    x_ema = x + 0.1 * torch.randn(b, 3, H, W, generator=g, device=dev)
+    labels = torch.from_numpy(synth.synth_labels(b, (1, H, W), 555 + rank)[:, 0].copy()).to(dev).to(torch.int32)
     net = mod.ResidualUNet2D_deep(in_channels=3, out_channels=2, nfeatures=[16, 32, 64, 128, 256], emd=16).to(dev)
     model = net
     if dist is not None:
+        # A rank that fails inside the DDP loop (out of memory, a shape the heads do not cover) would leave the others blocked in the
+        # gradient all-reduce until the RCCL timeout, and the headline line would never be printed.  So every rank first runs ONE
+        # step of its own, without any collective, and the ranks agree on the outcome before the reducer is built.
+        ok = torch.ones(1, dtype=torch.int32, device="cpu" if shared else dev)
+        err = None
+        try:
+            ts.CvpppTrainStep(net, ts.make_optimizer(net)).step(x, x_ema, labels)
+            torch.cuda.synchronize()
+        except Exception as ex:  # noqa: BLE001 -- reported, and the leg is dropped on every rank
+            ok.zero_()
+            err = ex
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            raise RuntimeError("train leg dropped on every rank: a rank failed its local step (%r)" % (err,))
+        torch.manual_seed(555)
+        net = mod.ResidualUNet2D_deep(in_channels=3, out_channels=2, nfeatures=[16, 32, 64, 128, 256], emd=16).to(dev)
         from torch.nn.parallel import DistributedDataParallel as DDP
         # the mask head takes no part in the shipped loss (mask_weight / ct_weight 0): its parameters never get a gradient
         DDP._set_params_and_buffers_to_ignore_for_model(net, [n for n, _ in net.named_parameters() if n.startswith("binary_seg.")]
                                                         + [n for n, _ in net.named_buffers() if n.startswith("binary_seg.")])
         model = DDP(net, device_ids=None if shared else [dev.index], broadcast_buffers=False, gradient_as_bucket_view=True)
     stepper = ts.CvpppTrainStep(model, ts.make_optimizer(net))
-    g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    x = torch.randn(b, 3, H, W, generator=g, device=dev)
-    x_ema = x + 0.1 * torch.randn(b, 3, H, W, generator=g, device=dev)
-    labels = torch.from_numpy(synth.synth_labels(b, (1, H, W), 555 + rank)[:, 0].copy()).to(dev).to(torch.int32)
     for _ in range(warm):
         stepper.step(x, x_ema, labels)
     fence()
@@ -176,7 +192,8 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
         "kernel_ms": {"fwd": round(kf, 5), "bwd": round(kb, 5)},
         "cross_kernels": {"fwd": int(L.pea_cross_supported(ctypes.byref(desc), 0)), "bwd": int(L.pea_cross_supported(ctypes.byref(desc), 1))},
         "roofline": {"bound": "hbm", "kernel": "pea_affinity_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_px": ab[dom], "px_per_launch": npx,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.config, dom) if B == c["B"] else None,
+                     "algorithmic_bytes_per_px": ab[dom], "px_per_launch": npx,
                      "ms": round(max(kf, kb), 5), "fwd_plus_bwd_GBs": round(step_gbs, 1), "fwd_plus_bwd_frac": round(step_gbs / HBM_PEAK_GBS, 4)},
     }
     if world == 1 and not args.no_cpu_baseline:
@@ -217,6 +234,17 @@ def in_step_times_ms(fwd, bwd, iters):
         c.record(s)
     ev[-1][2].synchronize()
     return (sum(a.elapsed_time(b) for a, b, _ in ev) / iters, sum(b.elapsed_time(c) for _, b, c in ev) / iters)
+
+
+def pmc_traffic(key, dom):
+    """PMC-measured HBM bytes per launch of the dominant entry point's kernel, recorded by profiles/make_traffic.py from a
+    rocprofv3 --pmc run of THESE sources (null when the kernel sources changed since)"""
+    tpath = os.path.join(ge.ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    tj = json.load(open(tpath))
+    rec = tj.get(key, {}).get(dom)
+    return rec.get("bytes_per_launch") if rec and tj.get("src_sha16") == source_sha16() else None
 
 
 def source_sha16():
@@ -276,27 +304,44 @@ def cpu_baseline(offsets, e, t, w, m, budget_s=20.0, shifts3d=None, what=None):
     what = what or "the same B=%d x %d x %dx%d K=%d batch" % (et.shape[0], et.shape[1], et.shape[2], et.shape[3], len(offsets))
     out = {"value": round(px / dt / 1e6, 4), "unit": "Mpx/s", "cores": cores, "kind": "port",
            "sample": "%d timed fwd+bwd iterations (after 1 warm-up) of %s, oracle/pea_oracle.py torch restatement, %.2f s/iter" % (iters, what, dt)}
-    if shifts3d is None:
-        # the same arithmetic as one scalar C thread (oracle/pea_oracle.c: fused loops, no temporaries) and as one torch thread,
-        # on the first image: what a single core of the host does (BASELINE.md section 3 asks for the 1-thread lines)
-        e1, t1, w1 = (np.ascontiguousarray(x[:1].numpy()) for x in (et, tt, wt))
-        m1 = None if mt is None else np.ascontiguousarray(mt[:1].numpy())
-        d = orc.desc_2d(e1, offsets)
+    # the same arithmetic as the oracle's C restatement (oracle/pea_oracle.c: fused loops, no temporaries): one scalar thread, and
+    # OpenMP over all host cores -- SURVEY.md section 8d's "second, stronger CPU line"; speedup_vs_cpu is quoted against the FASTER
+    # of the torch port and this one
+    en, tn, wn = (np.ascontiguousarray(x.numpy()) for x in (et, tt, wt))
+    mn = None if mt is None else np.ascontiguousarray(mt.numpy())
+    d = orc.desc_3d(en, shifts3d) if shifts3d is not None else orc.desc_2d(en, offsets)
+
+    def c_once(sl):
         t0 = time.perf_counter()
-        orc.c_fwd(d, e1, None, t1, w1, m1)
-        orc.c_bwd(d, e1, None, t1, w1, m1)
-        dc = time.perf_counter() - t0
-        out["c_1thread"] = {"value": round(e1[0, 0].size / dc / 1e6, 4), "unit": "Mpx/s", "cores": 1, "kind": "port",
-                            "sample": "one fwd + bwd of 1 image, oracle/pea_oracle.c, %.2f s" % dc}
+        orc.c_fwd(d if sl is None else d1, en[sl] if sl is not None else en, None, tn[sl] if sl is not None else tn,
+                  wn[sl] if sl is not None else wn, None if mn is None else (mn[sl] if sl is not None else mn))
+        orc.c_bwd(d if sl is None else d1, en[sl] if sl is not None else en, None, tn[sl] if sl is not None else tn,
+                  wn[sl] if sl is not None else wn, None if mn is None else (mn[sl] if sl is not None else mn))
+        return time.perf_counter() - t0
+
+    prev = orc.c_set_threads(cores)
+    c_once(None)  # warm-up (thread pool)
+    dco = min(c_once(None) for _ in range(2))
+    out["c_omp"] = {"value": round(px / dco / 1e6, 4), "unit": "Mpx/s", "cores": cores, "kind": "port",
+                    "sample": "best of 2 fwd + bwd of %s, oracle/pea_oracle.c with OpenMP (%d threads), %.2f s" % (what, cores, dco)}
+    if shifts3d is None:
+        sl = slice(0, 1)
+        d1 = orc.desc_2d(en[sl], offsets)
+        orc.c_set_threads(1)
+        dc = c_once(sl)
+        out["c_1thread"] = {"value": round(en[0, 0].size / dc / 1e6, 4), "unit": "Mpx/s", "cores": 1, "kind": "port",
+                            "sample": "one fwd + bwd of 1 image, oracle/pea_oracle.c, 1 thread, %.2f s" % dc}
         torch.set_num_threads(1)
         et1, tt1, wt1, mt1 = et[:1], tt[:1], wt[:1], (None if mt is None else mt[:1])
         t0 = time.perf_counter()
         x = et1.clone().requires_grad_(True)
         orc.torch_embedding_loss(x, tt1, wt1, mt1, offsets)[0].backward()
-        d1 = time.perf_counter() - t0
+        d1t = time.perf_counter() - t0
         torch.set_num_threads(cores)
-        out["torch_1thread"] = {"value": round(e1[0, 0].size / d1 / 1e6, 4), "unit": "Mpx/s", "cores": 1, "kind": "port",
-                                "sample": "one fwd + bwd of 1 image, torch restatement with 1 thread, %.2f s" % d1}
+        out["torch_1thread"] = {"value": round(en[0, 0].size / d1t / 1e6, 4), "unit": "Mpx/s", "cores": 1, "kind": "port",
+                                "sample": "one fwd + bwd of 1 image, torch restatement with 1 thread, %.2f s" % d1t}
+    orc.c_set_threads(prev)
+    out["best_cpu_value"] = max(out["value"], out["c_omp"]["value"])
     return out
 
 
@@ -429,9 +474,15 @@ def main():
         cnt_bytes = L.pea_targets_workspace_bytes(ctypes.byref(desc))
         cnt = torch.empty(cnt_bytes // 4, dtype=torch.int32, device=dev)
         lflags = pkg._lib.TGT_PADDING | pkg._lib.TGT_MASK_INSIDE
+        lsb = L.pea_labels_scratch_bytes(ctypes.byref(desc))  # g + 1 / norm plane lent to the two-launch labels step
+        lscr = torch.empty(max(lsb, 4) // 4, device=dev)
         labels_step = lambda: (L.pea_label_weights(ctypes.byref(desc), P(lab), lflags, P(wtab), P(cnt), cnt_bytes, st),
-                               L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(Ed), None, P(lab), P(wtab), lflags, P(affs),
-                                                             P(lossv), None, P(dE), P(work), wsb, st))
+                               L.pea_affinity_fwd_bwd_labels_ex(ctypes.byref(desc), P(Ed), None, P(lab), P(wtab), lflags, P(affs),
+                                                                P(lossv), None, P(dE), P(work), wsb, P(lscr), lsb, st))
+        labels_one = lambda: L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(Ed), None, P(lab), P(wtab), lflags, P(affs),
+                                                           P(lossv), None, P(dE), P(work), wsb, st)
+        labels_two = lambda: L.pea_affinity_fwd_bwd_labels_ex(ctypes.byref(desc), P(Ed), None, P(lab), P(wtab), lflags, P(affs),
+                                                              P(lossv), None, P(dE), P(work), wsb, P(lscr), lsb, st)
         # the embedding head in front of the path (OutConv 32 -> D, scripts_cvppp/model/unet2d_residual.py:307): forward and
         # backward (dx, dW, db) of the 1x1 convolution on the decoder's 32-channel feature map
         HC = 32
@@ -444,6 +495,7 @@ def main():
         head_bwd = lambda: L.pea_head_bwd(B, HC, D, H * W, P(hx), P(hw), P(dE), P(hdx), P(hdw), P(hdb), P(hwork), hws, st)
         kt = {}
         for name, fn in (("fwd", fwd), ("bwd", bwd), ("infer", inf), ("labels_step", labels_step),
+                         ("labels_one_launch", labels_one), ("labels_two_launch", labels_two),
                          ("head_fwd", head_fwd), ("head_bwd", head_bwd)):
             event_time_ms(fn, 10)
             kt[name] = event_time_ms(fn, max(20, min(args.steps, 200)))
@@ -493,13 +545,7 @@ def main():
         launch_bytes = ab[dom] * B * H * W
         achieved = launch_bytes / (kt[dom] * 1e-3) / 1e9
         step_gbs = ab["step"] * B * H * W / ((kt["fwd"] + kt["bwd"]) * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ge.ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):  # PMC-measured HBM bytes per launch, recorded from a rocprofv3 --pmc run of THESE sources
-            tj = json.load(open(tpath))
-            rec = tj.get(dom + "_b%d" % B)
-            if rec and tj.get("src_sha16") == source_sha16():
-                traffic = rec.get("bytes_per_launch")
+        traffic = pmc_traffic("c2", dom) if B == B_PER_GPU else None
         out = {
             "metric": "affinity-map Mpixels/sec (fwd+bwd)", "value": round(value, 2), "unit": "Mpx/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
@@ -527,7 +573,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(offsets, e, t, w, m)
-            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["best_cpu_value"], 1)  # vs the faster CPU line
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

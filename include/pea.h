@@ -127,7 +127,7 @@ size_t pea_workspace_bytes(const PeaDesc *desc);
 int pea_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
 
 /* Re-read the PEA_* environment switches (they are read once, at the first call): PEA_FORCE_DIRECT, PEA_FWD_XDMA, PEA_BWD_XDMA,
- * PEA_LABELS_DUAL, PEA_LOSS_TICKET, PEA_FWD_WG3 -- A/B and debugging switches; tests that change one call this. */
+ * PEA_LABELS_DUAL, PEA_FWD_WG3 -- A/B and debugging switches; tests that change one call this. */
 void pea_reload_env(void);
 
 /* Inference: affs[B,K,Z,Y,X] only.  e_other may be NULL. */
@@ -241,6 +241,16 @@ int pea_label_weights(const PeaDesc *desc, const int32_t *labels, unsigned flags
 int pea_affinity_fwd_bwd_labels(const PeaDesc *desc, const void *e, const void *e_other, const int32_t *labels,
                                 const float *wtab, unsigned flags, float *affs, float *loss_out, const float *dloss, void *de,
                                 void *workspace, size_t workspace_bytes, void *stream);
+/* The same with a SCRATCH buffer lent by the caller (pea_labels_scratch_bytes(desc) bytes, 16-byte aligned, contents undefined
+ * before and after; 0 = this descriptor has no use for it): where the LDS-DMA cross kernels cover the descriptor (self loss, 2D,
+ * f32, D = 16 / 32, axis-aligned stencil of at most 10 offsets) the step then runs as TWO launches on them -- a labels-in forward
+ * that writes g and the 1 / norm plane into the scratch (no target / weight / mask traffic: 4D + 8K + 8 bytes per pixel) and the
+ * cross backward -- instead of the one-launch box kernel: 70 + 94 us against 202 us at B=8 x 16 x 544^2.  Same results (to
+ * rounding).  scratch == NULL, a second operand, PEA_TGT_ACCUMULATE, or any other descriptor: exactly pea_affinity_fwd_bwd_labels. */
+size_t pea_labels_scratch_bytes(const PeaDesc *desc);
+int pea_affinity_fwd_bwd_labels_ex(const PeaDesc *desc, const void *e, const void *e_other, const int32_t *labels,
+                                   const float *wtab, unsigned flags, float *affs, float *loss_out, const float *dloss, void *de,
+                                   void *workspace, size_t workspace_bytes, void *scratch, size_t scratch_bytes, void *stream);
 
 /* The full-resolution pair of the training loop in ONE launch: the self loss (desc) and the detached-EMA cross loss
  * (desc_cross: same geometry and stencil, its own lambda / normaliser) of the same embedding and labels

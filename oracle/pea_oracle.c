@@ -116,7 +116,7 @@ int pea_oracle_fwd(const PeaDesc *d, const float *e, const float *e_other, const
   double total = 0.0;
   for (int i = 0; i < d->K; ++i) {
     double acc = 0.0;
-#pragma omp parallel for collapse(2) schedule(static) reduction(+ : acc)
+#pragma omp parallel for collapse(3) schedule(static) reduction(+ : acc)
     for (long b = 0; b < d->B; ++b)
       for (long z = 0; z < g.Z; ++z)
         for (long y = 0; y < g.Y; ++y)
@@ -235,7 +235,7 @@ int pea_oracle_bwd(const PeaDesc *d, const float *e, const float *e_other, const
     const float *src = pass == 0 ? e : e_other;
     const float *sh = pass == 0 ? eh : oh;
     float *dst = pass == 0 ? de : de_other;
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(3) schedule(static)
     for (long b = 0; b < d->B; ++b)
       for (long z = 0; z < g.Z; ++z)
         for (long y = 0; y < g.Y; ++y)
@@ -286,3 +286,16 @@ int pea_oracle_bwd(const PeaDesc *d, const float *e, const float *e_other, const
 }
 
 int pea_oracle_version(void) { return PEA_ABI_VERSION; }
+
+/* OpenMP threads of the loops above (rows of every (b, z) plane are shared out: collapse(3)); returns the previous maximum.
+ * bench.py's cpu_baseline times the oracle with 1 thread and with all host cores (the stronger CPU line). */
+#ifdef _OPENMP
+#include <omp.h>
+int pea_oracle_set_threads(int n) {
+  const int old = omp_get_max_threads();
+  if (n > 0) omp_set_num_threads(n);
+  return old;
+}
+#else
+int pea_oracle_set_threads(int n) { (void)n; return 1; }
+#endif

@@ -123,6 +123,14 @@ def _c(a, dt):
     return None if a is None else np.ascontiguousarray(a, dtype=dt)
 
 
+def c_set_threads(n):
+    """OpenMP threads of the C restatement (pea_oracle_set_threads); returns the previous maximum"""
+    L = lib()
+    L.pea_oracle_set_threads.restype = ctypes.c_int
+    L.pea_oracle_set_threads.argtypes = [ctypes.c_int]
+    return int(L.pea_oracle_set_threads(int(n)))
+
+
 def c_fwd(desc, e, e_other=None, target=None, weight=None, mask=None, want_affs=True):
     """-> (affs or None, loss_vec float64[1+K] or None)"""
     e, e_other = _c(e, np.float32), _c(e_other, np.float32)

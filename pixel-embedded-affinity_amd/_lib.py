@@ -28,7 +28,8 @@ EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_by
            "pea_cross_supported", "pea_affinity_bwd_dual", "pea_affinity_bwd_dual_ex", "pea_scale_inplace", "pea_scale_inplace_multi",
            "pea_fill_border_relu", "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd",
            "pea_targets_workspace_bytes", "pea_gen_targets", "pea_stitch_add", "pea_stitch_finalize",
-           "pea_label_weights", "pea_affinity_fwd_bwd_labels", "pea_affinity_fwd_bwd_labels_dual")
+           "pea_label_weights", "pea_affinity_fwd_bwd_labels", "pea_affinity_fwd_bwd_labels_ex", "pea_labels_scratch_bytes",
+           "pea_affinity_fwd_bwd_labels_dual")
 
 
 class PeaLibraryError(RuntimeError):
@@ -167,6 +168,10 @@ def lib():
     L.pea_label_weights.argtypes = [dp, vp, ctypes.c_uint, vp, vp, ctypes.c_size_t, vp]
     L.pea_affinity_fwd_bwd_labels.restype = ctypes.c_int
     L.pea_affinity_fwd_bwd_labels.argtypes = [dp, vp, vp, vp, vp, ctypes.c_uint, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.pea_affinity_fwd_bwd_labels_ex.restype = ctypes.c_int
+    L.pea_affinity_fwd_bwd_labels_ex.argtypes = [dp, vp, vp, vp, vp, ctypes.c_uint, vp, vp, vp, vp, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp]
+    L.pea_labels_scratch_bytes.restype = ctypes.c_size_t
+    L.pea_labels_scratch_bytes.argtypes = [dp]
     L.pea_affinity_fwd_bwd_labels_dual.restype = ctypes.c_int
     L.pea_affinity_fwd_bwd_labels_dual.argtypes = [dp, dp, vp, vp, vp, vp, ctypes.c_uint, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.pea_stitch_add.restype = ctypes.c_int

@@ -413,6 +413,9 @@ def _labels_int32(labels):
     return labels.to(torch.int32).contiguous()
 
 
+LABELS_TWO_LAUNCH_MIN_PX = 1 << 18  # B * pixels from which the two-launch labels step (pea_affinity_fwd_bwd_labels_ex) pays
+
+
 class LabelsStepUnsupported(NotImplementedError):
     """pea_affinity_fwd_bwd_labels has no kernel for the descriptor; the *_from_labels wrappers then generate the
     target / mask / weight tensors on the GPU (pea_gen_targets) and take the tensor path -- same results."""
@@ -452,8 +455,16 @@ class LabelsAffinityMSE(torch.autograd.Function):
             _lib.check(L.pea_label_weights(ctypes.byref(d), _ptr(lab), flags, _ptr(wtab), _ptr(counts), cb, _stream()), "pea_label_weights")
             work, wsb = workspace(e_c.device, d)
             de_unit = torch.empty_like(e_c)
-            rc = L.pea_affinity_fwd_bwd_labels(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(lab), _ptr(wtab), flags, _ptr(affs) if need_affs else None,
-                                               _ptr(loss_vec), None, _ptr(de_unit), _ptr(work), wsb, _stream())
+            # large self losses on the cross kernels: two launches (labels-in forward + cross backward) through a scratch buffer
+            # for g and the 1 / norm plane; small ones are launch-bound and keep the one-launch kernel
+            scratch, sb = None, 0
+            if o_c is None and e_c.numel() // e_c.shape[1] >= LABELS_TWO_LAUNCH_MIN_PX:
+                sb = int(L.pea_labels_scratch_bytes(ctypes.byref(d)))
+                if sb:
+                    scratch = torch.empty(sb // 4, dtype=torch.float32, device=e_c.device)
+            rc = L.pea_affinity_fwd_bwd_labels_ex(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(lab), _ptr(wtab), flags,
+                                                  _ptr(affs) if need_affs else None, _ptr(loss_vec), None, _ptr(de_unit), _ptr(work), wsb,
+                                                  _ptr(scratch), sb, _stream())
             if rc == _lib.E_UNSUPPORTED:
                 raise LabelsStepUnsupported("no labels-in kernel for this descriptor (D != 16, image smaller than a tile, "
                                             "stencil too wide): use gen_targets + the tensor API")

@@ -84,10 +84,8 @@ constexpr size_t kStateBytes = sizeof(LossState);
 // forward dispatch.  Returns PEA_OK or an error; the loss (training) is complete in stream order when it returns.
 int run_fwd(const KParams& P, FwdArgs A, hipStream_t s) {
   const bool self = A.eo == A.e;
-  bool launched = false, finished = false;
-  if (A.train) {
-    launched = self ? xdma_fwd_self(P, A, s, &finished) : xdma_fwd_other(P, A, s, &finished);
-  }
+  bool launched = false;
+  if (A.train) launched = self ? xdma_fwd_self(P, A, s) : xdma_fwd_other(P, A, s);
   if (!launched) {
     // 1 / norm planes: the tiled D = 16 self forward writes its plane while it stages; everything else gets k_inv_norm
     float* inv = A.inv_out;
@@ -103,7 +101,7 @@ int run_fwd(const KParams& P, FwdArgs A, hipStream_t s) {
   }
   int rc = hip_rc();
   if (rc) return rc;
-  if (A.train && !finished) {
+  if (A.train) {
     launch_loss_finish(P, A.st, A.loss_out, s);
     rc = hip_rc();
   }
@@ -279,21 +277,50 @@ int pea_label_weights(const PeaDesc* desc, const int32_t* labels, unsigned flags
   return label_weights(desc, labels, flags, wtab, workspace, (hipStream_t)stream);
 }
 
-int pea_affinity_fwd_bwd_labels(const PeaDesc* desc, const void* e, const void* e_other, const int32_t* labels,
-                                const float* wtab, unsigned flags, float* affs, float* loss_out, const float* dloss, void* de,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+size_t pea_labels_scratch_bytes(const PeaDesc* desc) {
+  if (validate(desc)) return 0;
+  const KParams P = make_params(desc);
+  if (!xdma_labels_supported(P, desc->dtype)) return 0;
+  return ((size_t)(P.K + 1) * P.B * P.S * sizeof(float) + 15) & ~(size_t)15;
+}
+
+int pea_affinity_fwd_bwd_labels_ex(const PeaDesc* desc, const void* e, const void* e_other, const int32_t* labels,
+                                   const float* wtab, unsigned flags, float* affs, float* loss_out, const float* dloss, void* de,
+                                   void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, void* stream) {
   int rc = validate(desc);
   if (rc) return rc;
   if (!e || !labels || !wtab || !loss_out || !de) return PEA_E_NULL;
   const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
   if (misaligned(e, es) || misaligned(e_other, es) || misaligned(de, es) || misaligned(affs, 4) || misaligned(labels, 4) ||
-      misaligned(wtab, 4) || misaligned(loss_out, 4) || misaligned(dloss, 4) || misaligned(workspace, 8))
+      misaligned(wtab, 4) || misaligned(loss_out, 4) || misaligned(dloss, 4) || misaligned(workspace, 8) || misaligned(scratch, 16))
     return PEA_E_ALIGN;
   if (flags & ~(PEA_TGT_PADDING | PEA_TGT_BOTH_FOREGROUND | PEA_TGT_MASK_INSIDE | PEA_TGT_ACCUMULATE)) return PEA_E_DESC;
   const KParams P = make_params(desc);
   if (!workspace || workspace_bytes < kStateBytes) return PEA_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   LossState* st = (LossState*)workspace;
+  // Two launches on the cross kernels where they apply and the caller lent the scratch for g and the 1 / norm plane: the
+  // labels-in forward (k_fwd_xdma<.., LAB>: 360 MB instead of the tensor forward's 596) and the cross backward -- 70 + 94 us
+  // against 202 us for the one-launch box kernel, whose single workgroup per CU and far gathers the cross structure avoids.
+  // (The one-launch form on the cross structure would stage every channel pair twice -- the dot products need all channels
+  // before the first coefficient exists -- i.e. twice the backward's L2 -> LDS traffic, which is what bounds it.)
+  if (scratch && !e_other && !(flags & PEA_TGT_ACCUMULATE) && scratch_bytes >= pea_labels_scratch_bytes(desc) &&
+      xdma_labels_supported(P, desc->dtype)) {
+    float* g = (float*)scratch;
+    float* inv = g + (size_t)P.K * P.B * P.S;
+    FwdArgs A = {};
+    A.e = e; A.eo = e; A.affs = affs; A.gout = g; A.st = st; A.loss_out = loss_out; A.inv_out = inv;
+    A.dtype = desc->dtype; A.train = true;
+    if (xdma_fwd_labels(P, A, labels, wtab, flags, s)) {
+      rc = hip_rc();
+      if (rc) return rc;
+      launch_loss_finish(P, st, loss_out, s);
+      if (!xdma_bwd_self(P, (const float*)e, inv, g, dloss, (float*)de, s)) return run_bwd(P, desc->dtype, 3, e, e, e, g, dloss, de, s);
+      return hip_rc();
+    }
+    rc = hip_rc();
+    if (rc) return rc;
+  }
   if (!labels_step(P, desc->dtype, e, e_other, labels, wtab, flags, affs, st, dloss, de, s)) {
     const int pe = hip_rc();
     return pe ? pe : PEA_E_UNSUPPORTED;
@@ -302,6 +329,13 @@ int pea_affinity_fwd_bwd_labels(const PeaDesc* desc, const void* e, const void* 
   if (rc) return rc;
   launch_loss_finish(P, st, loss_out, s);
   return hip_rc();
+}
+
+int pea_affinity_fwd_bwd_labels(const PeaDesc* desc, const void* e, const void* e_other, const int32_t* labels,
+                                const float* wtab, unsigned flags, float* affs, float* loss_out, const float* dloss, void* de,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  return pea_affinity_fwd_bwd_labels_ex(desc, e, e_other, labels, wtab, flags, affs, loss_out, dloss, de, workspace, workspace_bytes,
+                                        nullptr, 0, stream);
 }
 
 int pea_affinity_fwd_bwd_labels_dual(const PeaDesc* desc, const PeaDesc* desc_cross, const void* e, const void* ema,

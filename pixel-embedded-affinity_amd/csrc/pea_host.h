@@ -23,9 +23,6 @@ struct Env {
   int fwd_xdma;       // PEA_FWD_XDMA=0: no LDS-DMA forward
   int bwd_xdma;       // PEA_BWD_XDMA=0: no LDS-DMA backward
   int labels_dual;    // PEA_LABELS_DUAL=0: pea_affinity_fwd_bwd_labels_dual reports PEA_E_UNSUPPORTED
-  int loss_ticket;    // PEA_LOSS_TICKET=1: finish the loss inside the cross forward (last-ticket workgroup) instead of by a second,
-                      // tiny launch.  Off by default: measured equal in the step (114.8 us either way) and 3x SLOWER under
-                      // rocprofv3 (331 us: 4624 returning atomics on one word while the profiler serialises dispatches)
   int fwd_wg3;        // PEA_FWD_WG3=0: the 2-workgroups-per-CU forward
 };
 const Env& env();
@@ -98,9 +95,11 @@ struct FwdArgs {
   int dtype;            // PEA_F32 / PEA_F16
   bool train;
 };
-// Each returns true if it launched.  `finished`: the kernel finishes the loss itself (no launch_loss_finish needed).
-bool xdma_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s, bool* finished);
-bool xdma_fwd_other(const KParams& P, const FwdArgs& A, hipStream_t s, bool* finished);   // inv_out: two planes
+// Each returns true if it launched (the caller then launches the loss finish).
+bool xdma_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s);
+bool xdma_fwd_other(const KParams& P, const FwdArgs& A, hipStream_t s);   // inv_out: two planes
+bool xdma_labels_supported(const KParams& P, int dtype);
+bool xdma_fwd_labels(const KParams& P, const FwdArgs& A, const int32_t* labels, const float* wtab, unsigned lflags, hipStream_t s);
 bool tiled_fwd(const KParams& P, const FwdArgs& A, hipStream_t s, bool* wrote_inv);      // k_fwd_tiled_v / k_fwd_tiled / chunked
 void direct_fwd(const KParams& P, const FwdArgs& A, hipStream_t s);
 void launch_inv_norm(const KParams& P, int dtype, const void* e, float* inv, hipStream_t s);

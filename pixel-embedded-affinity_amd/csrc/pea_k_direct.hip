@@ -29,7 +29,6 @@ void env_load() {
   g_env.fwd_xdma = env_int("PEA_FWD_XDMA", 1);
   g_env.bwd_xdma = env_int("PEA_BWD_XDMA", 1);
   g_env.labels_dual = env_int("PEA_LABELS_DUAL", 1);
-  g_env.loss_ticket = env_int("PEA_LOSS_TICKET", 0);
   g_env.fwd_wg3 = env_int("PEA_FWD_WG3", 1);
 }
 }  // namespace

@@ -27,7 +27,7 @@ bool plan(const KParams& P, int psu, int mode, XPlan* out) {
   }
 
 template <int D_T, bool TRAIN>
-bool fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s, bool* finished) {
+bool fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s) {
   const float *e = (const float*)A.e, *t = A.t, *w = A.w;
   if (misaligned(e, 16) || misaligned(t, 16) || misaligned(w, 16) || misaligned(A.affs, 16) || misaligned(A.gout, 16) ||
       misaligned(A.m, 4) || misaligned(A.inv_out, 4))
@@ -45,13 +45,11 @@ bool fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s, bool* finished)
   if (z3 && P.K > kXP + 2) return false;
   const XParams& C = X.C;
   const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
-  float* fin = (TRAIN && env().loss_ticket) ? A.loss_out : nullptr;
-  *finished = fin != nullptr;
 #define PEA_XF(CROP_, PSU_, ZF_, WPE_)                                                                                      \
   {                                                                                                                         \
     constexpr auto kern = k_fwd_xdma<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, TRAIN, ZF_, false, WPE_>;                          \
-    PEA_LAUNCH(kern, grid, blk, X.lds, s, P, C, e, t, w, A.m, A.affs, A.gout, A.st, fin, A.inv_out, (const float*)nullptr,  \
-               (float*)nullptr)                                                                                             \
+    PEA_LAUNCH(kern, grid, blk, X.lds, s, P, C, e, t, w, A.m, A.affs, A.gout, A.st, A.inv_out, (const float*)nullptr,       \
+               (float*)nullptr, LabArgs{})                                                                                  \
   }
   const bool crop = P.border != PEA_BORDER_CIRCULAR;
   if constexpr (D_T == 16) {
@@ -107,19 +105,17 @@ bool bwd_self(const KParams& P, const float* x, const float* inv, const float* g
 // the LDS-DMA forward of the self loss (f32 storage, D in {16, 32, 64}, axis-aligned stencil, K <= kXP; 3D norm1 / norm5 at D = 16).
 // (Inference keeps k_fwd_tiled: 60 us against 68 us at B=8 x 544^2 -- without the epilogue streams the one-sided box of the
 //  tiled kernel moves fewer bytes than six ring planes do.)
-bool xdma_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s, bool* finished) {
-  *finished = false;
+bool xdma_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s) {
   if (!env().fwd_xdma || env().force_direct || A.dtype != PEA_F32 || !A.train || A.eo != A.e) return false;
-  if (P.D == 16) return fwd_self<16, true>(P, A, s, finished);
-  if (P.D == 32) return fwd_self<32, true>(P, A, s, finished);
-  if (P.D == 64) return fwd_self<64, true>(P, A, s, finished);
+  if (P.D == 16) return fwd_self<16, true>(P, A, s);
+  if (P.D == 32) return fwd_self<32, true>(P, A, s);
+  if (P.D == 64) return fwd_self<64, true>(P, A, s);
   return false;
 }
 
 // the cross loss with a second operand: 2D, D = 16, f32, circular border, axis-aligned stencil.  e_other staged, own pixel from e,
 // both 1 / norm planes written (inv_out[0 .. B*S) own, inv_out[B*S .. 2*B*S) second operand)
-bool xdma_fwd_other(const KParams& P, const FwdArgs& A, hipStream_t s, bool* finished) {
-  *finished = false;
+bool xdma_fwd_other(const KParams& P, const FwdArgs& A, hipStream_t s) {
   if (!env().fwd_xdma || env().force_direct || A.dtype != PEA_F32 || !A.train || !A.inv_out) return false;
   if (P.D != 16 || P.border != PEA_BORDER_CIRCULAR) return false;
   const float *e = (const float*)A.e, *e_other = (const float*)A.eo;
@@ -131,11 +127,48 @@ bool xdma_fwd_other(const KParams& P, const FwdArgs& A, hipStream_t s, bool* fin
   if (!plan(P, kXdmaPSU, 1, &X) || X.C.nfz > 0 || P.K > kXP) return false;
   const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
   constexpr auto kern = k_fwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, true, 0, true>;
-  float* fin = env().loss_ticket ? A.loss_out : nullptr;
-  *finished = fin != nullptr;
-  PEA_LAUNCH(kern, grid, blk, X.lds, s, P, X.C, e_other, A.t, A.w, A.m, A.affs, A.gout, A.st, fin, A.inv_out, e,
-             A.inv_out + (size_t)P.B * P.S)
+  PEA_LAUNCH(kern, grid, blk, X.lds, s, P, X.C, e_other, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out, e,
+             A.inv_out + (size_t)P.B * P.S, LabArgs{})
   return true;
+}
+
+// the labels-in forward (k_fwd_xdma<.., LAB>): self loss, 2D, f32, axis-aligned stencil, K <= kXP; g_out and inv_out are required
+// (the backward that follows is xdma_bwd_self).  true = launched.
+template <int D_T>
+static bool fwd_labels(const KParams& P, const FwdArgs& A, const LabArgs& LA, hipStream_t s) {
+  const float* e = (const float*)A.e;
+  if (misaligned(e, 16) || misaligned(A.affs, 16) || misaligned(A.gout, 16) || misaligned(A.inv_out, 4) || misaligned(LA.labels, 16))
+    return false;
+  XPlan X;
+  if (!plan(P, kXdmaPSUF, 1, &X) || X.C.nfz > 0 || P.K > kXP || P.Z != 1) return false;
+  const size_t lds = X.lds + (size_t)kXdmaPSUF * 256;  // + the label plane
+  const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  if (P.border != PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_fwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, true, true, 0, false, 6, true>;
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, e, (const float*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr, A.affs, A.gout,
+               A.st, A.inv_out, (const float*)nullptr, (float*)nullptr, LA)
+  } else {
+    constexpr auto kern = k_fwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, false, true, 0, false, 6, true>;
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, e, (const float*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr, A.affs, A.gout,
+               A.st, A.inv_out, (const float*)nullptr, (float*)nullptr, LA)
+  }
+  return true;
+}
+
+// would xdma_fwd_labels + xdma_bwd_self take this descriptor (16-byte aligned tensors assumed)?
+bool xdma_labels_supported(const KParams& P, int dtype) {
+  if (!env().fwd_xdma || !env().bwd_xdma || env().force_direct || dtype != PEA_F32 || (P.D != 16 && P.D != 32) || P.Z != 1) return false;
+  XPlan X;
+  if (!plan(P, kXdmaPSUF, 1, &X) || X.C.nfz > 0 || P.K > kXP) return false;
+  return plan(P, kXdmaPSU, 0, &X) && X.C.npz == 0 && X.C.npx <= kXP && X.C.npy <= kXP;
+}
+
+bool xdma_fwd_labels(const KParams& P, const FwdArgs& A, const int32_t* labels, const float* wtab, unsigned lflags, hipStream_t s) {
+  if (!env().fwd_xdma || !env().bwd_xdma || env().force_direct || A.dtype != PEA_F32 || !A.gout || !A.inv_out) return false;
+  const LabArgs LA = {labels, wtab, lflags};
+  if (P.D == 16) return fwd_labels<16>(P, A, LA, s);
+  if (P.D == 32) return fwd_labels<32>(P, A, LA, s);
+  return false;
 }
 
 // the cross backward (self loss, f32 storage, axis-aligned stencil): needs the 1 / norm plane

@@ -12,12 +12,12 @@
 // and exact: no rounding happens between the f32 partial and the final f64.  A digit word takes 2^32 additions before it can wrap.
 // The table is sharded kLossSlots ways by tile number so that no address sees more than ntiles / 16 adds.
 //
-// What is left for the end is 16 x K x 3 words.  Two ways to finish (same arithmetic, same bits):
-//   * k_loss_finish: one tiny launch of one wave (reads the table, writes loss_out, zeroes the table) -- the default;
-//   * in the forward kernel itself: the workgroup whose arrival ticket is the last one does it (PEA_LOSS_TICKET=1, pea_host.h;
-//     measured: no faster in the step, and 3x slower under rocprofv3 -- kept as a switch, bit-identical by test).
-//     The accumulators are read with returning atomics (exchange with 0), i.e. at the same point of the memory system where the
-//     adds were performed: no acquire fence, no cache to be stale (MI355X_MICROARCH.md: atomics execute at the memory side).
+// What is left for the end is 16 x K x 3 words: k_loss_finish, one launch of ONE wave, reads the table, writes loss_out and
+// zeroes the table again.
+// (Built, measured and removed in round 3: finishing inside the forward kernel -- every workgroup's wave 0 waits for its adds,
+//  takes a ticket with a returning atomic, the last ticket holder reads the table with atomic exchanges.  Bit-identical results,
+//  no faster in the step on one box (114.8 us either way), 3x SLOWER on another (332 us, and 331 us under rocprofv3 anywhere):
+//  4624 returning atomics on one word serialise at the memory side at a rate that differs by box.  DESIGN.md section 5.8.)
 //
 // Contract of the state block (include/pea.h, pea_workspace_init): it is ZERO between calls (except `magic`); the finish puts
 // it back to zero.  A block without the magic word (never initialised) yields NaN losses instead of silently wrong ones.
@@ -31,7 +31,7 @@ constexpr unsigned kLossMagic = 0x50454133u;  // "PEA3"
 
 struct LossState {
   unsigned magic;
-  unsigned ticket;  // arrivals of the current launch (in-kernel finish); zero between calls
+  unsigned reserved;
   unsigned pad[14];
   unsigned flags[PEA_MAX_K];                            // bit 0: +inf / overflow, bit 1: -inf, bit 2: NaN among the partials
   unsigned long long acc[kLossSlots][PEA_MAX_K][4];     // [0] sum of low digits, [1] of middle digits, [2] of upper words
@@ -88,12 +88,10 @@ __device__ __forceinline__ double loss_value(u64 lo_s, u64 mid_s, u64 hi_s, unsi
 }
 
 // The finish, by ONE whole wave: four offsets per pass (lane = 16 * j + s: offset k0 + j, slot s), totals in offset order.
-// XCHG: read the accumulators with atomic exchanges (the in-kernel finish: reads at the memory side, and zeroes in the same
-// operation); otherwise plain loads + plain zero stores (the separate launch: a kernel boundary lies between adds and reads).
-template <bool XCHG>
+// Plain loads and plain zero stores: a kernel boundary lies between the adds and these reads.
 __device__ __forceinline__ void loss_finish_wave(const KParams& P, LossState* __restrict__ st, float* __restrict__ loss_out) {
   const int lane = threadIdx.x & 63, s = lane & (kLossSlots - 1), j = lane >> 4;
-  const bool good = (XCHG ? __hip_atomic_load(&st->magic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st->magic) == kLossMagic;
+  const bool good = st->magic == kLossMagic;
   double tot = 0.0;
   for (int k0 = 0; k0 < P.K; k0 += 4) {  // uniform
     const int k = k0 + j;
@@ -102,16 +100,9 @@ __device__ __forceinline__ void loss_finish_wave(const KParams& P, LossState* __
     unsigned fl = 0;
     if (on) {
       u64* a = st->acc[s][k];
-      if (XCHG) {
-        v0 = __hip_atomic_exchange(a + 0, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v1 = __hip_atomic_exchange(a + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v2 = __hip_atomic_exchange(a + 2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (s == 0) fl = __hip_atomic_exchange(&st->flags[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        v0 = a[0]; v1 = a[1]; v2 = a[2];
-        a[0] = 0; a[1] = 0; a[2] = 0;
-        if (s == 0) { fl = st->flags[k]; st->flags[k] = 0; }
-      }
+      v0 = a[0]; v1 = a[1]; v2 = a[2];
+      a[0] = 0; a[1] = 0; a[2] = 0;
+      if (s == 0) { fl = st->flags[k]; st->flags[k] = 0; }
     }
 #pragma unroll
     for (int o = 1; o < kLossSlots; o <<= 1) {  // the 16 slots of an offset sit in 16 adjacent lanes
@@ -134,7 +125,7 @@ __device__ __forceinline__ void loss_finish_wave(const KParams& P, LossState* __
 
 // the separate launch
 static __global__ __launch_bounds__(64) void k_loss_finish(const KParams P, LossState* __restrict__ st, float* __restrict__ loss_out) {
-  loss_finish_wave<false>(P, st, loss_out);
+  loss_finish_wave(P, st, loss_out);
 }
 
 // pea_workspace_init: zero `n` states and mark them initialised
@@ -143,25 +134,6 @@ static __global__ __launch_bounds__(256) void k_loss_state_init(LossState* __res
   const size_t words = (size_t)n * (sizeof(LossState) / 4);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256)
     w[i] = (i % (sizeof(LossState) / 4) == 0) ? kLossMagic : 0u;
-}
-
-// In-kernel finish (PEA_LOSS_TICKET): the wave that issued a workgroup's loss_accumulate calls waits for them
-// (s_waitcnt vmcnt(0): an atomic counts in vmcnt until the memory side has performed it), takes a ticket, and the holder of the
-// last ticket of the launch finishes.  No other wave of any workgroup touches the state, so no barrier and no fence is involved:
-// every access to the state is an agent-scope atomic, performed at one place.  nwg = workgroups of the launch that call this.
-__device__ __forceinline__ void loss_ticket_finish(const KParams& P, LossState* __restrict__ st, unsigned nwg, int tile,
-                                                   float* __restrict__ loss_out) {
-  if (st->magic != kLossMagic) {  // never initialised: the ticket word is garbage too, nobody would finish -- say so instead
-    if (tile == 0 && (int)(threadIdx.x & 63) <= P.K) loss_out[threadIdx.x & 63] = __builtin_nanf("");
-    return;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  unsigned old = 0;
-  if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  old = __builtin_amdgcn_readfirstlane(old);
-  if (old != nwg - 1u) return;
-  if ((threadIdx.x & 63) == 0) __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  loss_finish_wave<true>(P, st, loss_out);
 }
 
 }  // namespace pea

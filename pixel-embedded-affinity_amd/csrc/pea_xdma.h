@@ -552,25 +552,40 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
 //   6 = THREE workgroups per CU -- the forward's one-sided cross needs 7.5 KB planes (6 x 7680 B = 45 KB of ring), so a third
 //   workgroup fits the LDS if the kernel stays within 80 VGPRs: target / weight / mask are then requested after the channel loop
 //   (LATE) instead of being held across it
-// loss_fin: non-null = finish the loss inside this launch (pea_loss.h, ticket); null = the caller launches k_loss_finish
-template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN, int ZF = 0, bool OTHER = false, int WPE = 4>
+// LAB: target / mask / weight come from a LABEL image (gen_affs_ours, scripts_cvppp/utils/affinity_ours.py
+//   :17-39, and weight_binary_ratio as two scalars per (image, channel), pea_label_weights) instead of three tensors: the label
+//   plane is staged like one more channel of the cross (a SEVENTH plane, alive until the loss is evaluated), so the neighbour's
+//   label sits at the LDS slot of the neighbour's embedding.  The loss term and g are evaluated per PIXEL right after the channel
+//   loop (own label, K neighbour labels: 11 LDS reads), a AND g are parked in LDS and leave as dwordx4 rows.  No t / w / m
+//   traffic at all: 4D + 4 + 8K + 4 bytes per pixel.  2D only.
+struct LabArgs {
+  const int32_t* labels;  // [B, Z, Y, X]
+  const float* wtab;      // [B, K, 2]: weight of target-1 pixels, of target-0 pixels
+  unsigned lflags;        // PEA_TGT_*
+};
+template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN, int ZF = 0, bool OTHER = false, int WPE = 4, bool LAB = false>
 __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const XParams C, const float* __restrict__ e,
                                                            const float* __restrict__ target, const float* __restrict__ weight,
                                                            const uint8_t* __restrict__ mask, float* __restrict__ affs,
                                                            float* __restrict__ gout, LossState* __restrict__ st,
-                                                           float* __restrict__ loss_fin, float* __restrict__ inv_out,
-                                                           const float* __restrict__ own, float* __restrict__ inv_other_out) {
+                                                           float* __restrict__ inv_out,
+                                                           const float* __restrict__ own, float* __restrict__ inv_other_out,
+                                                           const LabArgs LA) {
   static_assert(!OTHER || (D_T <= 16 && ZF == 0), "cross-loss instantiation: D <= 16, in-plane");
+  static_assert(!LAB || (TRAIN && ZF == 0 && !OTHER), "labels-in instantiation: 2D self loss");
   constexpr int NT = TH * TW, PS = PSU * 256, NP = D_T / 2, TP = NT, QP = TP / 4, NSL = QP / 64;
   constexpr int KMAX = ZF > 0 ? kXP + 2 : kXP;      // channels the epilogue handles (norm5: 8 in-plane + 4 z offsets)
   constexpr int ITEMS = (KMAX * QP + NT - 1) / NT;
   constexpr bool SDMA = ZF > 0, LATE = ZF > 0 || OTHER || WPE > 4;  // OTHER: the own pixel's registers instead of the early t / w / m
   static_assert(TW == 32 && D_T % 2 == 0 && QP % 64 == 0, "lane mapping / channel pairs");
+  constexpr int NW = NT / 64;
   static_assert(KMAX * TP * 4 + KMAX * NSL * 4 <= 6 * PS && KMAX <= kXK, "the parked dot products fit the ring");
+  static_assert(!LAB || 2 * KMAX * TP * 4 + KMAX * NW * 4 <= 6 * PS, "labels-in: a and g parked side by side");
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   float* sA = (float*)lds;                          // [K][TP] dot products, laid over the ring once it is dead
-  float* s_part = (float*)(lds + KMAX * TP * 4);    // [K][NSL]
+  float* sG = (float*)(lds + KMAX * TP * 4);        // LAB: [K][TP] d loss / d affs beside them
+  float* s_part = (float*)(lds + (LAB ? 2 : 1) * KMAX * TP * 4);  // [K][NSL]  (LAB: [K][NW])
   int tile, b, z, y0, x0;
   if (!xdma_tile<TH, TW>(C, P, tile, b, z, y0, x0)) return;
   const size_t S = (size_t)P.S;
@@ -591,20 +606,22 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
   int iqd[ITEMS], igy[ITEMS], igx[ITEMS], isl[ITEMS];
   f4 t4[ITEMS], w4[ITEMS];
   unsigned m4[ITEMS];
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const int tt = it * NT + (int)threadIdx.x;
-    const int sl = __builtin_amdgcn_readfirstlane(tt / QP);
-    ion[it] = sl < P.K;
-    isl[it] = min(sl, P.K - 1);
-    const int qd = tt - (tt / QP) * QP;
-    iqd[it] = qd;
-    const int l4 = qd * 4;
-    igy[it] = y0 + l4 / TW;
-    igx[it] = x0 + l4 % TW;
-    const bool lv = ion[it] && igy[it] < P.Y && igx[it] < P.X;  // X % 4 == 0: a quad is inside or outside as a whole
-    ivo[it] = lv ? (unsigned)(igy[it] * P.X + igx[it]) * 4u : kOOB;
+  // (the 80-VGPR instantiations evaluate this after the channel loop: three registers less across it)
+#define PEA_XITEMS()                                                                                                      \
+  _Pragma("unroll") for (int it = 0; it < ITEMS; ++it) {                                                                  \
+    const int tt = it * NT + (int)threadIdx.x;                                                                            \
+    const int sl = __builtin_amdgcn_readfirstlane(tt / QP);                                                               \
+    ion[it] = sl < P.K;                                                                                                   \
+    isl[it] = min(sl, P.K - 1);                                                                                           \
+    const int qd = tt - (tt / QP) * QP;                                                                                   \
+    iqd[it] = qd;                                                                                                         \
+    const int l4 = qd * 4;                                                                                                \
+    igy[it] = y0 + l4 / TW;                                                                                               \
+    igx[it] = x0 + l4 % TW;                                                                                               \
+    const bool lv = ion[it] && igy[it] < P.Y && igx[it] < P.X; /* X % 4 == 0: a quad is inside or outside as a whole */   \
+    ivo[it] = lv ? (unsigned)(igy[it] * P.X + igx[it]) * 4u : kOOB;                                                       \
   }
+  if (WPE <= 4) PEA_XITEMS()
 #define PEA_XLOAD_TWM()                                                                                                   \
   if (TRAIN) {                                                                                                            \
     _Pragma("unroll") for (int it = 0; it < ITEMS; ++it) {                                                                \
@@ -616,7 +633,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
                      : 0x01010101u;                                                                                       \
     }                                                                                                                     \
   }
-  if (!LATE) PEA_XLOAD_TWM()
+  if (!LATE && !LAB) PEA_XLOAD_TWM()
 
   const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
   const int py = y0 + ly, px = x0 + lx;
@@ -677,6 +694,11 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                \
   }
 #define PEA_XWAITZ() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * ZF + 4) : "memory");
+  if (LAB) {  // the label plane: same geometry as a channel plane (int32, [Y][X]), its own (seventh) LDS plane
+    const rsrc_t lB = mkbuf(LA.labels + (size_t)b * S);
+    if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(lB, (lds_ptr_t)(lds + 6 * PS + wbase), 16, vo[0], ezo, 0, 0);
+    if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(lB, (lds_ptr_t)(lds + 6 * PS + w1), 16, vo1, ezo, 0, 0);
+  }
   PEA_XDMA(0, ezo)
   PEA_XDMA(PS, ezo + ecs)
   if (NP > 1) {
@@ -774,7 +796,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
 #undef PEA_XWAIT1
 #undef PEA_XWAITZ
 #undef PEA_XZLOAD
-  if (LATE && WPE <= 4) PEA_XLOAD_TWM()
+  if (LATE && WPE <= 4 && !LAB) PEA_XLOAD_TWM()
 
   // ---- normalise; the lane's own 1 / norm for the backward
   const float osum = oss.x + oss.y;
@@ -787,6 +809,41 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
     bs32(mkbuf(inv_other_out + (size_t)b * S), csum < P.eps * P.eps ? -inv_c : inv_c, pe, ezo);
   }
   lds_barrier();  // every lane is done with the ring: sA goes over it
+  if constexpr (LAB) {
+    // target, mask, weight of every pair from two labels (pea_fused_labels.h PEA_LAB_PAIR: the same rules, the same order of
+    // operations); the neighbour's label is UNWRAPPED: a neighbour outside the image has none (inside = false)
+    const bool pad = LA.lflags & PEA_TGT_PADDING, fg = LA.lflags & PEA_TGT_BOTH_FOREGROUND, msk = LA.lflags & PEA_TGT_MASK_INSIDE;
+    const float* wt_b = LA.wtab + 2 * (size_t)b * P.K;
+    const int lown = *(const int*)(lds + 6 * PS + vown);
+    // the pixel's coordinates, derived again from an opaque copy of the lane id: kept from the top of the kernel they would be
+    // two more registers alive across the channel loop, and the 80-VGPR budget has none to spare (a spill otherwise)
+    int tid_ = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int py = y0 + (tid_ >> 5), px = x0 + (tid_ & 31);
+    const bool live = py < P.Y && px < P.X;
+#pragma unroll
+    for (int k = 0; k < kXP; ++k) {
+      if (k < C.nf) {  // uniform
+        const int ch = C.fi[k];
+        const int q = (C.fax[k] ? px : py) + C.fd[k];
+        const bool inside = (unsigned)q < (unsigned)(C.fax[k] ? P.X : P.Y);
+        const int lnb = *(const int*)(lds + 6 * PS + an[k]);
+        const bool eq = lown == lnb && (!fg || (lown > 0 && lnb > 0));
+        const float t = (inside ? eq : pad) ? 1.f : 0.f;
+        const float m = (msk && !inside) ? 0.f : 1.f;
+        const float w = t != 0.f ? wt_b[2 * ch] : wt_b[2 * ch + 1];
+        const bool exists = live && (!CROP || inside);
+        const float a = exists ? (dot[k].x + dot[k].y) * inv_own * rnorm(ssq[k].x + ssq[k].y, inv_eps) : 0.f;
+        const float rr = a * m - t * m;
+        const float wr = exists ? w * rr : 0.f;
+        sA[ch * TP + (int)threadIdx.x] = act_affs(a, af);
+        sG[ch * TP + (int)threadIdx.x] = C.gs[ch] * wr * m;
+        const float red = wave_sum63(wr * rr);
+        if (lane == 63) s_part[ch * NW + wave] = red;
+        asm volatile("" ::: "memory");  // one pair at a time (80 VGPRs: the scheduler otherwise hoists every label read)
+      }
+    }
+  } else {
 #pragma unroll
   for (int k = 0; k < kXP; ++k) {
     if (k < C.nf) {  // uniform
@@ -798,6 +855,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
       sA[C.fi[k] * TP + (int)threadIdx.x] = a;
     }
   }
+  }
 #pragma unroll
   for (int k = 0; k < ZF; ++k) {
     if (k < C.nfz) {
@@ -805,9 +863,12 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
       sA[C.fzi[k] * TP + (int)threadIdx.x] = a;
     }
   }
-  if (LATE && WPE > 4) PEA_XLOAD_TWM()  // 80-VGPR budget: only now are the 40 accumulator registers free
+  if (WPE > 4 && !LAB) PEA_XITEMS()
+  if (LATE && WPE > 4 && !LAB) PEA_XLOAD_TWM()  // 80-VGPR budget: only now are the 40 accumulator registers free
 #undef PEA_XLOAD_TWM
   lds_barrier();
+  if (WPE > 4 && LAB) PEA_XITEMS()
+#undef PEA_XITEMS
 
   // ---- epilogue: 4 x-adjacent pixels of one offset per lane, dwordx4 everywhere
 #pragma unroll
@@ -816,6 +877,11 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
     const int sl = isl[it];
     const f4 a4 = *(const f4*)(sA + sl * TP + iqd[it] * 4);
     const unsigned so = ezo + (unsigned)sl * ecs;
+    if constexpr (LAB) {  // everything was evaluated per pixel: two row stores
+      if (has_a) bs128<true>(aB, a4, ivo[it], so);
+      if (has_g) bs128<false>(gB, *(const f4*)(sG + sl * TP + iqd[it] * 4), ivo[it], so);
+      continue;
+    }
     if (has_a) {
       f4 o = a4;
       if (af) { o.x = act_affs(o.x, af); o.y = act_affs(o.y, af); o.z = act_affs(o.z, af); o.w = act_affs(o.w, af); }
@@ -849,10 +915,9 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
       if ((int)threadIdx.x < P.K) {
         float v = 0.f;
 #pragma unroll
-        for (int s = 0; s < NSL; ++s) v += s_part[threadIdx.x * NSL + s];
+        for (int s = 0; s < (LAB ? NW : NSL); ++s) v += s_part[threadIdx.x * (LAB ? NW : NSL) + s];
         loss_accumulate(st, tile, threadIdx.x, v);
       }
-      if (loss_fin) loss_ticket_finish(P, st, (unsigned)C.ntiles, tile, loss_fin);
     }
   }
 }

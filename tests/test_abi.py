@@ -29,7 +29,8 @@ def test_header_declares_the_expected_entry_points():
                                          "pea_targets_workspace_bytes", "pea_gen_targets",
                                          "pea_stitch_add", "pea_stitch_finalize", "pea_label_weights",
                                          "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd",
-                                         "pea_affinity_fwd_bwd_labels", "pea_affinity_fwd_bwd_labels_dual"])
+                                         "pea_affinity_fwd_bwd_labels", "pea_affinity_fwd_bwd_labels_ex", "pea_labels_scratch_bytes",
+                                         "pea_affinity_fwd_bwd_labels_dual"])
 
 
 def test_library_exports_every_declared_symbol(pkg, lib):

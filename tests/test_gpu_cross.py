@@ -373,8 +373,7 @@ def test_second_operand_that_aliases_the_first(pkg, dev, orc, synth):
 
 def test_loss_state_contract(pkg, dev, orc, synth, monkeypatch):
     """the loss is summed in integers in a state block (csrc/pea_loss.h): a block that was never prepared gives NaN, a prepared one
-    the oracle's loss -- identically whether the forward finishes the sum itself (ticket) or a second launch does, whichever
-    forward kernel runs (3 / 2 workgroups per CU, tiled, direct), call after call on the same block"""
+    the oracle's loss, whichever forward kernel runs (3 / 2 workgroups per CU, tiled, direct), call after call on the same block"""
     B, D, H, W = 3, 16, 80, 128
     offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
     K = len(offsets)
@@ -389,17 +388,13 @@ def test_loss_state_contract(pkg, dev, orc, synth, monkeypatch):
     wsb = L.pea_workspace_bytes(ctypes.byref(desc))
     raw = torch.full((wsb // 4,), 1.0e-3, device=dev)      # garbage, not initialised
     lossv = torch.zeros(1 + K, device=dev)
-    for ticket in ("0", "1"):                               # either finish says so
-        monkeypatch.setenv("PEA_LOSS_TICKET", ticket)
-        lossv.zero_()
-        assert L.pea_affinity_fwd_ex(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), None, None, None, P(lossv), P(raw), wsb, st) == 0
-        assert bool(torch.isnan(lossv).all())
-    monkeypatch.delenv("PEA_LOSS_TICKET")
+    assert L.pea_affinity_fwd_ex(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), None, None, None, P(lossv), P(raw), wsb, st) == 0
+    assert bool(torch.isnan(lossv).all())
     assert L.pea_workspace_init(P(raw), wsb, st) == 0
     d = orc.desc_2d(e, offsets)
     _, o_loss = orc.c_fwd(d, e, None, t, w, m)
     seen = []
-    for switches in ({}, {"PEA_LOSS_TICKET": "1"}, {"PEA_FWD_WG3": "0"}, {"PEA_FWD_XDMA": "0"}, {"PEA_FORCE_DIRECT": "1"}):
+    for switches in ({}, {"PEA_FWD_WG3": "0"}, {"PEA_FWD_XDMA": "0"}, {"PEA_FORCE_DIRECT": "1"}):
         for k_, v_ in switches.items():
             monkeypatch.setenv(k_, v_)
         for _ in range(2):
@@ -411,6 +406,6 @@ def test_loss_state_contract(pkg, dev, orc, synth, monkeypatch):
             seen.append((tuple(sorted(switches)), got))
         for k_ in switches:
             monkeypatch.delenv(k_)
-    # the two finishes (and the two occupancies of the same cross kernel) add the same integers: bit-identical
-    for i in range(1, 6):
+    # the two occupancies of the same cross kernel add the same integers: bit-identical, call after call
+    for i in range(1, 4):
         assert np.array_equal(seen[0][1], seen[i][1]), seen[i][0]

@@ -134,3 +134,39 @@ def test_two_ranks_hip_kernels_sharding_identity_and_ddp_step():
     replica_gap, ddp_vs_full, scale = res["ddp"]
     assert replica_gap == 0.0                   # the all-reduced gradients are identical on both ranks
     assert ddp_vs_full <= 2e-5 * max(scale, 1)  # and equal the full-batch step (local normalisers average to the global one)
+
+
+def test_bench_two_ranks_path_runs_and_reports_whole_job_throughput():
+    """bench.py's N > 1 path as the driver launches it (python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2),
+    in fresh child processes.  On a one-GPU box the two ranks share the device and the control-plane collectives go over gloo; on
+    a box with >= 2 GPUs the same command takes the RCCL branch.  Checks the line's shape (n_gpus, weak scaling, a train leg) and
+    that `value` is the whole job's: twice what each rank did, in the time both took."""
+    import json
+    import subprocess
+    import sys
+    root = ge.ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "30", "--warmup", "3", "--no-cpu-baseline", "--no-section"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, two.stdout[-2000:]                       # rank 0 prints ONE line
+    r2 = json.loads(lines[0])
+    assert r2["n_gpus"] == 2 and r2["scaling"] == "weak" and r2["config"]["images_per_gpu"] == 8
+    assert r2.get("train_imgs_per_s"), r2.get("train_error")
+    shared = torch.cuda.device_count() < 2
+    assert ("gloo" in r2["train_config"]["parallelism"]) == shared
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-train"] + common, capture_output=True, text=True,
+                         timeout=600, env=env, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    r1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    # whole-job pixels: 2 ranks x 8 images per step
+    px2 = r2["value"] * 1e6 * r2["ms_per_step"] * 1e-3
+    px1 = r1["value"] * 1e6 * r1["ms_per_step"] * 1e-3
+    assert abs(px2 / px1 - 2.0) < 1e-3
+    if shared:   # two ranks time-share one GPU: each step takes about twice as long, the job's rate stays that of one GPU
+        assert 0.7 < r2["value"] / r1["value"] < 1.3
+    else:        # one GPU each, no data-path collective: close to twice the rate
+        assert r2["value"] / r1["value"] > 1.6

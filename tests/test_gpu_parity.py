@@ -4,6 +4,7 @@ CPU oracle, and size-independent properties at BASELINE.json's full sizes.
 Tolerances (north_star: affinity maps within 1e-4 of the reference; fp32 everywhere in the reference):
     affs   abs 1e-5  (10x tighter than required)      loss  rel 1e-5      grads  rel-to-max 1e-4
 """
+import ctypes
 import importlib
 
 import os
@@ -593,9 +594,13 @@ def test_volume_stitcher_matches_reference_statements(pkg, dev):
 
 
 @pytest.mark.parametrize("case", ["self_nb4", "self_nb8", "ema", "f16", "d32", "d32_ema"])
-def test_labels_step_matches_targets_path(pkg, dev, synth, case):
-    """the labels-in training step (pea_label_weights + pea_affinity_fwd_bwd_labels) against pea_gen_targets +
-    embedding_loss / ema_embedding_loss on the same label images: loss, per-offset losses, affs, gradient"""
+@pytest.mark.parametrize("two_launch", [False, True])
+def test_labels_step_matches_targets_path(pkg, dev, synth, case, two_launch, monkeypatch):
+    """the labels-in training step (pea_label_weights + pea_affinity_fwd_bwd_labels[_ex]) against pea_gen_targets +
+    embedding_loss / ema_embedding_loss on the same label images: loss, per-offset losses, affs, gradient.
+    two_launch: the scratch-lending form at every size (on the cross kernels where they cover the case: f32 self losses with the
+    axis-aligned stencils -- the labels-in forward k_fwd_xdma<.., LAB> + the cross backward; else it is the one-launch kernel)"""
+    monkeypatch.setattr(pkg.affinity_op, "LABELS_TWO_LAUNCH_MIN_PX", 0 if two_launch else 1 << 62)
     nb = 8 if case == "self_nb8" else 4
     offsets = pkg.multi_offset(([1, 3, 5, 9, 11] if case.startswith("d32") else [1, 3, 5, 9, 27]) if nb == 4 else [1, 3, 9], nb)
     B, D, H, W = 3, (32 if case.startswith("d32") else 16), 80, 136
@@ -630,6 +635,10 @@ def test_labels_step_matches_targets_path(pkg, dev, synth, case):
     assert relmax(g1, g0) < (2e-3 if case == "f16" else 1e-5)
     if p0 is not None:
         np.testing.assert_allclose(p1, p0, rtol=2e-6)
+    # which cases the two-launch form really covers (the others silently ran the one-launch kernel, as documented)
+    spec = pkg.affinity_op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX)
+    sb = pkg._lib.lib().pea_labels_scratch_bytes(ctypes.byref(pkg.affinity_op.make_desc(spec, torch.from_numpy(e).to(dev))))
+    assert (sb > 0) == (case in ("self_nb4", "ema", "d32", "d32_ema"))   # (the descriptor qualifies; a second operand opts out per call)
 
 
 def test_labels_step_3d_and_section(pkg, dev, orc, synth):
