@@ -86,6 +86,7 @@ int run_fwd(const KParams& P, FwdArgs A, hipStream_t s) {
   const bool self = A.eo == A.e;
   bool launched = false;
   if (A.train) launched = self ? xdma_fwd_self(P, A, s) : xdma_fwd_other(P, A, s);
+  else if (self) launched = xdma_fwd_self(P, A, s);
   if (!launched) {
     // 1 / norm planes: the tiled D = 16 self forward writes its plane while it stages; everything else gets k_inv_norm
     float* inv = A.inv_out;

@@ -23,6 +23,7 @@ struct Env {
   int fwd_xdma;       // PEA_FWD_XDMA=0: no LDS-DMA forward
   int bwd_xdma;       // PEA_BWD_XDMA=0: no LDS-DMA backward
   int labels_dual;    // PEA_LABELS_DUAL=0: pea_affinity_fwd_bwd_labels_dual reports PEA_E_UNSUPPORTED
+  int infer_xdma;     // PEA_INFER_XDMA=0: inference (affs only) on k_fwd_tiled / the chunked kernels instead of the LDS-DMA forward
   int fwd_wg3;        // PEA_FWD_WG3=0: the 2-workgroups-per-CU forward
 };
 const Env& env();

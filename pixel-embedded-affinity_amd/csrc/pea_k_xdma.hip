@@ -106,7 +106,14 @@ bool bwd_self(const KParams& P, const float* x, const float* inv, const float* g
 // (Inference keeps k_fwd_tiled: 60 us against 68 us at B=8 x 544^2 -- without the epilogue streams the one-sided box of the
 //  tiled kernel moves fewer bytes than six ring planes do.)
 bool xdma_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s) {
-  if (!env().fwd_xdma || env().force_direct || A.dtype != PEA_F32 || !A.train || A.eo != A.e) return false;
+  if (!env().fwd_xdma || env().force_direct || A.dtype != PEA_F32 || A.eo != A.e) return false;
+  if (!A.train) {
+    if (!env().infer_xdma) return false;
+    if (P.D == 16) return fwd_self<16, false>(P, A, s);
+    if (P.D == 32) return fwd_self<32, false>(P, A, s);
+    if (P.D == 64) return fwd_self<64, false>(P, A, s);
+    return false;
+  }
   if (P.D == 16) return fwd_self<16, true>(P, A, s);
   if (P.D == 32) return fwd_self<32, true>(P, A, s);
   if (P.D == 64) return fwd_self<64, true>(P, A, s);
@@ -124,6 +131,7 @@ bool xdma_fwd_other(const KParams& P, const FwdArgs& A, hipStream_t s) {
     return false;
   if ((P.tbs | P.wbs | P.mbs) & 3) return false;
   XPlan X;
+  // (three workgroups per CU do not fit here: the own pixel's 16 registers on top of the accumulators spill at 80 VGPRs)
   if (!plan(P, kXdmaPSU, 1, &X) || X.C.nfz > 0 || P.K > kXP) return false;
   const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
   constexpr auto kern = k_fwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, true, 0, true>;
