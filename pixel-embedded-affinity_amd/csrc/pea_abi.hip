@@ -230,6 +230,7 @@ int pea_affinity_bwd_ex(const PeaDesc* desc, const void* e, const void* e_other,
     if (accumulate) return PEA_E_UNSUPPORTED;  // de += is implemented for the detached second operand's role-A backward only
     // self loss: the LDS-DMA cross kernel when the 1 / norm plane came along and the stencil is axis-aligned
     if (dt == PEA_F32 && xdma_bwd_self(P, (const float*)e, inv_norm, g, dloss, (float*)de, s)) return hip_rc();
+    if (dt == PEA_F16 && xdma_bwd_self_h(P, e, inv_norm, g, dloss, de, s)) return hip_rc();
     return run_bwd(P, dt, 3, e, e, e, g, dloss, de, s);
   }
   // (a second operand that aliases the first is still a second operand: its roles are separate)

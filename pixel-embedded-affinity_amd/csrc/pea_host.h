@@ -108,6 +108,7 @@ int xdma_cross_supported(const KParams& P, int dtype, int mode);
 
 // backward: roles bit 0 = A (x is the first operand, neighbours nbA), bit 1 = B (x is the second operand, neighbours nbB)
 bool xdma_bwd_self(const KParams& P, const float* x, const float* inv, const float* g, const float* dl, float* dx, hipStream_t s);
+bool xdma_bwd_self_h(const KParams& P, const void* x, const float* inv, const float* g, const float* dl, void* dx, hipStream_t s);  // f16
 bool xdma_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* dl,
                     float* de, bool accumulate, hipStream_t s);
 bool xdma_bwd_dual(const KParams& P, const float* e, const float* ema, const float* inv, const float* inv_other, const float* g,

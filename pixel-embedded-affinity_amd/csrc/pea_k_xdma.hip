@@ -1,7 +1,7 @@
 // pea_k_xdma.hip -- launchers of the LDS-DMA cross kernels (pea_xdma.h): plan, pick the instantiation, launch.
 // One translation unit of libpea_hip.so (pea_host.h).
 #include "pea_host.h"
-#include "pea_xdma.h"
+#include "pea_xdma_h16.h"
 
 namespace pea {
 
@@ -100,13 +100,62 @@ bool bwd_self(const KParams& P, const float* x, const float* inv, const float* g
   return true;
 }
 
+// ---- f16 storage (pea_xdma_h16.h): 2D self loss / inference, X % 8 == 0 ---------------------------------------------------
+template <int D_T, bool TRAIN>
+bool fwd_self_h(const KParams& P, const FwdArgs& A, hipStream_t s) {
+  const __half* e = (const __half*)A.e;
+  if (P.X % 8 || P.Z != 1 || misaligned(e, 16) || misaligned(A.t, 16) || misaligned(A.w, 16) || misaligned(A.affs, 16) ||
+      misaligned(A.gout, 16) || misaligned(A.m, 4) || misaligned(A.inv_out, 4))
+    return false;
+  if (TRAIN && ((P.tbs | P.wbs | P.mbs) & 3)) return false;
+  XPlan X;
+  if (!plan(P, kXdmaPSUF, 1, &X) || X.C.nfz > 0 || P.K > kXP) return false;
+  const size_t lds = (size_t)5 * kXdmaPSUF * 256;  // two f32 working planes + six half-size ring planes
+  const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  if (P.border != PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_fwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, true, TRAIN, 6>;
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out)
+  } else {
+    constexpr auto kern = k_fwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, false, TRAIN, 6>;
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out)
+  }
+  return true;
+}
+
+constexpr int kXdmaPSUH = 52;  // backward, f16: 13312-byte f32 planes (the half-size ring planes stay whole 256-byte units)
+template <int D_T>
+bool bwd_self_h(const KParams& P, const __half* x, const float* inv, const float* g, const float* dl, __half* dx, hipStream_t s) {
+  if (P.X % 8 || P.Z != 1 || misaligned(x, 16) || misaligned(inv, 16) || misaligned(g, 4) || misaligned(dx, 2)) return false;
+  XPlan X;
+  if (!plan(P, kXdmaPSUH, 0, &X) || X.C.npz > 0) return false;
+  constexpr int XP = D_T > 32 ? 8 : kXP;
+  if (X.C.npx > XP || X.C.npy > XP) return false;
+  const size_t lds = (size_t)5 * kXdmaPSUH * 256;
+  const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  if (P.border != PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_bwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUH, true, XP>;
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, x, inv, g, dl, dx)
+  } else {
+    constexpr auto kern = k_bwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUH, false, XP>;
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, x, inv, g, dl, dx)
+  }
+  return true;
+}
+
 }  // namespace
 
 // the LDS-DMA forward of the self loss (f32 storage, D in {16, 32, 64}, axis-aligned stencil, K <= kXP; 3D norm1 / norm5 at D = 16).
 // (Inference keeps k_fwd_tiled: 60 us against 68 us at B=8 x 544^2 -- without the epilogue streams the one-sided box of the
 //  tiled kernel moves fewer bytes than six ring planes do.)
 bool xdma_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s) {
-  if (!env().fwd_xdma || env().force_direct || A.dtype != PEA_F32 || A.eo != A.e) return false;
+  if (!env().fwd_xdma || env().force_direct || A.eo != A.e) return false;
+  if (A.dtype == PEA_F16) {  // f16 storage: pea_xdma_h16.h
+    if (!A.train && !env().infer_xdma) return false;
+    if (P.D == 16) return A.train ? fwd_self_h<16, true>(P, A, s) : fwd_self_h<16, false>(P, A, s);
+    if (P.D == 32) return A.train ? fwd_self_h<32, true>(P, A, s) : fwd_self_h<32, false>(P, A, s);
+    if (P.D == 64) return A.train ? fwd_self_h<64, true>(P, A, s) : fwd_self_h<64, false>(P, A, s);
+    return false;
+  }
   if (!A.train) {
     if (!env().infer_xdma) return false;
     if (P.D == 16) return fwd_self<16, false>(P, A, s);
@@ -188,6 +237,14 @@ bool xdma_bwd_self(const KParams& P, const float* x, const float* inv, const flo
   return false;
 }
 
+bool xdma_bwd_self_h(const KParams& P, const void* x, const float* inv, const float* g, const float* dl, void* dx, hipStream_t s) {
+  if (!inv || !env().bwd_xdma || env().force_direct) return false;
+  if (P.D == 16) return bwd_self_h<16>(P, (const __half*)x, inv, g, dl, (__half*)dx, s);
+  if (P.D == 32) return bwd_self_h<32>(P, (const __half*)x, inv, g, dl, (__half*)dx, s);
+  if (P.D == 64) return bwd_self_h<64>(P, (const __half*)x, inv, g, dl, (__half*)dx, s);
+  return false;
+}
+
 // backward, role A only (the second operand is detached): de (+)= dloss * d loss / d e
 bool xdma_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* dl,
                     float* de, bool accumulate, hipStream_t s) {
@@ -229,9 +286,16 @@ void launch_inv_norm(const KParams& P, int dtype, const void* e, float* inv, hip
 // pea_cross_supported: would the cross kernels take this descriptor?  mode 0: forward, 1: backward (self loss),
 // 2: the cross loss with a detached second operand (forward + role-A backward)
 int xdma_cross_supported(const KParams& P, int dtype, int mode) {
-  if (dtype != PEA_F32 || (P.D != 16 && P.D != 32 && P.D != 64) || env().force_direct) return 0;
+  if ((P.D != 16 && P.D != 32 && P.D != 64) || env().force_direct) return 0;
   if (!(mode ? env().bwd_xdma : env().fwd_xdma)) return 0;
   XPlan X;
+  if (dtype == PEA_F16) {  // pea_xdma_h16.h: 2D self loss
+    if (mode == 2 || P.X % 8 || P.Z != 1) return 0;
+    if (mode == 0) return (plan(P, kXdmaPSUF, 1, &X) && X.C.nfz == 0 && P.K <= kXP) ? 1 : 0;
+    if (!plan(P, kXdmaPSUH, 0, &X) || X.C.npz > 0) return 0;
+    const int xp = P.D > 32 ? 8 : kXP;
+    return (X.C.npx <= xp && X.C.npy <= xp) ? 1 : 0;
+  }
   if (mode == 2) {
     if (P.D != 16 || P.border != PEA_BORDER_CIRCULAR || P.K > kXP || !env().fwd_xdma) return 0;
     if (!plan(P, kXdmaPSU, 1, &X) || X.C.nfz > 0) return 0;

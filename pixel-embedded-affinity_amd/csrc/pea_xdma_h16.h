@@ -1,0 +1,445 @@
+// pea_xdma_h16.h -- the LDS-DMA cross kernels (pea_xdma.h) for f16 STORAGE of the embedding (BASELINE.json configs[4]: D = 64 in
+// half precision; e and d loss / d e are __half, all arithmetic f32, target / weight / affs / g / 1/norm stay f32).
+//
+// Round 2 left f16 storage on the box kernels (tiled / chunked forward, direct backward: 0.93 ms at B=8 x 64 x 544^2 against 0.65 ms
+// for the same shape stored in f32): an f16 plane in LDS costs MORE instructions per channel in the gather (ds_read_u16 has no
+// two-plane form, v_fma_mix is not packed).  So the gather stays exactly the f32 one, and the half precision ends at the staging:
+//   * the channel planes arrive RAW in f16 by buffer_load_dwordx4 ... lds -- 8 pixels per lane, ONE wave instruction per plane
+//     and wave instead of two, half the bytes from HBM and, what bounds the backward, half the bytes from L2 into the CU --
+//     into a ring of three chunk buffers of half-size planes;
+//   * before a chunk is gathered the workgroup converts it (ds_read_b64 -> 4 x v_cvt_f32_f16 -> ds_write_b128, at most two quads
+//     per lane and plane) into ONE pair of f32 working planes laid out exactly like the planes pea_xdma.h gathers from.
+// Two barriers per chunk instead of one (converted / consumed); the second workgroup of the CU fills them.  LDS: backward
+// 2 x 13 KB + 6 x 6.5 KB = 64 KB (two workgroups per CU), forward 2 x 7.5 KB + 6 x 3.75 KB = 37.5 KB (three).
+// Self loss / inference, 2D, X % 8 == 0 (an 8-pixel DMA item never straddles a row end), axis-aligned stencils, D in {16, 32, 64}.
+#pragma once
+#include "pea_xdma.h"
+
+namespace pea {
+
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+
+// geometry of this lane's DMA items: up to two QUADS (4 pixels: the f32 1 / norm plane, and the conversion) and one OCT
+// (8 pixels: the f16 channel planes).  Same region order as pea_xdma.h (VF rows of TW pixels, then strip rows of SW pixels).
+// (Plain locals, not a struct: with the operands of the LDS-DMA builtin taken from members of a local struct, ROCm 7.2's host pass
+//  silently emits no stub for the kernel -- an undefined symbol at load time.  Found by bisection.)
+template <int TH, int TW, bool CROP>
+__device__ __forceinline__ void x_items(const KParams& P, const XParams& C, int y0, int x0, int wave, int lane, unsigned (&vo)[2],
+                                        bool (&act)[2], int (&qq)[2], unsigned& vo8, bool& act8) {
+  constexpr int NT = TH * TW;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int q = (s * (NT / 64) + wave) * 64 + lane;
+    qq[s] = q;
+    int gy, gx;
+    if (q < C.QV) {
+      gy = y0 - C.hy0 + (q >> 3);
+      gx = x0 + 4 * (q & 7);
+    } else {
+      const int k = q - C.QV;
+      const int sh = C.SW == 64 ? 4 : 3;
+      const int cc = 4 * (k & ((1 << sh) - 1));
+      gy = y0 + (k >> sh);
+      gx = cc < C.split ? x0 + TW + cc : x0 - C.SW + cc;
+    }
+    act[s] = q < C.QA;
+    bool oky, okx;
+    gy = wrap1<CROP>(gy, P.Y, oky);
+    gx = wrap1<CROP>(gx, P.X, okx);
+    vo[s] = (act[s] && oky && okx) ? (unsigned)(gy * P.X + gx) * 4u : kOOB;
+  }
+  const int o = wave * 64 + lane;
+  int gy, gx;
+  if (o < (C.QV >> 1)) {
+    gy = y0 - C.hy0 + (o >> 2);
+    gx = x0 + 8 * (o & 3);
+  } else {
+    const int k = o - (C.QV >> 1);
+    const int sh = C.SW == 64 ? 3 : 2;
+    const int cc = 8 * (k & ((1 << sh) - 1));
+    gy = y0 + (k >> sh);
+    gx = cc < C.split ? x0 + TW + cc : x0 - C.SW + cc;
+  }
+  act8 = o < (C.QA >> 1);
+  bool oky, okx;
+  gy = wrap1<CROP>(gy, P.Y, oky);
+  gx = wrap1<CROP>(gx, P.X, okx);
+  vo8 = (act8 && oky && okx) ? (unsigned)(gy * P.X + gx) * 2u : kOOB;
+}
+
+// wait until only the youngest chunk's DMA (npc wave instructions of this wave: 2 or 0) may be in flight, then the barrier
+#define PEA_HWAIT1(npc)                                                                          \
+  {                                                                                              \
+    if ((npc) == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");     \
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                \
+  }
+#define PEA_HWAIT0() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+// f16 chunk `rbuf` of the ring -> the two f32 working planes
+template <int PS>
+__device__ __forceinline__ void convert_chunk(char* W, const char* R, int rbuf, const int (&qq)[2], const bool (&act)[2]) {
+  constexpr int PH = PS / 2;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      if (act[s]) {
+        const h4_t h = *(const h4_t*)(R + (rbuf * 2 + j) * PH + qq[s] * 8);
+        f4 v;
+        v.x = (float)h.x; v.y = (float)h.y; v.z = (float)h.z; v.w = (float)h.w;
+        *(f4*)(W + j * PS + qq[s] * 16) = v;
+      }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward, self loss (both roles), f16 e / de
+// ------------------------------------------------------------------------------------------------------------------
+template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP>
+__global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma_h(const KParams P, const XParams C, const __half* __restrict__ xt,
+                                                           const float* __restrict__ invp, const float* __restrict__ gin,
+                                                           const float* __restrict__ dloss, __half* __restrict__ dx) {
+  constexpr int NT = TH * TW, PS = PSU * 256, PH = PS / 2, NP = D_T / 2;
+  static_assert(TW == 32 && D_T % 2 == 0 && PS % 512 == 0, "lane mapping / channel pairs / half planes in whole 256-byte units");
+  extern __shared__ f4 lds4[];
+  char* lds = (char*)lds4;
+  char* const W = lds;            // two f32 working planes (the 1 / norm plane sits in the second one first)
+  char* const R = lds + 2 * PS;   // ring: 3 buffers x 2 f16 planes
+  int tile, b, z, y0, x0;
+  if (!xdma_tile<TH, TW>(C, P, tile, b, z, y0, x0)) return;
+  const size_t S = (size_t)P.S;
+  const unsigned YX = (unsigned)(P.Y * P.X);
+  const rsrc_t xB = mkbuf(xt + (size_t)b * D_T * S), dB = mkbuf(dx + (size_t)b * D_T * S);
+  const rsrc_t gB = mkbuf(gin + (size_t)b * P.K * S), iB = mkbuf(invp + (size_t)b * S);
+  const unsigned hcs = (unsigned)P.S * 2u, hzo = (unsigned)z * YX * 2u;  // e / de (f16): channel stride, plane offset
+  const unsigned fcs = (unsigned)P.S * 4u, fzo = (unsigned)z * YX * 4u;  // g, 1 / norm (f32)
+  const float dl = dloss ? dloss[0] : 1.f;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
+  const int py = y0 + ly, px = x0 + lx;
+  const bool live = py < P.Y && px < P.X;
+  const unsigned po = (unsigned)(py * P.X + px);
+  const unsigned ph = live ? po * 2u : kOOB;
+
+  unsigned vo[2], vo8;
+  bool act[2], act8;
+  int qq[2];
+  x_items<TH, TW, CROP>(P, C, y0, x0, wave, lane, vo, act, qq, vo8, act8);
+  const int wbase = wave * 1024;
+  const int npc = 2 * (__builtin_amdgcn_ballot_w64(act8) != 0);
+#define PEA_HDMA16(rbuf, ch)                                                                                                  \
+  if (act8) {                                                                                                               \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(R + ((rbuf) * 2) * PH + wbase), 16, vo8, hzo + (unsigned)(ch) * hcs, 0, 0);        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(R + ((rbuf) * 2 + 1) * PH + wbase), 16, vo8, hzo + (unsigned)((ch) + 1) * hcs, 0, 0); \
+  }
+  // the 1 / norm plane (f32) -> the second working plane
+  if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(iB, (lds_ptr_t)(W + PS + wbase), 16, vo[0], fzo, 0, 0);
+  if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(iB, (lds_ptr_t)(W + PS + wbase + (NT / 64) * 1024), 16, vo[1], fzo, 0, 0);
+  PEA_HDMA16(0, 0)
+
+  // ---- g of every pair (role A at p, role B at p - o) and the LDS slot of every neighbour (pea_xdma.h k_bwd_xdma)
+  const unsigned pg = live ? po * 4u : 0xC0000000u;
+  float cx[XP], cy[XP];
+  int ax[XP], ay[XP];
+  const int vown = ((C.hy0 + ly) * TW + lx) * 4;
+  const int hrow = (C.QV * 4 + ly * C.SW) * 4;
+#pragma unroll
+  for (int k = 0; k < XP; ++k) {
+    const int go = C.xgo[k];
+    const int t = px + go;
+    const bool out = (unsigned)t >= (unsigned)P.X;
+    const int fix = go > 0 ? -P.X : P.X;
+    const unsigned o = CROP ? (out ? kOOB : pg + (unsigned)(go * 4)) : pg + (unsigned)((out ? go + fix : go) * 4);
+    cx[k] = bl32(gB, k < C.npx ? o : kOOB, fzo + (unsigned)C.xgi[k] * fcs);
+    const int d = C.xd[k], c = lx + d;
+    ax[k] = (unsigned)c < (unsigned)TW ? vown + d * 4 : hrow + (c & C.xm[k]) * 4;
+  }
+#pragma unroll
+  for (int k = 0; k < XP; ++k) {
+    const int go = C.ygo[k];
+    const int t = py + go;
+    const bool out = (unsigned)t >= (unsigned)P.Y;
+    const int fix = go > 0 ? -P.Y : P.Y;
+    const unsigned o = CROP ? (out ? kOOB : pg + (unsigned)(go * P.X * 4)) : pg + (unsigned)((out ? go + fix : go) * P.X * 4);
+    cy[k] = bl32(gB, k < C.npy ? o : kOOB, fzo + (unsigned)C.ygi[k] * fcs);
+    ay[k] = vown + C.yd[k] * TW * 4;
+  }
+  if (NP > 1) PEA_HDMA16(1, 2)
+  // the 1 / norm plane, chunk 0 and g have landed (chunk 1 may still fly)
+  if (NP > 1) PEA_HWAIT1(npc)
+  else PEA_HWAIT0()
+  const float invo = *(const float*)(W + PS + vown);
+  const float inv_own = fabsf(invo);
+#pragma unroll
+  for (int k = 0; k < XP; ++k) {
+    cx[k] *= fabsf(*(const float*)(W + PS + ax[k]));
+    cy[k] *= fabsf(*(const float*)(W + PS + ay[k]));
+    asm volatile("" : "+v"(cx[k]), "+v"(cy[k]));
+  }
+  lds_barrier();  // the 1 / norm plane is dead: the working planes may be written
+  if (NP > 2) PEA_HDMA16(2, 4)
+
+  constexpr bool KEEP = D_T <= 16;
+  f2 G[NP], eh[KEEP ? NP : 1];
+  float proj = 0.f;
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    convert_chunk<PS>(W, R, ps % 3, qq, act);
+    lds_barrier();  // the working planes hold chunk ps
+    f2 o;
+    o.x = *(const float*)(W + vown);
+    o.y = *(const float*)(W + PS + vown);
+    o = o * inv_own;
+    if (KEEP) {
+      eh[ps] = o;
+      asm volatile("" : "+v"(eh[ps]));
+    }
+    f2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < XP; ++k) {
+      f2 v;
+      v.x = *(const float*)(W + ax[k]);
+      v.y = *(const float*)(W + PS + ax[k]);
+      acc = __builtin_elementwise_fma((f2){cx[k], cx[k]}, v, acc);
+      if (k % 5 == 4) asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int k = 0; k < XP; ++k) {
+      f2 v;
+      v.x = *(const float*)(W + ay[k]);
+      v.y = *(const float*)(W + PS + ay[k]);
+      acc = __builtin_elementwise_fma((f2){cy[k], cy[k]}, v, acc);
+      if (k % 5 == 4) asm volatile("" ::: "memory");
+    }
+    if (!KEEP) {
+      proj = fmaf(o.x, acc.x, fmaf(o.y, acc.y, proj));
+      asm volatile("" : "+v"(proj));
+    }
+    asm volatile("" : "+v"(acc));
+    G[ps] = acc;
+    if (ps + 1 < NP) {
+      // everyone is done with the working planes and with ring buffer ps % 3; chunk ps + 1 has landed (ps + 2 may still fly)
+      if (ps + 2 < NP) PEA_HWAIT1(npc)
+      else PEA_HWAIT0()
+      if (ps + 3 < NP) PEA_HDMA16(ps % 3, 2 * ps + 6)
+    }
+  }
+#undef PEA_HDMA16
+
+  if (KEEP) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) proj = fmaf(eh[ps].x, G[ps].x, fmaf(eh[ps].y, G[ps].y, proj));
+  }
+  if (invo < 0.f) proj = 0.f;  // clamp branch of F.normalize
+  const float sc = dl * inv_own;
+  const float pn = proj * inv_own;
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    float ex, ey;
+    if (KEEP) { ex = eh[ps].x * proj; ey = eh[ps].y * proj; }
+    else {
+      ex = bl_emb<__half>(xB, ph, hzo + (unsigned)(2 * ps) * hcs) * pn;
+      ey = bl_emb<__half>(xB, ph, hzo + (unsigned)(2 * ps + 1) * hcs) * pn;
+    }
+    bs_emb<__half, true>(dB, (G[ps].x - ex) * sc, ph, hzo + (unsigned)(2 * ps) * hcs);
+    bs_emb<__half, true>(dB, (G[ps].y - ey) * sc, ph, hzo + (unsigned)(2 * ps + 1) * hcs);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward (self loss with TRAIN, or inference), f16 e; writes the f32 1 / norm plane for the backward.  Epilogue as k_fwd_xdma.
+// ------------------------------------------------------------------------------------------------------------------
+template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN, int WPE>
+__global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, const XParams C, const __half* __restrict__ e,
+                                                             const float* __restrict__ target, const float* __restrict__ weight,
+                                                             const uint8_t* __restrict__ mask, float* __restrict__ affs,
+                                                             float* __restrict__ gout, LossState* __restrict__ st,
+                                                             float* __restrict__ inv_out) {
+  constexpr int NT = TH * TW, PS = PSU * 256, PH = PS / 2, NP = D_T / 2, TP = NT, QP = TP / 4, NSL = QP / 64;
+  constexpr int KMAX = kXP;
+  constexpr int ITEMS = (KMAX * QP + NT - 1) / NT;
+  static_assert(TW == 32 && D_T % 2 == 0 && QP % 64 == 0 && PS % 512 == 0, "lane mapping / channel pairs");
+  static_assert(KMAX * TP * 4 + KMAX * NSL * 4 <= 5 * PS, "the parked dot products fit the dead planes");
+  extern __shared__ f4 lds4[];
+  char* lds = (char*)lds4;
+  char* const W = lds;
+  char* const R = lds + 2 * PS;
+  float* sA = (float*)lds;                          // [K][TP] dot products, over the dead planes
+  float* s_part = (float*)(lds + KMAX * TP * 4);    // [K][NSL]
+  int tile, b, z, y0, x0;
+  if (!xdma_tile<TH, TW>(C, P, tile, b, z, y0, x0)) return;
+  const size_t S = (size_t)P.S;
+  const unsigned YX = (unsigned)(P.Y * P.X);
+  const rsrc_t xB = mkbuf(e + (size_t)b * D_T * S);
+  const rsrc_t aB = mkbuf(affs ? affs + (size_t)b * P.K * S : nullptr), gB = mkbuf(gout ? gout + (size_t)b * P.K * S : nullptr);
+  const rsrc_t tB = mkbuf(TRAIN ? target + (size_t)b * P.tbs : nullptr), wB = mkbuf(TRAIN ? weight + (size_t)b * P.wbs : nullptr);
+  const rsrc_t mB = mkbuf(mask ? mask + (size_t)b * P.mbs : nullptr);
+  const rsrc_t iB = mkbuf(inv_out ? inv_out + (size_t)b * S : nullptr);
+  const unsigned hcs = (unsigned)P.S * 2u, hzo = (unsigned)z * YX * 2u;
+  const unsigned ecs = (unsigned)P.S * 4u, ezo = (unsigned)z * YX * 4u;  // the f32 tensors
+  const bool has_a = affs != nullptr, has_g = gout != nullptr, has_m = mask != nullptr;
+  const unsigned af = P.flags & kActMask;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
+
+  unsigned vo[2], vo8;
+  bool act[2], act8;
+  int qq[2];
+  x_items<TH, TW, CROP>(P, C, y0, x0, wave, lane, vo, act, qq, vo8, act8);
+  const int wbase = wave * 1024;
+  const int npc = 2 * (__builtin_amdgcn_ballot_w64(act8) != 0);
+#define PEA_HDMA16(rbuf, ch)                                                                                                  \
+  if (act8) {                                                                                                               \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(R + ((rbuf) * 2) * PH + wbase), 16, vo8, hzo + (unsigned)(ch) * hcs, 0, 0);        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(R + ((rbuf) * 2 + 1) * PH + wbase), 16, vo8, hzo + (unsigned)((ch) + 1) * hcs, 0, 0); \
+  }
+  PEA_HDMA16(0, 0)
+  if (NP > 1) PEA_HDMA16(1, 2)
+
+  int an[kXP];
+  const int vown = ((C.hy0 + ly) * TW + lx) * 4;
+  const int hrow = (C.QV * 4 + ly * C.SW) * 4;
+#pragma unroll
+  for (int k = 0; k < kXP; ++k) {
+    const int d = C.fd[k], c = lx + d;
+    const int a_x = (unsigned)c < (unsigned)TW ? vown + d * 4 : hrow + (c & C.fm[k]) * 4;
+    an[k] = C.fax[k] ? a_x : vown + d * TW * 4;
+  }
+  if (NP > 1) PEA_HWAIT1(npc)
+  else PEA_HWAIT0()
+  if (NP > 2) PEA_HDMA16(2, 4)
+
+  f2 dot[kXP], ssq[kXP], oss = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < kXP; ++k) { dot[k] = (f2){0.f, 0.f}; ssq[k] = (f2){0.f, 0.f}; }
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    convert_chunk<PS>(W, R, ps % 3, qq, act);
+    lds_barrier();
+    f2 o;
+    o.x = *(const float*)(W + vown);
+    o.y = *(const float*)(W + PS + vown);
+    oss = __builtin_elementwise_fma(o, o, oss);
+#pragma unroll
+    for (int k = 0; k < kXP; ++k) {
+      f2 v;
+      v.x = *(const float*)(W + an[k]);
+      v.y = *(const float*)(W + PS + an[k]);
+      dot[k] = __builtin_elementwise_fma(o, v, dot[k]);
+      ssq[k] = __builtin_elementwise_fma(v, v, ssq[k]);
+      if (k % 5 == 4) asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int k = 0; k < kXP; ++k) asm volatile("" : "+v"(dot[k]), "+v"(ssq[k]));
+    asm volatile("" : "+v"(oss));
+    if (ps + 1 < NP) {
+      if (ps + 2 < NP) PEA_HWAIT1(npc)
+      else PEA_HWAIT0()
+      if (ps + 3 < NP) PEA_HDMA16(ps % 3, 2 * ps + 6)
+    }
+  }
+#undef PEA_HDMA16
+
+  // ---- normalise; the lane's own 1 / norm for the backward.  (The pixel's coordinates are derived again from an opaque copy of
+  //      the lane id: kept from the top they would be two registers more across the channel loop.)
+  int tid_ = (int)threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int py = y0 + (tid_ >> 5), px = x0 + (tid_ & 31);
+  const bool live = py < P.Y && px < P.X;
+  const unsigned pe = live ? (unsigned)(py * P.X + px) * 4u : kOOB;
+  const float osum = oss.x + oss.y;
+  const float inv_eps = 1.0f / P.eps;
+  const float inv_own = rnorm(osum, inv_eps);
+  if (inv_out) bs32(iB, osum < P.eps * P.eps ? -inv_own : inv_own, pe, ezo);
+  lds_barrier();  // every lane is done with the working planes: sA goes over them
+#pragma unroll
+  for (int k = 0; k < kXP; ++k) {
+    if (k < C.nf) {
+      float a = (dot[k].x + dot[k].y) * inv_own * rnorm(ssq[k].x + ssq[k].y, inv_eps);
+      if (CROP) {
+        const int q = (C.fax[k] ? px : py) + C.fd[k];
+        a = (unsigned)q < (unsigned)(C.fax[k] ? P.X : P.Y) ? a : 0.f;
+      }
+      sA[C.fi[k] * TP + (int)threadIdx.x] = a;
+    }
+  }
+  // ---- the epilogue's operands: item = (offset, quad of 4 x-adjacent tile pixels)
+  bool ion[ITEMS];
+  unsigned ivo[ITEMS];
+  int iqd[ITEMS], igy[ITEMS], igx[ITEMS], isl[ITEMS];
+  f4 t4[ITEMS], w4[ITEMS];
+  unsigned m4[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int tt = it * NT + tid_;
+    const int sl = __builtin_amdgcn_readfirstlane(tt / QP);
+    ion[it] = sl < P.K;
+    isl[it] = min(sl, P.K - 1);
+    const int qd = tt - (tt / QP) * QP;
+    iqd[it] = qd;
+    const int l4 = qd * 4;
+    igy[it] = y0 + l4 / TW;
+    igx[it] = x0 + l4 % TW;
+    const bool lv = ion[it] && igy[it] < P.Y && igx[it] < P.X;
+    ivo[it] = lv ? (unsigned)(igy[it] * P.X + igx[it]) * 4u : kOOB;
+  }
+  if (TRAIN) {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const unsigned so = ezo + (unsigned)isl[it] * ecs;
+      t4[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(tB, ivo[it], so, kAuxNT));
+      w4[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wB, ivo[it], so, kAuxNT));
+      m4[it] = has_m ? __builtin_amdgcn_raw_buffer_load_b32(mB, ivo[it] == kOOB ? kOOB : ivo[it] >> 2,
+                                                           (ezo >> 2) + (unsigned)isl[it] * (unsigned)P.S, kAuxNT)
+                     : 0x01010101u;
+    }
+  }
+  lds_barrier();
+
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    if (!ion[it]) continue;  // wave-uniform
+    const int sl = isl[it];
+    const f4 a4 = *(const f4*)(sA + sl * TP + iqd[it] * 4);
+    const unsigned so = ezo + (unsigned)sl * ecs;
+    if (has_a) {
+      f4 o = a4;
+      if (af) { o.x = act_affs(o.x, af); o.y = act_affs(o.y, af); o.z = act_affs(o.z, af); o.w = act_affs(o.w, af); }
+      bs128<true>(aB, o, ivo[it], so);
+    }
+    if (TRAIN) {
+      float acc = 0.f;
+      f4 g4;
+      const float gs = C.gs[sl];
+      const int ax_ = C.oax[sl], od_ = C.od[sl];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float m = (float)((m4[it] >> (8 * j)) & 0xffu);
+        const float r = a4[j] * m - t4[it][j] * m;
+        float wr = w4[it][j] * r;
+        if (CROP) {
+          const int q = (ax_ == 1 ? igx[it] + j : igy[it]) + od_;
+          wr = (unsigned)q < (unsigned)(ax_ == 1 ? P.X : P.Y) ? wr : 0.f;
+        }
+        g4[j] = gs * wr * m;
+        acc = fmaf(wr, r, acc);
+      }
+      if (has_g) bs128<false>(gB, g4, ivo[it], so);
+      const float red = wave_sum63(acc);
+      if ((tid_ & 63) == 63) s_part[sl * NSL + (iqd[it] >> 6)] = red;
+    }
+  }
+  if (TRAIN) {
+    lds_barrier();
+    if (wave == 0 && (int)threadIdx.x < P.K) {
+      float v = 0.f;
+#pragma unroll
+      for (int s = 0; s < NSL; ++s) v += s_part[threadIdx.x * NSL + s];
+      loss_accumulate(st, tile, threadIdx.x, v);
+    }
+  }
+}
+
+#undef PEA_HWAIT1
+#undef PEA_HWAIT0
+
+}  // namespace pea

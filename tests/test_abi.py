@@ -149,7 +149,9 @@ def test_cross_kernels_cover_the_shipped_2d_shapes(pkg, lib):
         assert q(desc(32, 704, 704, pkg.multi_offset([1, 3, 5, 9, 11], 4)), bwd) == 1   # BASELINE configs[2]
         assert q(desc(64, 544, 544, cv[:8]), bwd) == 1                                  # configs[4] in f32
         assert q(desc(8, 544, 544, cv), bwd) == 0                                       # D not in {16, 32, 64}
-        assert q(desc(16, 544, 544, cv, dtype=1), bwd) == 0       # f16 storage
+        assert q(desc(16, 544, 544, cv, dtype=1), bwd) == 1       # f16 storage: pea_xdma_h16.h (8-pixel DMA items: X % 8 == 0)
+        assert q(desc(64, 544, 544, cv[:8], dtype=1), bwd) == 1   # BASELINE configs[4]
+        assert q(desc(16, 544, 548, cv, dtype=1), bwd) == 0
         assert q(desc(16, 544, 542, cv), bwd) == 0                # X % 4 != 0
         assert q(desc(16, 40, 56, cv, B=2), bwd) == 0             # narrower than a tile plus its strips
     assert q(desc(16, 34, 34, cv[:2]), 0) == 0
