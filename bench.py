@@ -175,7 +175,7 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
     P = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     fwd = lambda: L.pea_affinity_fwd_ex(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(affs), P(G), P(INV), P(lossv), P(work), wsb, st)
-    bwd = lambda: L.pea_affinity_bwd_ex(ctypes.byref(desc), P(Ed), None, P(G), P(INV), P(one), P(dE), None, st)
+    bwd = lambda: L.pea_affinity_bwd_ex2(ctypes.byref(desc), P(Ed), None, P(G), P(INV), P(affs), P(one), P(dE), None, st)
     in_step_times_ms(fwd, bwd, 3)
     kf, kb = in_step_times_ms(fwd, bwd, max(10, min(args.steps, 50)))
     ab = algorithmic_bytes_per_px(Dm, K, 2 if c["f16"] else 4, mask=M is not None)
@@ -466,8 +466,9 @@ def main():
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         INV = torch.empty(B, H, W, device=dev)  # 1 / norm plane: written by the forward, staged by the cross backward
         fwd = lambda: L.pea_affinity_fwd_ex(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(affs), P(G), P(INV), P(lossv), P(work), wsb, st)
-        bwd = lambda: L.pea_affinity_bwd_ex(ctypes.byref(desc), P(Ed), None, P(G), P(INV), P(one), P(dE), None, st)
-        inf = lambda: L.pea_affinity_infer(ctypes.byref(desc), P(Ed), None, P(affs), st)
+        bwd = lambda: L.pea_affinity_bwd_ex2(ctypes.byref(desc), P(Ed), None, P(G), P(INV), P(affs), P(one), P(dE), None, st)
+        affs2 = torch.empty_like(affs)  # (the other entry points get their own map: `affs` is an input of the backward)
+        inf = lambda: L.pea_affinity_infer(ctypes.byref(desc), P(Ed), None, P(affs2), st)
         # the labels-in training step (embedding_loss_from_labels): same outputs from the int32 label image, no t / w / m
         lab = torch.from_numpy(synth.synth_labels(B, (1, H, W), 555 + rank)[:, 0].copy()).to(dev)
         wtab = torch.empty(B * K * 2, device=dev)
@@ -477,11 +478,11 @@ def main():
         lsb = L.pea_labels_scratch_bytes(ctypes.byref(desc))  # g + 1 / norm plane lent to the two-launch labels step
         lscr = torch.empty(max(lsb, 4) // 4, device=dev)
         labels_step = lambda: (L.pea_label_weights(ctypes.byref(desc), P(lab), lflags, P(wtab), P(cnt), cnt_bytes, st),
-                               L.pea_affinity_fwd_bwd_labels_ex(ctypes.byref(desc), P(Ed), None, P(lab), P(wtab), lflags, P(affs),
+                               L.pea_affinity_fwd_bwd_labels_ex(ctypes.byref(desc), P(Ed), None, P(lab), P(wtab), lflags, P(affs2),
                                                                 P(lossv), None, P(dE), P(work), wsb, P(lscr), lsb, st))
-        labels_one = lambda: L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(Ed), None, P(lab), P(wtab), lflags, P(affs),
+        labels_one = lambda: L.pea_affinity_fwd_bwd_labels(ctypes.byref(desc), P(Ed), None, P(lab), P(wtab), lflags, P(affs2),
                                                            P(lossv), None, P(dE), P(work), wsb, st)
-        labels_two = lambda: L.pea_affinity_fwd_bwd_labels_ex(ctypes.byref(desc), P(Ed), None, P(lab), P(wtab), lflags, P(affs),
+        labels_two = lambda: L.pea_affinity_fwd_bwd_labels_ex(ctypes.byref(desc), P(Ed), None, P(lab), P(wtab), lflags, P(affs2),
                                                               P(lossv), None, P(dE), P(work), wsb, P(lscr), lsb, st)
         # the embedding head in front of the path (OutConv 32 -> D, scripts_cvppp/model/unet2d_residual.py:307): forward and
         # backward (dx, dW, db) of the 1x1 convolution on the decoder's 32-channel feature map

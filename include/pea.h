@@ -127,7 +127,7 @@ size_t pea_workspace_bytes(const PeaDesc *desc);
 int pea_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
 
 /* Re-read the PEA_* environment switches (they are read once, at the first call): PEA_FORCE_DIRECT, PEA_FWD_XDMA, PEA_BWD_XDMA,
- * PEA_LABELS_DUAL, PEA_FWD_WG3 -- A/B and debugging switches; tests that change one call this. */
+ * PEA_LABELS_DUAL, PEA_FWD_WG3, PEA_INFER_XDMA, PEA_BWD_PF -- A/B and debugging switches; tests that change one call this. */
 void pea_reload_env(void);
 
 /* Inference: affs[B,K,Z,Y,X] only.  e_other may be NULL. */
@@ -173,6 +173,14 @@ int pea_affinity_fwd_ex(const PeaDesc *desc, const void *e, const void *e_other,
                         float *loss_out, void *workspace, size_t workspace_bytes, void *stream);
 int pea_affinity_bwd_ex(const PeaDesc *desc, const void *e, const void *e_other, const float *g, const float *inv_norm,
                         const float *dloss, void *de, void *de_other, void *stream);
+/* pea_affinity_bwd_ex with the forward's affinity map as one more input: affs [B,K,Z,Y,X] f32 must be the RAW cosine map that
+ * pea_affinity_fwd(_ex) wrote for the same descriptor with NO activation flag (PEA_FLAG_RELU_AFFS ...), unmodified.  The self-loss
+ * backward then knows <ehat, G> = sum_i g_i(p) a_i(p) + g_i(p - o_i) a_i(p - o_i) before it touches a channel and finishes two
+ * channels per chunk (csrc/pea_xdma_pf.h): no second read of e at D > 16, three workgroups per CU for short stencils.  affs == NULL,
+ * a second operand, z offsets, D = 16 (where the kernel that keeps G is the faster one) or an activation flag in desc->flags:
+ * exactly pea_affinity_bwd_ex. */
+int pea_affinity_bwd_ex2(const PeaDesc *desc, const void *e, const void *e_other, const float *g, const float *inv_norm,
+                         const float *affs, const float *dloss, void *de, void *de_other, void *stream);
 int pea_inv_norm(const PeaDesc *desc, const void *e, float *inv_norm_out, void *stream);
 /* Host-only: 1 when the LDS-DMA cross kernels cover the descriptor (self loss, 16-byte aligned tensors assumed) for the
  * forward (backward == 0) or the backward (backward == 1, given the 1 / norm plane); backward == 2: the cross loss with a detached

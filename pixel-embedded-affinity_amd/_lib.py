@@ -24,7 +24,7 @@ FLAG_RELU_AFFS, FLAG_ONE_MINUS, FLAG_HALF_SHIFT, FLAG_CLAMP01, FLAG_ACCUMULATE_D
 TGT_PADDING, TGT_BOTH_FOREGROUND, TGT_MASK_INSIDE, TGT_ACCUMULATE = 1, 2, 4, 8
 
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_workspace_init", "pea_reload_env",
-           "pea_affinity_infer", "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_ex", "pea_affinity_bwd_ex", "pea_inv_norm",
+           "pea_affinity_infer", "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_ex", "pea_affinity_bwd_ex", "pea_affinity_bwd_ex2", "pea_inv_norm",
            "pea_cross_supported", "pea_affinity_bwd_dual", "pea_affinity_bwd_dual_ex", "pea_scale_inplace", "pea_scale_inplace_multi",
            "pea_fill_border_relu", "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd",
            "pea_targets_workspace_bytes", "pea_gen_targets", "pea_stitch_add", "pea_stitch_finalize",
@@ -148,6 +148,8 @@ def lib():
     L.pea_affinity_fwd_ex.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.pea_affinity_bwd_ex.restype = ctypes.c_int
     L.pea_affinity_bwd_ex.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pea_affinity_bwd_ex2.restype = ctypes.c_int
+    L.pea_affinity_bwd_ex2.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pea_cross_supported.restype = ctypes.c_int
     L.pea_cross_supported.argtypes = [dp, ctypes.c_int]
     L.pea_inv_norm.restype = ctypes.c_int

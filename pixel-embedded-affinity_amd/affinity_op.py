@@ -262,14 +262,17 @@ class FusedAffinityMSE(torch.autograd.Function):
                        "pea_affinity_fwd_ex")
         ctx.spec, ctx.desc = spec, d
         ctx.has_other = o_c is not None
-        ctx.save_for_backward(e_c, o_c, g, inv)
+        # the raw cosine map is an input of the projection-first backward (pea_affinity_bwd_ex2): saved like an input, so autograd's
+        # version counter catches an in-place edit of the returned map (affs.relu_()) between forward and backward
+        raw = affs if (inv is not None and o_c is None and spec.act == 0) else None
+        ctx.save_for_backward(e_c, o_c, g, inv, raw)
         loss, per_offset = loss_vec[0], loss_vec[1:]  # views of a buffer that is not itself returned
         ctx.mark_non_differentiable(affs, per_offset)
         return loss, affs, per_offset
 
     @staticmethod
     def backward(ctx, dloss, _daffs, _dvec):
-        e_c, o_c, g, inv = ctx.saved_tensors
+        e_c, o_c, g, inv, raw = ctx.saved_tensors
         want_e = ctx.needs_input_grad[0]
         want_o = ctx.has_other and ctx.needs_input_grad[1]
         if not (want_e or want_o) or dloss is None:
@@ -281,8 +284,8 @@ class FusedAffinityMSE(torch.autograd.Function):
             dl = dloss.to(device=e_c.device, dtype=torch.float32).contiguous()
             de = torch.empty_like(e_c) if want_e else None
             de_o = torch.empty_like(o_c) if want_o else None
-            _lib.check(L.pea_affinity_bwd_ex(ctypes.byref(ctx.desc), _ptr(e_c), _ptr(o_c), _ptr(g), _ptr(inv), _ptr(dl), _ptr(de),
-                                             _ptr(de_o), _stream()), "pea_affinity_bwd_ex")
+            _lib.check(L.pea_affinity_bwd_ex2(ctypes.byref(ctx.desc), _ptr(e_c), _ptr(o_c), _ptr(g), _ptr(inv), _ptr(raw), _ptr(dl),
+                                              _ptr(de), _ptr(de_o), _stream()), "pea_affinity_bwd_ex2")
         return de, de_o, None, None, None, None
 
 

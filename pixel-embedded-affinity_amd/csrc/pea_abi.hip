@@ -214,13 +214,18 @@ int pea_inv_norm(const PeaDesc* desc, const void* e, float* inv_norm_out, void* 
 
 int pea_affinity_bwd_ex(const PeaDesc* desc, const void* e, const void* e_other, const float* g, const float* inv_norm,
                         const float* dloss, void* de, void* de_other, void* stream) {
+  return pea_affinity_bwd_ex2(desc, e, e_other, g, inv_norm, nullptr, dloss, de, de_other, stream);
+}
+
+int pea_affinity_bwd_ex2(const PeaDesc* desc, const void* e, const void* e_other, const float* g, const float* inv_norm,
+                         const float* affs, const float* dloss, void* de, void* de_other, void* stream) {
   int rc = validate(desc);
   if (rc) return rc;
   if (!e || !g || (!de && !de_other)) return PEA_E_NULL;
   if (de_other && !e_other) return PEA_E_NULL;
   const size_t es = desc->dtype == PEA_F16 ? 2 : 4;
   if (misaligned(e, es) || misaligned(e_other, es) || misaligned(de, es) || misaligned(de_other, es) ||
-      misaligned(g, 4) || misaligned(dloss, 4) || misaligned(inv_norm, 4))
+      misaligned(g, 4) || misaligned(dloss, 4) || misaligned(inv_norm, 4) || misaligned(affs, 4))
     return PEA_E_ALIGN;
   const KParams P = make_params(desc);
   hipStream_t s = (hipStream_t)stream;
@@ -229,8 +234,8 @@ int pea_affinity_bwd_ex(const PeaDesc* desc, const void* e, const void* e_other,
   if (!e_other) {
     if (accumulate) return PEA_E_UNSUPPORTED;  // de += is implemented for the detached second operand's role-A backward only
     // self loss: the LDS-DMA cross kernel when the 1 / norm plane came along and the stencil is axis-aligned
-    if (dt == PEA_F32 && xdma_bwd_self(P, (const float*)e, inv_norm, g, dloss, (float*)de, s)) return hip_rc();
-    if (dt == PEA_F16 && xdma_bwd_self_h(P, e, inv_norm, g, dloss, de, s)) return hip_rc();
+    if (dt == PEA_F32 && xdma_bwd_self(P, (const float*)e, inv_norm, g, affs, dloss, (float*)de, s)) return hip_rc();
+    if (dt == PEA_F16 && xdma_bwd_self_h(P, e, inv_norm, g, affs, dloss, de, s)) return hip_rc();
     return run_bwd(P, dt, 3, e, e, e, g, dloss, de, s);
   }
   // (a second operand that aliases the first is still a second operand: its roles are separate)
@@ -317,7 +322,9 @@ int pea_affinity_fwd_bwd_labels_ex(const PeaDesc* desc, const void* e, const voi
       rc = hip_rc();
       if (rc) return rc;
       launch_loss_finish(P, st, loss_out, s);
-      if (!xdma_bwd_self(P, (const float*)e, inv, g, dloss, (float*)de, s)) return run_bwd(P, desc->dtype, 3, e, e, e, g, dloss, de, s);
+      // (the map this forward wrote is raw unless the caller asked for an activation: the projection-first backward takes it)
+      if (!xdma_bwd_self(P, (const float*)e, inv, g, (P.flags & kActMask) ? nullptr : affs, dloss, (float*)de, s))
+        return run_bwd(P, desc->dtype, 3, e, e, e, g, dloss, de, s);
       return hip_rc();
     }
     rc = hip_rc();

@@ -24,6 +24,7 @@ struct Env {
   int bwd_xdma;       // PEA_BWD_XDMA=0: no LDS-DMA backward
   int labels_dual;    // PEA_LABELS_DUAL=0: pea_affinity_fwd_bwd_labels_dual reports PEA_E_UNSUPPORTED
   int infer_xdma;     // PEA_INFER_XDMA=0: inference (affs only) on k_fwd_tiled / the chunked kernels instead of the LDS-DMA forward
+  int bwd_pf;         // PEA_BWD_PF=0: never the projection-first backward (pea_xdma_pf.h); 2: also at D = 16 (where it loses)
   int fwd_wg3;        // PEA_FWD_WG3=0: the 2-workgroups-per-CU forward
 };
 const Env& env();
@@ -107,8 +108,10 @@ void launch_inv_norm(const KParams& P, int dtype, const void* e, float* inv, hip
 int xdma_cross_supported(const KParams& P, int dtype, int mode);
 
 // backward: roles bit 0 = A (x is the first operand, neighbours nbA), bit 1 = B (x is the second operand, neighbours nbB)
-bool xdma_bwd_self(const KParams& P, const float* x, const float* inv, const float* g, const float* dl, float* dx, hipStream_t s);
-bool xdma_bwd_self_h(const KParams& P, const void* x, const float* inv, const float* g, const float* dl, void* dx, hipStream_t s);  // f16
+bool xdma_bwd_self(const KParams& P, const float* x, const float* inv, const float* g, const float* affs, const float* dl, float* dx,
+                   hipStream_t s);  // affs: the raw cosine map or null
+bool xdma_bwd_self_h(const KParams& P, const void* x, const float* inv, const float* g, const float* affs, const float* dl, void* dx,
+                     hipStream_t s);  // f16 storage
 bool xdma_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* dl,
                     float* de, bool accumulate, hipStream_t s);
 bool xdma_bwd_dual(const KParams& P, const float* e, const float* ema, const float* inv, const float* inv_other, const float* g,

@@ -31,6 +31,7 @@ void env_load() {
   g_env.labels_dual = env_int("PEA_LABELS_DUAL", 1);
   g_env.fwd_wg3 = env_int("PEA_FWD_WG3", 1);
   g_env.infer_xdma = env_int("PEA_INFER_XDMA", 1);
+  g_env.bwd_pf = env_int("PEA_BWD_PF", 1);
 }
 }  // namespace
 const Env& env() {

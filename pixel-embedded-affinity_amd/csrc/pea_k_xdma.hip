@@ -2,6 +2,7 @@
 // One translation unit of libpea_hip.so (pea_host.h).
 #include "pea_host.h"
 #include "pea_xdma_h16.h"
+#include "pea_xdma_pf.h"
 
 namespace pea {
 
@@ -122,23 +123,68 @@ bool fwd_self_h(const KParams& P, const FwdArgs& A, hipStream_t s) {
   return true;
 }
 
-constexpr int kXdmaPSUH = 52;  // backward, f16: 13312-byte f32 planes (the half-size ring planes stay whole 256-byte units)
+constexpr int kXdmaPSUH = 52;   // backward, f16: 13312-byte f32 planes (the half-size ring planes stay whole 256-byte units)
+constexpr int kXdmaPSUHS = 28;  // small crosses: 7168-byte planes, 35 KB per workgroup
 template <int D_T>
-bool bwd_self_h(const KParams& P, const __half* x, const float* inv, const float* g, const float* dl, __half* dx, hipStream_t s) {
-  if (P.X % 8 || P.Z != 1 || misaligned(x, 16) || misaligned(inv, 16) || misaligned(g, 4) || misaligned(dx, 2)) return false;
+bool bwd_self_h(const KParams& P, const __half* x, const float* inv, const float* g, const float* affs, const float* dl, __half* dx,
+                hipStream_t s) {
+  if (P.X % 8 || P.Z != 1 || misaligned(x, 16) || misaligned(inv, 16) || misaligned(g, 4) || misaligned(dx, 2) || misaligned(affs, 4))
+    return false;
   XPlan X;
+  const dim3 blk(kXdmaTH * kXdmaTW);
+  const bool crop = P.border != PEA_BORDER_CIRCULAR;
+  if (affs && env().bwd_pf && !(P.flags & kActMask) && (D_T > 16 || env().bwd_pf == 2)) {  // the projection first (pea_xdma_pf.h)
+    const bool small = plan(P, kXdmaPSUHS, 0, &X);
+    if ((small || plan(P, kXdmaPSUH, 0, &X)) && X.C.npz == 0 && X.C.npx <= kXP && X.C.npy <= kXP) {
+      const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd));
+#define PEA_HPF(CROP_, PSU_, WPE_)                                                                   \
+  {                                                                                                  \
+    constexpr auto kern = k_bwd_xdma_h<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, kXP, true, WPE_>;          \
+    PEA_LAUNCH(kern, grid, blk, (size_t)5 * PSU_ * 256, s, P, X.C, x, inv, g, affs, dl, dx)            \
+  }
+      // (87 VGPRs: the conversion's temporaries keep it above the 80 a third workgroup would need; small planes all the same --
+      //  less LDS per workgroup never hurts the other kernels sharing the CU in a multi-stream section)
+      if (small) { if (crop) PEA_HPF(true, kXdmaPSUHS, 4) else PEA_HPF(false, kXdmaPSUHS, 4) }
+      else { if (crop) PEA_HPF(true, kXdmaPSUH, 4) else PEA_HPF(false, kXdmaPSUH, 4) }
+#undef PEA_HPF
+      return true;
+    }
+  }
   if (!plan(P, kXdmaPSUH, 0, &X) || X.C.npz > 0) return false;
   constexpr int XP = D_T > 32 ? 8 : kXP;
   if (X.C.npx > XP || X.C.npy > XP) return false;
   const size_t lds = (size_t)5 * kXdmaPSUH * 256;
-  const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
-  if (P.border != PEA_BORDER_CIRCULAR) {
+  const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd));
+  if (crop) {
     constexpr auto kern = k_bwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUH, true, XP>;
-    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, x, inv, g, dl, dx)
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, x, inv, g, (const float*)nullptr, dl, dx)
   } else {
     constexpr auto kern = k_bwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUH, false, XP>;
-    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, x, inv, g, dl, dx)
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, x, inv, g, (const float*)nullptr, dl, dx)
   }
+  return true;
+}
+
+// ---- the backward with the projection first (pea_xdma_pf.h): 2D / in-plane stencils, self loss, f32, needs the raw affs map
+constexpr int kXdmaPSUS = 27;  // small crosses (reach <= 11 or so): 6912-byte planes, 41 KB of ring, three workgroups per CU
+template <int D_T>
+bool bwd_self_pf(const KParams& P, const float* x, const float* inv, const float* g, const float* affs, const float* dl, float* dx,
+                 hipStream_t s) {
+  if (misaligned(x, 16) || misaligned(inv, 16) || misaligned(g, 4) || misaligned(affs, 4) || misaligned(dx, 4)) return false;
+  XPlan X;
+  const bool small = plan(P, kXdmaPSUS, 0, &X);
+  if (!small && !plan(P, kXdmaPSU, 0, &X)) return false;
+  if (X.C.npz > 0 || X.C.npx > kXP || X.C.npy > kXP) return false;
+  const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+#define PEA_PF(CROP_, PSU_, WPE_, RB_)                                                         \
+  {                                                                                            \
+    constexpr auto kern = k_bwd_xdma_pf<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, WPE_, RB_>;        \
+    PEA_LAUNCH(kern, grid, blk, (size_t)2 * RB_ * PSU_ * 256, s, P, X.C, x, inv, g, affs, dl, dx) \
+  }
+  const bool crop = P.border != PEA_BORDER_CIRCULAR;
+  if (small) { if (crop) PEA_PF(true, kXdmaPSUS, 6, 3) else PEA_PF(false, kXdmaPSUS, 6, 3) }
+  else { if (crop) PEA_PF(true, kXdmaPSU, 4, 3) else PEA_PF(false, kXdmaPSU, 4, 3) }
+#undef PEA_PF
   return true;
 }
 
@@ -228,20 +274,32 @@ bool xdma_fwd_labels(const KParams& P, const FwdArgs& A, const int32_t* labels, 
   return false;
 }
 
-// the cross backward (self loss, f32 storage, axis-aligned stencil): needs the 1 / norm plane
-bool xdma_bwd_self(const KParams& P, const float* x, const float* inv, const float* g, const float* dl, float* dx, hipStream_t s) {
+// the cross backward (self loss, f32 storage, axis-aligned stencil): needs the 1 / norm plane; with the raw affinity map too
+// (affs: what the forward wrote with no activation flag) the projection-first kernel runs
+bool xdma_bwd_self(const KParams& P, const float* x, const float* inv, const float* g, const float* affs, const float* dl, float* dx,
+                   hipStream_t s) {
   if (!inv || !env().bwd_xdma || env().force_direct) return false;
+  // (D = 16 keeps k_bwd_xdma: with G in 16 registers and the own pixel kept there is no second read to save, and the stores
+  //  inside the chunk loop cost more than they give: 137 against 94-107 us at the bench shape; PEA_BWD_PF=2 forces it)
+  if (affs && env().bwd_pf && !(P.flags & kActMask) && (P.D > 16 || env().bwd_pf == 2)) {
+    bool done = false;
+    if (P.D == 16) done = bwd_self_pf<16>(P, x, inv, g, affs, dl, dx, s);
+    else if (P.D == 32) done = bwd_self_pf<32>(P, x, inv, g, affs, dl, dx, s);
+    else if (P.D == 64) done = bwd_self_pf<64>(P, x, inv, g, affs, dl, dx, s);
+    if (done) return true;
+  }
   if (P.D == 16) return bwd_self<16>(P, x, inv, g, dl, dx, s);
   if (P.D == 32) return bwd_self<32>(P, x, inv, g, dl, dx, s);
   if (P.D == 64) return bwd_self<64>(P, x, inv, g, dl, dx, s);
   return false;
 }
 
-bool xdma_bwd_self_h(const KParams& P, const void* x, const float* inv, const float* g, const float* dl, void* dx, hipStream_t s) {
+bool xdma_bwd_self_h(const KParams& P, const void* x, const float* inv, const float* g, const float* affs, const float* dl, void* dx,
+                     hipStream_t s) {
   if (!inv || !env().bwd_xdma || env().force_direct) return false;
-  if (P.D == 16) return bwd_self_h<16>(P, (const __half*)x, inv, g, dl, (__half*)dx, s);
-  if (P.D == 32) return bwd_self_h<32>(P, (const __half*)x, inv, g, dl, (__half*)dx, s);
-  if (P.D == 64) return bwd_self_h<64>(P, (const __half*)x, inv, g, dl, (__half*)dx, s);
+  if (P.D == 16) return bwd_self_h<16>(P, (const __half*)x, inv, g, affs, dl, (__half*)dx, s);
+  if (P.D == 32) return bwd_self_h<32>(P, (const __half*)x, inv, g, affs, dl, (__half*)dx, s);
+  if (P.D == 64) return bwd_self_h<64>(P, (const __half*)x, inv, g, affs, dl, (__half*)dx, s);
   return false;
 }
 

@@ -27,6 +27,26 @@
 
 namespace pea {
 
+// In-kernel stamps (cdna_hip_programming.md section 7): only in the diagnostic build profiles/microbench/stamp_bwd.hip, which
+// defines PEA_STAMPS; in the library no stamp executes.  Wave `w` of workgroup `b` < kStampWgs writes s_memtime into its own row
+// of a buffer nothing else reads.
+#ifdef PEA_STAMPS
+constexpr int kStampWgs = 128, kStampN = 96;
+__device__ unsigned long long* g_stamps;
+#define PEA_STAMP(i)                                                                                              \
+  {                                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    unsigned long long t_;                                                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    if (blockIdx.x < kStampWgs && (threadIdx.x & 63) == 0 && (i) < kStampN)                                       \
+      g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * kStampN + (i)] = t_;                               \
+  }
+#else
+#define PEA_STAMP(i)
+#endif
+constexpr int kStampLast = 95;
+
 constexpr int kXP = 10;  // (offset, role) pairs per axis held in registers (CVPPP: 5 shifts x 2 roles)
 constexpr int kXZ = 8;   // (offset, role) pairs along z (AC3/AC4 norm5: shifts 1, 2, 3, 4)
 constexpr int kXK = 16;  // channels (offsets) the forward's epilogue handles
@@ -343,6 +363,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + w1), 16, vo1, so, 0, 0); \
     }                                                                                                               \
   }
+  PEA_STAMP(0)
   PEA_XDMA(iB, 4 * PS, ezo)
   PEA_XDMA(xB, 0, ezo)
   PEA_XDMA(xB, PS, ezo + ecs)
@@ -404,7 +425,9 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   PEA_XDMA(xB, 2 * PS, ezo + 2u * ecs)
   PEA_XDMA(xB, 3 * PS, ezo + 3u * ecs)
   // inv, chunk 0 and g have landed (the 4 DMA instructions of chunk 1 may still fly); every wave's share of them too
+  PEA_STAMP(1)
   PEA_XWAIT1()
+  PEA_STAMP(2)
 
   // coefficient of a pair = g * 1 / |e(q)|
   const float invo = OTHER ? invo_g : *(const float*)(lds + 4 * PS + vown);
@@ -457,6 +480,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       asm volatile("" : "+v"(eh[ps]));
     }
     f2 acc = {0.f, 0.f};
+#ifndef PEA_ABL_NOGATHER  // (diagnostic builds of profiles/microbench/stamp_bwd.hip only)
 #pragma unroll
     for (int k = 0; k < XP; ++k) {
       f2 v;
@@ -473,6 +497,9 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       acc = __builtin_elementwise_fma((f2){cy[k], cy[k]}, v, acc);
       if (k % 5 == 4) asm volatile("" ::: "memory");
     }
+#else
+    acc.x = cx[ps % XP] + cy[ps % XP];
+#endif
 #pragma unroll
     for (int k = 0; k < ZP; ++k) acc = __builtin_elementwise_fma((f2){cz[k], cz[k]}, zv[ps & 1][k], acc);
     if (!KEEP) {
@@ -481,17 +508,22 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
     }
     asm volatile("" : "+v"(acc));  // the chunk's sums exist before its barrier
     G[ps] = acc;
+    PEA_STAMP(3 + 3 * ps)
     if (ps + 1 < NP) {
       // chunk ps + 1 has landed (chunk ps + 2, issued after it, may still fly); everyone is done with buffer ps % 3
       if (ps + 2 < NP) {
         if (ZP > 0) PEA_XWAITZ()
         else PEA_XWAIT1()
       } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      PEA_STAMP(4 + 3 * ps)
       if (ps + 2 < NP) PEA_XZLOAD(ps + 2)
+#ifndef PEA_ABL_NODMA
       if (ps + 3 < NP) {
         PEA_XDMA(xB, bo, ezo + (unsigned)(2 * ps + 6) * ecs)
         PEA_XDMA(xB, bo + PS, ezo + (unsigned)(2 * ps + 7) * ecs)
       }
+#endif
+      PEA_STAMP(5 + 3 * ps)
     }
   }
 #undef PEA_XDMA
@@ -532,6 +564,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), dB, pe, ezo + (unsigned)(2 * ps) * ecs, AUXS);
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs, AUXS);
   }
+  PEA_STAMP(kStampLast)
 }
 
 // ------------------------------------------------------------------------------------------------------------------

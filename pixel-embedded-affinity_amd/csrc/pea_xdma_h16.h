@@ -8,16 +8,28 @@
 //     and wave instead of two, half the bytes from HBM and, what bounds the backward, half the bytes from L2 into the CU --
 //     into a ring of three chunk buffers of half-size planes;
 //   * before a chunk is gathered the workgroup converts it (ds_read_b64 -> 4 x v_cvt_f32_f16 -> ds_write_b128, at most two quads
-//     per lane and plane) into ONE pair of f32 working planes laid out exactly like the planes pea_xdma.h gathers from.
+//     per lane and plane) into ONE f32 working buffer in which the two channels of a pixel sit side by side: the gather is one
+//     ds_read_b64 per pair (256 B/clk) instead of the planar ds_read2st64_b32 (128 B/clk).
 // Two barriers per chunk instead of one (converted / consumed); the second workgroup of the CU fills them.  LDS: backward
 // 2 x 13 KB + 6 x 6.5 KB = 64 KB (two workgroups per CU), forward 2 x 7.5 KB + 6 x 3.75 KB = 37.5 KB (three).
 // Self loss / inference, 2D, X % 8 == 0 (an 8-pixel DMA item never straddles a row end), axis-aligned stencils, D in {16, 32, 64}.
 #pragma once
-#include "pea_xdma.h"
+#include "pea_xdma_pf.h"
 
 namespace pea {
 
 typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+
+// acc += c * v for both channels of a pair, the coefficient c taken from the LOW (HI = false) or HIGH half of a register pair
+// that holds TWO pairs' coefficients.  hipcc materialises (f2){c, c} in two registers per coefficient (20 pairs: 40 VGPRs of
+// coefficients); v_pk_fma_f32's op_sel / op_sel_hi select the half per lane of the packed operation, so one register pair
+// serves two pairs: 20 VGPRs less in the gather loops, which is what lets the f16 kernels keep to their register budgets.
+template <bool HI>
+__device__ __forceinline__ f2 pk_fma_c(f2 cpair, f2 v, f2 acc) {
+  if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(cpair), "v"(v));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(cpair), "v"(v));
+  return acc;
+}
 
 // geometry of this lane's DMA items: up to two QUADS (4 pixels: the f32 1 / norm plane, and the conversion) and one OCT
 // (8 pixels: the f16 channel planes).  Same region order as pea_xdma.h (VF rows of TW pixels, then strip rows of SW pixels).
@@ -75,29 +87,38 @@ __device__ __forceinline__ void x_items(const KParams& P, const XParams& C, int 
   }
 #define PEA_HWAIT0() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-// f16 chunk `rbuf` of the ring -> the two f32 working planes
-template <int PS>
-__device__ __forceinline__ void convert_chunk(char* W, const char* R, int rbuf, const int (&qq)[2], const bool (&act)[2]) {
+// f16 chunk `rbuf` of the ring -> the f32 working buffer, the two channels of a pixel SIDE BY SIDE (8 bytes per region pixel).
+// The layout is free here (this step writes it, not the DMA), and it is what makes the gather cheap: one ds_read_b64 per
+// (offset, role) pair delivers both channels at 256 B/clk, where the planar form needs ds_read2st64_b32 at 128 B/clk -- and the
+// stamps (profiles/microbench/stamp_bwd.hip) say the gather phases are bound by exactly that pipe.
+template <int PS, int NT>
+__device__ __forceinline__ void convert_chunk(char* W, const char* R, int rbuf, int qa) {
   constexpr int PH = PS / 2;
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-      if (act[s]) {
-        const h4_t h = *(const h4_t*)(R + (rbuf * 2 + j) * PH + qq[s] * 8);
-        f4 v;
-        v.x = (float)h.x; v.y = (float)h.y; v.z = (float)h.z; v.w = (float)h.w;
-        *(f4*)(W + j * PS + qq[s] * 16) = v;
-      }
+  for (int s = 0; s < 2; ++s) {
+    const int q = s * NT + (int)threadIdx.x;  // = (s * (NT / 64) + wave) * 64 + lane: the quads this lane moved by DMA as well
+    if (q < qa) {
+      const h4_t h0 = *(const h4_t*)(R + (rbuf * 2) * PH + q * 8);
+      const h4_t h1 = *(const h4_t*)(R + (rbuf * 2 + 1) * PH + q * 8);
+      f4 a, b;
+      a.x = (float)h0.x; a.y = (float)h1.x; a.z = (float)h0.y; a.w = (float)h1.y;
+      b.x = (float)h0.z; b.y = (float)h1.z; b.z = (float)h0.w; b.w = (float)h1.w;
+      *(f4*)(W + q * 32) = a;
+      *(f4*)(W + q * 32 + 16) = b;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // backward, self loss (both roles), f16 e / de
 // ------------------------------------------------------------------------------------------------------------------
-template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP>
-__global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma_h(const KParams P, const XParams C, const __half* __restrict__ xt,
-                                                           const float* __restrict__ invp, const float* __restrict__ gin,
-                                                           const float* __restrict__ dloss, __half* __restrict__ dx) {
+// PF: the projection first (pea_xdma_pf.h): `affs` = the raw cosine map of the forward; a chunk then finishes its two channels
+// (stored at once, in f16), there is no G array and no second read of the own pixel; WPE = 6 with the small planes.
+template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, bool PF = false, int WPE = 4>
+__global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, const XParams C, const __half* __restrict__ xt,
+                                                             const float* __restrict__ invp, const float* __restrict__ gin,
+                                                             const float* __restrict__ affs, const float* __restrict__ dloss,
+                                                             __half* __restrict__ dx) {
   constexpr int NT = TH * TW, PS = PSU * 256, PH = PS / 2, NP = D_T / 2;
   static_assert(TW == 32 && D_T % 2 == 0 && PS % 512 == 0, "lane mapping / channel pairs / half planes in whole 256-byte units");
   extern __shared__ f4 lds4[];
@@ -137,10 +158,13 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma_h(const KParams P, const
   PEA_HDMA16(0, 0)
 
   // ---- g of every pair (role A at p, role B at p - o) and the LDS slot of every neighbour (pea_xdma.h k_bwd_xdma)
+  const rsrc_t aB = mkbuf(PF ? affs + (size_t)b * P.K * S : nullptr);
+  float proj = 0.f;
   const unsigned pg = live ? po * 4u : 0xC0000000u;
-  float cx[XP], cy[XP];
+  static_assert(XP % 2 == 0, "coefficients are kept two to a register pair");
+  f2 cx2[XP / 2], cy2[XP / 2];  // pair k in half (k & 1) of element k / 2
   int ax[XP], ay[XP];
-  const int vown = ((C.hy0 + ly) * TW + lx) * 4;
+  const int vown = ((C.hy0 + ly) * TW + lx) * 4;   // byte offset of the own pixel in a PLANE (the 1 / norm plane); x 2 in W
   const int hrow = (C.QV * 4 + ly * C.SW) * 4;
 #pragma unroll
   for (int k = 0; k < XP; ++k) {
@@ -149,7 +173,9 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma_h(const KParams P, const
     const bool out = (unsigned)t >= (unsigned)P.X;
     const int fix = go > 0 ? -P.X : P.X;
     const unsigned o = CROP ? (out ? kOOB : pg + (unsigned)(go * 4)) : pg + (unsigned)((out ? go + fix : go) * 4);
-    cx[k] = bl32(gB, k < C.npx ? o : kOOB, fzo + (unsigned)C.xgi[k] * fcs);
+    const float gk = bl32(gB, k < C.npx ? o : kOOB, fzo + (unsigned)C.xgi[k] * fcs);
+    cx2[k / 2][k & 1] = gk;
+    if (PF) proj = fmaf(gk, bl32(aB, k < C.npx ? o : kOOB, fzo + (unsigned)C.xgi[k] * fcs), proj);
     const int d = C.xd[k], c = lx + d;
     ax[k] = (unsigned)c < (unsigned)TW ? vown + d * 4 : hrow + (c & C.xm[k]) * 4;
   }
@@ -160,7 +186,9 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma_h(const KParams P, const
     const bool out = (unsigned)t >= (unsigned)P.Y;
     const int fix = go > 0 ? -P.Y : P.Y;
     const unsigned o = CROP ? (out ? kOOB : pg + (unsigned)(go * P.X * 4)) : pg + (unsigned)((out ? go + fix : go) * P.X * 4);
-    cy[k] = bl32(gB, k < C.npy ? o : kOOB, fzo + (unsigned)C.ygi[k] * fcs);
+    const float gk = bl32(gB, k < C.npy ? o : kOOB, fzo + (unsigned)C.ygi[k] * fcs);
+    cy2[k / 2][k & 1] = gk;
+    if (PF) proj = fmaf(gk, bl32(aB, k < C.npy ? o : kOOB, fzo + (unsigned)C.ygi[k] * fcs), proj);
     ay[k] = vown + C.yd[k] * TW * 4;
   }
   if (NP > 1) PEA_HDMA16(1, 2)
@@ -171,23 +199,24 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma_h(const KParams P, const
   const float inv_own = fabsf(invo);
 #pragma unroll
   for (int k = 0; k < XP; ++k) {
-    cx[k] *= fabsf(*(const float*)(W + PS + ax[k]));
-    cy[k] *= fabsf(*(const float*)(W + PS + ay[k]));
-    asm volatile("" : "+v"(cx[k]), "+v"(cy[k]));
+    cx2[k / 2][k & 1] *= fabsf(*(const float*)(W + PS + ax[k]));
+    cy2[k / 2][k & 1] *= fabsf(*(const float*)(W + PS + ay[k]));
+    if (k & 1) asm volatile("" : "+v"(cx2[k / 2]), "+v"(cy2[k / 2]));
   }
   lds_barrier();  // the 1 / norm plane is dead: the working planes may be written
   if (NP > 2) PEA_HDMA16(2, 4)
 
-  constexpr bool KEEP = D_T <= 16;
-  f2 G[NP], eh[KEEP ? NP : 1];
-  float proj = 0.f;
+  constexpr bool KEEP = D_T <= 16 && !PF;
+  f2 G[PF ? 1 : NP], eh[KEEP ? NP : 1];
+  if (PF) {
+    if (invo < 0.f) proj = 0.f;  // clamp branch of F.normalize
+    asm volatile("" : "+v"(proj));
+  }
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
-    convert_chunk<PS>(W, R, ps % 3, qq, act);
-    lds_barrier();  // the working planes hold chunk ps
-    f2 o;
-    o.x = *(const float*)(W + vown);
-    o.y = *(const float*)(W + PS + vown);
+    convert_chunk<PS, NT>(W, R, ps % 3, C.QA);
+    lds_barrier();  // the working buffer holds chunk ps
+    f2 o = *(const f2*)(W + 2 * vown);
     o = o * inv_own;
     if (KEEP) {
       eh[ps] = o;
@@ -196,52 +225,55 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma_h(const KParams P, const
     f2 acc = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < XP; ++k) {
-      f2 v;
-      v.x = *(const float*)(W + ax[k]);
-      v.y = *(const float*)(W + PS + ax[k]);
-      acc = __builtin_elementwise_fma((f2){cx[k], cx[k]}, v, acc);
+      const f2 v = *(const f2*)(W + 2 * ax[k]);
+      acc = (k & 1) ? pk_fma_c<true>(cx2[k / 2], v, acc) : pk_fma_c<false>(cx2[k / 2], v, acc);
       if (k % 5 == 4) asm volatile("" ::: "memory");
     }
 #pragma unroll
     for (int k = 0; k < XP; ++k) {
-      f2 v;
-      v.x = *(const float*)(W + ay[k]);
-      v.y = *(const float*)(W + PS + ay[k]);
-      acc = __builtin_elementwise_fma((f2){cy[k], cy[k]}, v, acc);
+      const f2 v = *(const f2*)(W + 2 * ay[k]);
+      acc = (k & 1) ? pk_fma_c<true>(cy2[k / 2], v, acc) : pk_fma_c<false>(cy2[k / 2], v, acc);
       if (k % 5 == 4) asm volatile("" ::: "memory");
     }
-    if (!KEEP) {
-      proj = fmaf(o.x, acc.x, fmaf(o.y, acc.y, proj));
-      asm volatile("" : "+v"(proj));
+    if (PF) {  // this chunk's two channels are final
+      bs_emb<__half, true>(dB, (acc.x - o.x * proj) * inv_own * dl, ph, hzo + (unsigned)(2 * ps) * hcs);
+      bs_emb<__half, true>(dB, (acc.y - o.y * proj) * inv_own * dl, ph, hzo + (unsigned)(2 * ps + 1) * hcs);
+    } else {
+      if (!KEEP) {
+        proj = fmaf(o.x, acc.x, fmaf(o.y, acc.y, proj));
+        asm volatile("" : "+v"(proj));
+      }
+      asm volatile("" : "+v"(acc));
+      G[ps] = acc;
     }
-    asm volatile("" : "+v"(acc));
-    G[ps] = acc;
     if (ps + 1 < NP) {
-      // everyone is done with the working planes and with ring buffer ps % 3; chunk ps + 1 has landed (ps + 2 may still fly)
-      if (ps + 2 < NP) PEA_HWAIT1(npc)
-      else PEA_HWAIT0()
+      // everyone is done with the working buffer and with ring buffer ps % 3; chunk ps + 1 has landed (chunk ps + 2 and, PF, the
+      // stores of the last two chunks may still fly: vmcnt retires in order, pea_xdma_pf.h)
+      const int nd = ps + 2 < NP ? 1 : 0, ns = PF ? 2 * (ps + 1 < 2 ? ps + 1 : 2) : 0;
+      pf_wait(nd * npc + ns);
       if (ps + 3 < NP) PEA_HDMA16(ps % 3, 2 * ps + 6)
     }
   }
 #undef PEA_HDMA16
 
-  if (KEEP) {
+  if constexpr (!PF) {
+    if (KEEP) {
 #pragma unroll
-    for (int ps = 0; ps < NP; ++ps) proj = fmaf(eh[ps].x, G[ps].x, fmaf(eh[ps].y, G[ps].y, proj));
-  }
-  if (invo < 0.f) proj = 0.f;  // clamp branch of F.normalize
-  const float sc = dl * inv_own;
-  const float pn = proj * inv_own;
-#pragma unroll
-  for (int ps = 0; ps < NP; ++ps) {
-    float ex, ey;
-    if (KEEP) { ex = eh[ps].x * proj; ey = eh[ps].y * proj; }
-    else {
-      ex = bl_emb<__half>(xB, ph, hzo + (unsigned)(2 * ps) * hcs) * pn;
-      ey = bl_emb<__half>(xB, ph, hzo + (unsigned)(2 * ps + 1) * hcs) * pn;
+      for (int ps = 0; ps < NP; ++ps) proj = fmaf(eh[ps].x, G[ps].x, fmaf(eh[ps].y, G[ps].y, proj));
     }
-    bs_emb<__half, true>(dB, (G[ps].x - ex) * sc, ph, hzo + (unsigned)(2 * ps) * hcs);
-    bs_emb<__half, true>(dB, (G[ps].y - ey) * sc, ph, hzo + (unsigned)(2 * ps + 1) * hcs);
+    if (invo < 0.f) proj = 0.f;  // clamp branch of F.normalize
+    const float pn = proj * inv_own, sc = dl * inv_own;
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      float ex, ey;
+      if (KEEP) { ex = eh[ps].x * proj; ey = eh[ps].y * proj; }
+      else {
+        ex = bl_emb<__half>(xB, ph, hzo + (unsigned)(2 * ps) * hcs) * pn;
+        ey = bl_emb<__half>(xB, ph, hzo + (unsigned)(2 * ps + 1) * hcs) * pn;
+      }
+      bs_emb<__half, true>(dB, (G[ps].x - ex) * sc, ph, hzo + (unsigned)(2 * ps) * hcs);
+      bs_emb<__half, true>(dB, (G[ps].y - ey) * sc, ph, hzo + (unsigned)(2 * ps + 1) * hcs);
+    }
   }
 }
 
@@ -313,17 +345,13 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
   for (int k = 0; k < kXP; ++k) { dot[k] = (f2){0.f, 0.f}; ssq[k] = (f2){0.f, 0.f}; }
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
-    convert_chunk<PS>(W, R, ps % 3, qq, act);
+    convert_chunk<PS, NT>(W, R, ps % 3, C.QA);
     lds_barrier();
-    f2 o;
-    o.x = *(const float*)(W + vown);
-    o.y = *(const float*)(W + PS + vown);
+    const f2 o = *(const f2*)(W + 2 * vown);
     oss = __builtin_elementwise_fma(o, o, oss);
 #pragma unroll
     for (int k = 0; k < kXP; ++k) {
-      f2 v;
-      v.x = *(const float*)(W + an[k]);
-      v.y = *(const float*)(W + PS + an[k]);
+      const f2 v = *(const f2*)(W + 2 * an[k]);
       dot[k] = __builtin_elementwise_fma(o, v, dot[k]);
       ssq[k] = __builtin_elementwise_fma(v, v, ssq[k]);
       if (k % 5 == 4) asm volatile("" ::: "memory");
