@@ -182,9 +182,11 @@ int pea_affinity_bwd_ex(const PeaDesc *desc, const void *e, const void *e_other,
 int pea_affinity_bwd_ex2(const PeaDesc *desc, const void *e, const void *e_other, const float *g, const float *inv_norm,
                          const float *affs, const float *dloss, void *de, void *de_other, void *stream);
 int pea_inv_norm(const PeaDesc *desc, const void *e, float *inv_norm_out, void *stream);
-/* Host-only: 1 when the LDS-DMA cross kernels cover the descriptor (self loss, 16-byte aligned tensors assumed) for the
- * forward (backward == 0) or the backward (backward == 1, given the 1 / norm plane); backward == 2: the cross loss with a detached
- * second operand (forward and role-A backward, given the two planes); else 0 (the tiled / direct kernels run). */
+/* Host-only: 1 when the LDS-DMA kernels cover the descriptor (self loss, 16-byte aligned tensors assumed) for the forward
+ * (backward == 0) or the backward (backward == 1, given the 1 / norm plane): the cross kernels for axis-aligned stencils, the
+ * unit-box kernels (csrc/pea_box.h) for stencils with |dz|, |dy|, |dx| <= 1 such as the 26-neighbourhood; backward == 2: the cross
+ * loss with a detached second operand (forward and role-A backward, given the two planes); else 0 (the tiled / direct kernels
+ * run).  A caller uses it to decide whether to allocate the 1 / norm plane. */
 int pea_cross_supported(const PeaDesc *desc, int backward);
 
 /* The backward of the full-resolution pair of the training loop in one launch: g is what pea_affinity_fwd wrote for the self

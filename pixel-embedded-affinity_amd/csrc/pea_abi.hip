@@ -87,6 +87,7 @@ int run_fwd(const KParams& P, FwdArgs A, hipStream_t s) {
   bool launched = false;
   if (A.train) launched = self ? xdma_fwd_self(P, A, s) : xdma_fwd_other(P, A, s);
   else if (self) launched = xdma_fwd_self(P, A, s);
+  if (!launched && self) launched = box_fwd(P, A, s);
   if (!launched) {
     // 1 / norm planes: the tiled D = 16 self forward writes its plane while it stages; everything else gets k_inv_norm
     float* inv = A.inv_out;
@@ -199,7 +200,8 @@ int pea_affinity_fwd(const PeaDesc* desc, const void* e, const void* e_other, co
 int pea_cross_supported(const PeaDesc* desc, int backward) {
   if (validate(desc)) return 0;
   const KParams P = make_params(desc);
-  return xdma_cross_supported(P, desc->dtype, backward);
+  if (xdma_cross_supported(P, desc->dtype, backward)) return 1;
+  return (backward == 0 || backward == 1) && box_supported(P, desc->dtype) ? 1 : 0;
 }
 
 int pea_inv_norm(const PeaDesc* desc, const void* e, float* inv_norm_out, void* stream) {
@@ -236,6 +238,7 @@ int pea_affinity_bwd_ex2(const PeaDesc* desc, const void* e, const void* e_other
     // self loss: the LDS-DMA cross kernel when the 1 / norm plane came along and the stencil is axis-aligned
     if (dt == PEA_F32 && xdma_bwd_self(P, (const float*)e, inv_norm, g, affs, dloss, (float*)de, s)) return hip_rc();
     if (dt == PEA_F16 && xdma_bwd_self_h(P, e, inv_norm, g, affs, dloss, de, s)) return hip_rc();
+    if (dt == PEA_F32 && box_bwd(P, (const float*)e, inv_norm, g, dloss, (float*)de, s)) return hip_rc();
     return run_bwd(P, dt, 3, e, e, e, g, dloss, de, s);
   }
   // (a second operand that aliases the first is still a second operand: its roles are separate)

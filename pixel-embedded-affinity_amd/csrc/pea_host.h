@@ -3,6 +3,7 @@
 // The library is built from several .hip files compiled in parallel (one per kernel family; a single file took 1 m 47 s):
 //   pea_abi.hip        the extern "C" entry points of include/pea.h: validation, descriptor -> KParams, dispatch
 //   pea_k_xdma.hip     LDS-DMA cross kernels (pea_xdma.h): the training forward / backward of axis-aligned stencils
+//   pea_k_box.hip      unit-box stencils (pea_box.h): the 26-neighbourhood of a 3D volume through an LDS-DMA ring of 3-plane boxes
 //   pea_k_tiled.hip    LDS-tiled box kernels (pea_tiled.h, pea_chunked.h): diagonal stencils, f16 storage, inference
 //   pea_k_labels.hip   the labels-in training step (pea_fused_labels.h) and the label-weight tables
 //   pea_k_direct.hip   global-memory kernels (pea_direct.h): the general fallback; loss finish; caller epilogues, stitcher
@@ -26,6 +27,8 @@ struct Env {
   int infer_xdma;     // PEA_INFER_XDMA=0: inference (affs only) on k_fwd_tiled / the chunked kernels instead of the LDS-DMA forward
   int bwd_pf;         // PEA_BWD_PF=0: never the projection-first backward (pea_xdma_pf.h); 2: also at D = 16 (where it loses)
   int fwd_wg3;        // PEA_FWD_WG3=0: the 2-workgroups-per-CU forward
+  int box;            // PEA_BOX=0: unit-box stencils (the 26-neighbourhood) on the tiled kernels instead of pea_box.h
+  int zblk_y, zblk_x; // PEA_ZBLK_Y / PEA_ZBLK_X: tiles per block of the z-fastest walk of 3D volumes (0: the default 4 x 2; Y < 0: plane-major)
 };
 const Env& env();
 void env_reload();  // pea_reload_env(): tests that change a switch call it
@@ -106,6 +109,10 @@ bool tiled_fwd(const KParams& P, const FwdArgs& A, hipStream_t s, bool* wrote_in
 void direct_fwd(const KParams& P, const FwdArgs& A, hipStream_t s);
 void launch_inv_norm(const KParams& P, int dtype, const void* e, float* inv, hipStream_t s);
 int xdma_cross_supported(const KParams& P, int dtype, int mode);
+// unit-box stencils (pea_k_box.hip): f32, D = 16, self loss; the backward needs the forward's 1 / norm plane
+bool box_supported(const KParams& P, int dtype);
+bool box_fwd(const KParams& P, const FwdArgs& A, hipStream_t s);
+bool box_bwd(const KParams& P, const float* x, const float* inv, const float* g, const float* dl, float* dx, hipStream_t s);
 
 // backward: roles bit 0 = A (x is the first operand, neighbours nbA), bit 1 = B (x is the second operand, neighbours nbB)
 bool xdma_bwd_self(const KParams& P, const float* x, const float* inv, const float* g, const float* affs, const float* dl, float* dx,

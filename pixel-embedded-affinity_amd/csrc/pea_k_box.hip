@@ -1,0 +1,79 @@
+// pea_k_box.hip -- launchers of the unit-box kernels (pea_box.h): the 26-neighbourhood of BASELINE.json configs[3] and its subsets.
+// One translation unit of libpea_hip.so (pea_host.h).
+#include "pea_host.h"
+#include "pea_box.h"
+
+namespace pea {
+
+namespace {
+
+struct BPlan { BParams C; };
+
+bool plan(const KParams& P, BParams* out) {
+  static thread_local PlanCache<BPlan, 8> cache;
+  BPlan t;
+  if (!cache.get(P, 0, &t, [&](BPlan* p) {
+        if (!plan_box(P, &p->C)) return false;
+        if (env().zblk_y > 0) p->C.zgy = env().zblk_y;
+        if (env().zblk_x > 0) p->C.zgx = env().zblk_x;
+        if (env().zblk_y < 0) p->C.zrun = 0;
+        return true;
+      }))
+    return false;
+  *out = t.C;
+  return true;
+}
+
+}  // namespace
+
+// axis-aligned in-plane stencils belong to the cross kernels (their caller asks them first); everything else inside the unit box
+bool box_supported(const KParams& P, int dtype) {
+  BParams C;
+  return dtype == PEA_F32 && P.D == 16 && env().box && !env().force_direct && plan(P, &C);
+}
+
+bool box_fwd(const KParams& P, const FwdArgs& A, hipStream_t s) {
+  if (A.dtype != PEA_F32 || P.D != 16 || A.eo != A.e || !env().box || env().force_direct) return false;
+  if (misaligned(A.e, 16) || misaligned(A.t, 16) || misaligned(A.w, 16) || misaligned(A.affs, 16) || misaligned(A.gout, 16) ||
+      misaligned(A.m, 4) || misaligned(A.inv_out, 4))
+    return false;
+  if (A.train && ((P.tbs | P.wbs | P.mbs) & 3)) return false;
+  BParams C;
+  if (!plan(P, &C)) return false;
+  const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kBoxTH * kBoxTW);
+  const float* e = (const float*)A.e;
+#define PEA_BF(CROP_, TRAIN_)                                                                                   \
+  {                                                                                                             \
+    constexpr auto kern = k_fwd_box<16, CROP_, TRAIN_>;                                                         \
+    if (allow_lds<kern>(kBoxLds)) return false;                                                                 \
+    hipLaunchKernelGGL(kern, grid, blk, kBoxLds, s, P, C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out);   \
+  }
+  const bool crop = P.border != PEA_BORDER_CIRCULAR;
+  if (A.train) {
+    if (crop) PEA_BF(true, true) else PEA_BF(false, true)
+  } else {
+    if (crop) PEA_BF(true, false) else PEA_BF(false, false)
+  }
+#undef PEA_BF
+  return true;
+}
+
+bool box_bwd(const KParams& P, const float* x, const float* inv, const float* g, const float* dl, float* dx, hipStream_t s) {
+  if (P.D != 16 || !inv || !env().box || env().force_direct) return false;
+  if (misaligned(x, 16) || misaligned(inv, 16) || misaligned(g, 4) || misaligned(dx, 4)) return false;
+  BParams C;
+  if (!plan(P, &C)) return false;
+  const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kBoxTH * kBoxTW);
+  if (P.border != PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_bwd_box<16, true>;
+    if (allow_lds<kern>(kBoxLds)) return false;
+    hipLaunchKernelGGL(kern, grid, blk, kBoxLds, s, P, C, x, inv, g, dl, dx);
+  } else {
+    constexpr auto kern = k_bwd_box<16, false>;
+    if (allow_lds<kern>(kBoxLds)) return false;
+    hipLaunchKernelGGL(kern, grid, blk, kBoxLds, s, P, C, x, inv, g, dl, dx);
+  }
+  return true;
+}
+
+}  // namespace pea

@@ -32,6 +32,9 @@ void env_load() {
   g_env.fwd_wg3 = env_int("PEA_FWD_WG3", 1);
   g_env.infer_xdma = env_int("PEA_INFER_XDMA", 1);
   g_env.bwd_pf = env_int("PEA_BWD_PF", 1);
+  g_env.box = env_int("PEA_BOX", 1);
+  g_env.zblk_y = env_int("PEA_ZBLK_Y", 0);
+  g_env.zblk_x = env_int("PEA_ZBLK_X", 0);
 }
 }  // namespace
 const Env& env() {

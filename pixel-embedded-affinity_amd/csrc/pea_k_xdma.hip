@@ -10,7 +10,10 @@ namespace {
 
 constexpr int kXdmaTH = 16, kXdmaTW = 32;
 constexpr int kXdmaPSU = 51;   // 13 KB planes: the backward's two-sided +-27 cross; 6 planes = 78 KB, two workgroups per CU
-constexpr int kXdmaPSU3 = 52;  // 3D instantiations: whole 64-quad blocks
+constexpr int kXdmaPSU3 = 52;  // 3D backward: whole 64-quad blocks
+constexpr int kXdmaPSU3F = 32; // 3D forward: the one-sided cross in 8 KB planes (and every ds_read offset of the ring below 2^16: with
+                               // 13 KB planes the sixth plane's reads needed computed addresses, which the inference instantiation
+                               // spilled -- profiles/kernel_resources.py)
 constexpr int kXdmaPSUF = 30;  // the forward's one-sided cross (27 rows up, one strip): 7.5 KB planes, 45 KB, THREE workgroups per CU
 
 struct XPlan { XParams C; size_t lds; };
@@ -18,7 +21,13 @@ struct XPlan { XParams C; size_t lds; };
 // memoised plan_xdma (per thread; keyed by KParams, the plane size and the mode)
 bool plan(const KParams& P, int psu, int mode, XPlan* out) {
   static thread_local PlanCache<XPlan, 12> cache;
-  return cache.get(P, psu * 4 + mode, out, [&](XPlan* p) { return plan_xdma(P, kXdmaTH, kXdmaTW, psu, &p->C, &p->lds, mode); });
+  return cache.get(P, psu * 4 + mode, out, [&](XPlan* p) {
+    if (!plan_xdma(P, kXdmaTH, kXdmaTW, psu, &p->C, &p->lds, mode)) return false;
+    if (env().zblk_y > 0) p->C.zgy = env().zblk_y;
+    if (env().zblk_x > 0) p->C.zgx = env().zblk_x;
+    if (env().zblk_y < 0) p->C.zrun = 0;  // plane-major walk
+    return true;
+  });
 }
 
 #define PEA_LAUNCH(kern, grid, blk, lds, s, ...)              \
@@ -39,7 +48,7 @@ bool fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s) {
   if (env().fwd_wg3 && plan(P, kXdmaPSUF, 1, &X) && X.C.nfz == 0) {
     wg3 = true;
   } else if (!plan(P, kXdmaPSU, 1, &X) || X.C.nfz > 0) {
-    if (D_T != 16 || !plan(P, kXdmaPSU3, 1, &X) || X.C.nfz == 0) return false;
+    if (D_T != 16 || !plan(P, kXdmaPSU3F, 1, &X) || X.C.nfz == 0) return false;
     z3 = true;
   }
   if (!z3 && P.K > kXP) return false;
@@ -55,7 +64,7 @@ bool fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s) {
   const bool crop = P.border != PEA_BORDER_CIRCULAR;
   if constexpr (D_T == 16) {
     if (z3) {
-      if (crop) PEA_XF(true, kXdmaPSU3, kXZ / 2, 4) else PEA_XF(false, kXdmaPSU3, kXZ / 2, 4)
+      if (crop) PEA_XF(true, kXdmaPSU3F, kXZ / 2, 4) else PEA_XF(false, kXdmaPSU3F, kXZ / 2, 4)
       return true;
     }
   }
@@ -362,7 +371,7 @@ int xdma_cross_supported(const KParams& P, int dtype, int mode) {
   const int pm = mode == 0 ? 1 : 0;
   if (!plan(P, kXdmaPSU3, pm, &X)) return 0;
   const bool z3 = X.C.npz > 0 || X.C.nfz > 0;
-  if (z3) return (P.D == 16 && X.C.npx <= 8 && X.C.npy <= 8 && P.K <= kXP + 2) ? 1 : 0;
+  if (z3) return (P.D == 16 && X.C.npx <= 8 && X.C.npy <= 8 && P.K <= kXP + 2 && (mode || plan(P, kXdmaPSU3F, 1, &X))) ? 1 : 0;
   if (!plan(P, kXdmaPSU, pm, &X)) return 0;
   if (!mode && P.K > kXP) return 0;
   return (mode && P.D > 32 && (X.C.npx > 8 || X.C.npy > 8)) ? 0 : 1;

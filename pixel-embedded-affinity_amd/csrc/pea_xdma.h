@@ -53,6 +53,17 @@ constexpr int kXK = 16;  // channels (offsets) the forward's epilogue handles
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// acc += c * v for both channels of a pair, the coefficient c taken from the LOW (HI = false) or HIGH half of a register pair
+// that holds TWO pairs' coefficients.  hipcc materialises (f2){c, c} in two registers per coefficient (20 pairs: 40 VGPRs of
+// coefficients); v_pk_fma_f32's op_sel / op_sel_hi select the half per lane of the packed operation, so one register pair
+// serves two pairs: half the coefficient registers in the gather loops (the f16 kernels and the box kernels need that).
+template <bool HI>
+__device__ __forceinline__ f2 pk_fma_c(f2 cpair, f2 v, f2 acc) {
+  if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(cpair), "v"(v));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(cpair), "v"(v));
+  return acc;
+}
+
 struct XParams {
   int hy0, hy1;   // halo rows above / below the tile in VF
   int SW;         // strip row length in LDS: 32 or 64 pixels
@@ -71,6 +82,7 @@ struct XParams {
   int zd[kXZ];             // plane displacement of the neighbour
   int zgi[kXZ], zgo[kXZ];  // g channel; plane displacement of the g sample (role A: 0, role B: -oz)
   int zrun;                // > 1: tiles walk z fastest (= Z), so the planes a z offset reaches were staged just before
+  int zgy, zgx;            // ... inside blocks of zgy x zgx tiles
   // forward (role A only): in-plane offsets in their own order (nf <= kXP), z offsets (nfz <= kXZ / 2)
   int nf, nfz;
   int fd[kXP];             // displacement along the offset's axis
@@ -104,8 +116,8 @@ __global__ __launch_bounds__(256) void k_inv_norm(const KParams P, const T* __re
 // tile id -> (plane = b * Z + z, y0, x0).  XCD g walks tiles [g * tpx, (g+1) * tpx); volumes with z offsets walk z FASTEST
 // (zrun = Z): the tiles running together on an XCD are a few (y, x) columns over all z, so the planes a z offset reaches
 // are in that XCD's L2.  The returned tile id stays plane-major (the loss-partial slot of a tile does not depend on the walk).
-template <int TH, int TW>
-__device__ __forceinline__ bool xdma_tile(const XParams& C, const KParams& P, int& tile, int& b, int& z, int& y0, int& x0) {
+template <int TH, int TW, typename CP = XParams>
+__device__ __forceinline__ bool xdma_tile(const CP& C, const KParams& P, int& tile, int& b, int& z, int& y0, int& x0) {
   const int bid = blockIdx.x;
   const int lin = (bid % kXcd) * C.tiles_per_xcd + bid / kXcd;
   if (lin >= C.ntiles) return false;
@@ -113,7 +125,7 @@ __device__ __forceinline__ bool xdma_tile(const XParams& C, const KParams& P, in
   if (C.zrun > 1) {
     // walk: blocks of kGY x kGX tiles; inside a block z, then y, then x fastest -- the tiles in flight on an XCD (64) are a few
     // planes of one block: the z neighbours were staged 1-4 planes ago, the in-plane halos are shared inside the block
-    constexpr int kGY = 4, kGX = 2;
+    const int kGY = C.zgy, kGX = C.zgx;
     const int per_b = C.tiles_per_plane * C.zrun;
     b = lin / per_b;
     int r = lin - b * per_b;
@@ -610,6 +622,9 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
   constexpr int KMAX = ZF > 0 ? kXP + 2 : kXP;      // channels the epilogue handles (norm5: 8 in-plane + 4 z offsets)
   constexpr int ITEMS = (KMAX * QP + NT - 1) / NT;
   constexpr bool SDMA = ZF > 0, LATE = ZF > 0 || OTHER || WPE > 4;  // OTHER: the own pixel's registers instead of the early t / w / m
+  // the epilogue's item geometry after the channel loop: the 80-VGPR instantiations, and the 3D inference one (which spilled 13
+  // registers with the items alive across the loop -- profiles/kernel_resources.py)
+  constexpr bool ILATE = WPE > 4 || (ZF > 0 && !TRAIN);
   static_assert(TW == 32 && D_T % 2 == 0 && QP % 64 == 0, "lane mapping / channel pairs");
   constexpr int NW = NT / 64;
   static_assert(KMAX * TP * 4 + KMAX * NSL * 4 <= 6 * PS && KMAX <= kXK, "the parked dot products fit the ring");
@@ -641,8 +656,10 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
   unsigned m4[ITEMS];
   // (the 80-VGPR instantiations evaluate this after the channel loop: three registers less across it)
 #define PEA_XITEMS()                                                                                                      \
+  int tid_i = (int)threadIdx.x;                                                                                           \
+  if (ILATE) asm volatile("" : "+v"(tid_i)); /* opaque: not hoisted back over the channel loop */                        \
   _Pragma("unroll") for (int it = 0; it < ITEMS; ++it) {                                                                  \
-    const int tt = it * NT + (int)threadIdx.x;                                                                            \
+    const int tt = it * NT + tid_i;                                                                                       \
     const int sl = __builtin_amdgcn_readfirstlane(tt / QP);                                                               \
     ion[it] = sl < P.K;                                                                                                   \
     isl[it] = min(sl, P.K - 1);                                                                                           \
@@ -654,7 +671,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
     const bool lv = ion[it] && igy[it] < P.Y && igx[it] < P.X; /* X % 4 == 0: a quad is inside or outside as a whole */   \
     ivo[it] = lv ? (unsigned)(igy[it] * P.X + igx[it]) * 4u : kOOB;                                                       \
   }
-  if (WPE <= 4) PEA_XITEMS()
+  if (!ILATE) { PEA_XITEMS() }
 #define PEA_XLOAD_TWM()                                                                                                   \
   if (TRAIN) {                                                                                                            \
     _Pragma("unroll") for (int it = 0; it < ITEMS; ++it) {                                                                \
@@ -800,7 +817,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
       v.y = *(const float*)(lds + bo + PS + an[k]);
       dot[k] = __builtin_elementwise_fma(o, v, dot[k]);
       ssq[k] = __builtin_elementwise_fma(v, v, ssq[k]);
-      if (k % 5 == 4) asm volatile("" ::: "memory");
+      if (k % (ZF > 0 && !TRAIN ? 2 : 5) == (ZF > 0 && !TRAIN ? 1 : 4)) asm volatile("" ::: "memory");
     }
 #pragma unroll
     for (int k = 0; k < ZF; ++k) {
@@ -829,7 +846,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
 #undef PEA_XWAIT1
 #undef PEA_XWAITZ
 #undef PEA_XZLOAD
-  if (LATE && WPE <= 4 && !LAB) PEA_XLOAD_TWM()
+  if (LATE && !ILATE && !LAB) PEA_XLOAD_TWM()
 
   // ---- normalise; the lane's own 1 / norm for the backward
   const float osum = oss.x + oss.y;
@@ -896,11 +913,11 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
       sA[C.fzi[k] * TP + (int)threadIdx.x] = a;
     }
   }
-  if (WPE > 4 && !LAB) PEA_XITEMS()
-  if (LATE && WPE > 4 && !LAB) PEA_XLOAD_TWM()  // 80-VGPR budget: only now are the 40 accumulator registers free
+  if (ILATE && !LAB) { PEA_XITEMS() }
+  if (LATE && ILATE && !LAB) PEA_XLOAD_TWM()  // 80-VGPR budget: only now are the 40 accumulator registers free
 #undef PEA_XLOAD_TWM
   lds_barrier();
-  if (WPE > 4 && LAB) PEA_XITEMS()
+  if (ILATE && LAB) { PEA_XITEMS() }
 #undef PEA_XITEMS
 
   // ---- epilogue: 4 x-adjacent pixels of one offset per lane, dwordx4 everywhere
@@ -1009,6 +1026,7 @@ inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, s
   }
   const bool has_z = C.npz > 0 || C.nfz > 0;
   if (has_z && P.Z > 1) C.zrun = P.Z;
+  C.zgy = 4; C.zgx = 2;
   if (fwd || role_a) { hx = left > right ? left : right; C.hy0 = up; C.hy1 = down; }
   else { C.hy0 = C.hy1 = hy; left = right = hx; }
   if (hx > TW) return false;  // a neighbour column is inside the tile or in the strip next to it

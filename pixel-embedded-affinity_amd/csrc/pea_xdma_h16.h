@@ -20,17 +20,6 @@ namespace pea {
 
 typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 
-// acc += c * v for both channels of a pair, the coefficient c taken from the LOW (HI = false) or HIGH half of a register pair
-// that holds TWO pairs' coefficients.  hipcc materialises (f2){c, c} in two registers per coefficient (20 pairs: 40 VGPRs of
-// coefficients); v_pk_fma_f32's op_sel / op_sel_hi select the half per lane of the packed operation, so one register pair
-// serves two pairs: 20 VGPRs less in the gather loops, which is what lets the f16 kernels keep to their register budgets.
-template <bool HI>
-__device__ __forceinline__ f2 pk_fma_c(f2 cpair, f2 v, f2 acc) {
-  if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(cpair), "v"(v));
-  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(cpair), "v"(v));
-  return acc;
-}
-
 // geometry of this lane's DMA items: up to two QUADS (4 pixels: the f32 1 / norm plane, and the conversion) and one OCT
 // (8 pixels: the f16 channel planes).  Same region order as pea_xdma.h (VF rows of TW pixels, then strip rows of SW pixels).
 // (Plain locals, not a struct: with the operands of the LDS-DMA builtin taken from members of a local struct, ROCm 7.2's host pass

@@ -282,6 +282,61 @@ def test_3d_26_neighbourhood_vs_oracle(pkg, dev, orc, synth):
     assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL
 
 
+@pytest.mark.parametrize("case", ["n26_crop", "n26_circular", "subset_3d", "diag_2d_mask", "z1_volume"])
+def test_unit_box_stencils_vs_oracle(pkg, dev, orc, synth, monkeypatch, case):
+    """stencils inside the unit box on the LDS-DMA box kernels (csrc/pea_box.h: X % 4 == 0, D = 16): the 26-neighbourhood with both
+    borders, subsets with one sign only, a 2D diagonal stencil with a mask, partial tiles in y and x; against the C oracle, against
+    the tiled kernels (PEA_BOX=0) and the inference entry point"""
+    op, lib = pkg.affinity_op, pkg._lib.lib()
+    n26 = [[dz, dy, dx] for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dz, dy, dx) != (0, 0, 0)]
+    if case == "n26_crop":
+        ndim, B, dims, offs, border, norm = 3, 2, [5, 37, 72], n26, pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED
+    elif case == "n26_circular":
+        ndim, B, dims, offs, border, norm = 3, 1, [4, 33, 68], n26, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_FULL
+    elif case == "subset_3d":
+        ndim, B, dims, offs = 3, 2, [3, 20, 40], [[-1, 0, 0], [0, -1, 1], [1, 1, -1], [0, 0, -1], [-1, -1, -1], [1, 0, 1], [0, 1, 0]]
+        border, norm = pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED
+    elif case == "diag_2d_mask":
+        ndim, B, dims, offs = 2, 3, [1, 50, 100], [[0, -1, -1], [0, -1, 1], [0, 1, 1], [0, 0, -1], [0, -1, 0]]
+        border, norm = pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX
+    else:  # a volume of one plane: the z neighbours do not exist
+        ndim, B, dims, offs = 3, 1, [1, 48, 64], [[0, dy, dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dy, dx) != (0, 0)]
+        border, norm = pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED
+    D, K = 16, len(offs)
+    Z, Y, X = dims
+    lam = [1.0 + 0.25 * (i % 3) for i in range(K)]
+    e, t, w = synth.synth_inputs_3d(B, D, Z, Y, X, offs, 31 + K)
+    m = None
+    if case == "diag_2d_mask":
+        m = (synth.hash_uniform(np.arange(B * K * Z * Y * X, dtype=np.uint64), 77) < 0.85).astype(np.uint8).reshape(B, K, Z, Y, X)
+    shp = (lambda a: a) if ndim == 3 else (lambda a: None if a is None else a.reshape(a.shape[0], a.shape[1], Y, X))
+    spec = op.AffinitySpec(ndim, [o[3 - ndim:] for o in offs], lam, border, norm)
+    et = cu(shp(e), dev).requires_grad_(True)
+    d_hip = op.make_desc(spec, et)
+    assert lib.pea_cross_supported(ctypes.byref(d_hip), 0) == 1 and lib.pea_cross_supported(ctypes.byref(d_hip), 1) == 1
+    mt = None if m is None else cu(shp(m), dev)
+    loss, affs, parts = op.FusedAffinityMSE.apply(et, None, cu(shp(t), dev), cu(shp(w), dev), mt, spec)
+    (loss * 0.5).backward()
+    d = orc.make_desc(B, D, dims, offs, lam, border, norm, ndim=ndim)
+    o_affs, o_loss = orc.c_fwd(d, e, None, t, w, m)
+    o_grad, _ = orc.c_bwd(d, e, None, t, w, m, dloss=0.5)
+    assert np.abs(affs.cpu().numpy().reshape(o_affs.shape) - o_affs).max() < AFFS_ATOL
+    np.testing.assert_allclose(parts.cpu().numpy(), o_loss[1:], rtol=LOSS_RTOL)
+    assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+    assert relmax(et.grad.cpu().numpy().reshape(o_grad.shape), o_grad) < GRAD_RTOL
+    inf = op.affinity_infer(et.detach(), None, spec)
+    assert torch.equal(inf, affs)
+    # the tiled kernels on the same inputs: the dispatcher really took a different path above
+    monkeypatch.setenv("PEA_BOX", "0")
+    pkg._lib.reload_env()
+    assert lib.pea_cross_supported(ctypes.byref(d_hip), 1) == 0
+    et2 = cu(shp(e), dev).requires_grad_(True)
+    loss2, affs2, _ = op.FusedAffinityMSE.apply(et2, None, cu(shp(t), dev), cu(shp(w), dev), mt, spec)
+    (loss2 * 0.5).backward()
+    assert np.abs((affs2 - affs).cpu().numpy()).max() < AFFS_ATOL
+    assert relmax(et2.grad.cpu().numpy(), et.grad.cpu().numpy()) < GRAD_RTOL
+
+
 def test_random_shapes_and_stencils_vs_oracle(pkg, dev, orc, synth):
     """seeded sweep over ragged sizes, offset lists (both signs), borders, batch and D"""
     op = pkg.affinity_op
