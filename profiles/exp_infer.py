@@ -13,6 +13,8 @@ B, D, H, W = 8, int(os.environ.get("D", 16)), int(os.environ.get("HW", 544)), in
 offsets = pkg.multi_offset([int(v) for v in os.environ.get("SHIFTS", "1,3,5,9,27").split(",")], 4)[:int(os.environ.get("K", 10))]
 K = len(offsets)
 E = torch.from_numpy(synth.synth_embedding((B, D, H, W), 555)).to(dev)
+if os.environ.get("F16"):   # f16 storage (BASELINE configs[4])
+    E = E.half()
 desc = op.make_desc(op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX), E)
 P = lambda x: ctypes.c_void_p(x.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,321 @@
+// gram_mfma.hip -- the MFMA "Gram" form of the affinity forward that BASELINE.json configs[4] names (D = 64, f16 storage, f32
+// accumulate), as a MEASURED EXPERIMENT against the library's LDS-DMA forward (csrc/pea_xdma_h16.h).  Inference only (raw cosine
+// map out), the CVPPP offsets[:8] = {-1, -3, -5, -9} along y and along x, circular border, B = 8 x 64 x 544 x 544.
+//
+// The K affinities of a pixel are K entries of the Gram matrix of the embedding vectors; v_mfma_f32_16x16x16_f16 computes a
+// 16 x 16 block of it per 16 channels.  Blocks here are 16 consecutive pixels of a row (x offsets) or of a column (y offsets):
+//   per tile row    : I x I, I x P   (P = the 16 pixels left of the tile row I)
+//   per tile column : I x I, I x U   (U = the 16 pixels above the tile column I)
+// and the offset -d is the d-th sub-diagonal of the block (wrapping into the neighbour block).  A block of 16 pixels costs 2 x 256
+// accumulator values per axis -- 64 VGPRs per pixel-lane whatever the tile shape -- so the tile is 16 x 16 with 4 waves (a wave owns
+// four rows and four columns: 16 accumulator blocks, alive over the four chunks of 16 channels) and three workgroups share a CU at
+// 168 VGPRs; 16 x 32 tiles of 8 waves need <= 128 and spilled.
+// Operands: lane (i, g) of an MFMA holds channels 4g .. 4g+3 of pixel i -- the planar [D][Y][X] tensor has them a plane apart, so
+// the region is TRANSPOSED while it is staged: global -> registers (4 channels x 8 pixels per item, buffer_load_dwordx4) ->
+// v_perm -> LDS as [4-channel group][region pixel][4 halves]; an operand is then ONE ds_read_b64 per lane.  The squared norms
+// come from the same operand registers (v_dot2_f32_f16), summed over the four channel groups with ds_add_f32 after the loop.
+//
+// build: hipcc -O3 --offload-arch=gfx950 -o gram_mfma gram_mfma.hip ; run: ./gram_mfma [iters]
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+constexpr int D = 64, TH = 16, TW = 16, NT = TH * TW, K = 8;
+constexpr int RH = 32, RW = 32, PITCH = 34;            // region rows y0-16 .. y0+15, columns x0-16 .. x0+15; row pitch in pixels
+constexpr int PLANE = RH * PITCH * 8 + 128;            // one 4-channel group of the region (8 bytes per pixel), bank-staggered
+constexpr int CH = 16, NCH = D / CH, NG = CH / 4;      // channels per chunk (= one MFMA K step), chunks, groups per chunk
+constexpr int LDS_REGION = NG * PLANE;                 // 35328
+constexpr int LDS_BYTES = 4 * 8 * 16 * 17 * 4 + RH * PITCH * 4 + 4 * NT * 4;  // 43264: the epilogue's layout is the larger one
+static_assert(LDS_BYTES >= LDS_REGION, "LDS");
+constexpr int UNITS = RW / 8;
+constexpr int ITEMS = NG * RH * UNITS;                 // 512 staging items per chunk: (group, row, 8-pixel unit)
+constexpr unsigned kOOB = 0x80000000u;
+__constant__ int c_d[4] = {1, 3, 5, 9};                // offsets -d along y: channels 0, 2, 4, 6; along x: 1, 3, 5, 7
+
+__device__ __forceinline__ rsrc_t mkbuf(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)kOOB, 0x00020000);
+}
+__device__ __forceinline__ float rnorm(float ss) { return fminf(__builtin_amdgcn_rsqf(ss), 1e12f); }
+__device__ __forceinline__ float pick(f4 c, int r) { return r == 0 ? c.x : r == 1 ? c.y : r == 2 ? c.z : c.w; }
+
+struct Op { h4_t v; };
+__device__ __forceinline__ h4_t ld_op(const char* lds, int addr) { return *(const h4_t*)(lds + addr); }
+__device__ __forceinline__ float ssq4(h4_t a, float acc) {
+  acc = __builtin_amdgcn_fdot2((h2_t){a.x, a.y}, (h2_t){a.x, a.y}, acc, false);
+  return __builtin_amdgcn_fdot2((h2_t){a.z, a.w}, (h2_t){a.z, a.w}, acc, false);
+}
+
+__global__ __launch_bounds__(NT, 3) void k_gram(const __half* __restrict__ e, float* __restrict__ affs, int B, int H, int W,
+                                               int tiles_x, int tiles_per_img, int ntiles, int tiles_per_xcd) {
+  extern __shared__ f4 lds4[];
+  char* lds = (char*)lds4;
+  const int lin = (blockIdx.x % 8) * tiles_per_xcd + blockIdx.x / 8;
+  if (lin >= ntiles) return;
+  const int b = lin / tiles_per_img, rem = lin - b * tiles_per_img;
+  const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
+  const size_t S = (size_t)H * W;
+  const rsrc_t eB = mkbuf(e + (size_t)b * D * S);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 15, lg = lane >> 4;
+
+  // ---- staging items of this lane: item = (group G, region row r, unit u of 8 pixels); the unused top-left corner is skipped
+  unsigned svo[2];
+  int sld[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int it = s * NT + tid;
+    const int G = it / (RH * UNITS), rr = it - G * (RH * UNITS), r = rr / UNITS, u = rr - r * UNITS;
+    int gy = y0 - 16 + r, gx = x0 - 16 + 8 * u;
+    gy += gy < 0 ? H : 0; gy -= gy >= H ? H : 0;
+    gx += gx < 0 ? W : 0; gx -= gx >= W ? W : 0;
+    const bool on = it < ITEMS && !(r < 16 && u < 2);
+    svo[s] = on ? (unsigned)(((4 * G) * S + (size_t)gy * W + gx) * 2) : kOOB;
+    sld[s] = G * PLANE + (r * PITCH + 8 * u) * 8;
+  }
+  const bool two = tid < ITEMS - NT;
+  const unsigned cs = (unsigned)(S * 2);  // channel stride in bytes
+  u4 st[2][4];
+#define STAGE_LOAD(c)                                                                                                      \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                          \
+    if (s == 0 || two) {                                                                                                   \
+      _Pragma("unroll") for (int cc = 0; cc < 4; ++cc)                                                                     \
+        st[s][cc] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(eB, svo[s], (unsigned)((c) * CH + cc) * cs, 0)); \
+    }                                                                                                                      \
+  }
+#define STAGE_WRITE()                                                                                                      \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                          \
+    if ((s == 0 || two) && svo[s] != kOOB) {                                                                               \
+      _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                                      \
+        u4 o;                                                                                                              \
+        o.x = (st[s][0][m] & 0xffffu) | (st[s][1][m] << 16);                                                               \
+        o.y = (st[s][2][m] & 0xffffu) | (st[s][3][m] << 16);                                                               \
+        o.z = (st[s][0][m] >> 16) | (st[s][1][m] & 0xffff0000u);                                                          \
+        o.w = (st[s][2][m] >> 16) | (st[s][3][m] & 0xffff0000u);                                                          \
+        *(u4*)(lds + sld[s] + 16 * m) = o;                                                                                 \
+      }                                                                                                                    \
+    }                                                                                                                      \
+  }
+
+  // ---- operand addresses: lane (li, lg) reads pixel li of the block, channel group lg
+  // x blocks of row r (r = 16 + 4 wave + a): P at column 0, I at 16; y blocks of column c (c = 16 + 4 wave + a): U rows 0.., I rows 16..
+  int ax[4], ay[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) ax[a] = lg * PLANE + ((16 + 4 * wave + a) * PITCH + li) * 8;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) ay[a] = lg * PLANE + (li * PITCH + 16 + 4 * wave + a) * 8;
+
+  f4 cx[4][2], cy[4][2];
+  float nx[4][2], ny[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    cx[a][0] = cx[a][1] = cy[a][0] = cy[a][1] = (f4){0.f, 0.f, 0.f, 0.f};
+    nx[a][0] = nx[a][1] = ny[a] = 0.f;
+  }
+
+  // ablations (timing only, results wrong): -DABL_NOSTAGE no global loads, -DABL_NOMFMA no operand reads / MFMAs, -DABL_NOSTORE no output, -DABL_NOEPI nothing after the channel loop, -DABL_NOWRITE no transposing LDS writes
+#ifndef ABL_NOSTAGE
+  STAGE_LOAD(0)
+#else
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) st[s][cc] = (u4){svo[s], 1u, 2u, 3u};
+#endif
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    __builtin_amdgcn_sched_barrier(0);  // nothing of the previous chunk (its MFMAs hold the operand registers) drifts down here
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef ABL_NOWRITE
+    STAGE_WRITE()
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef ABL_NOSTAGE
+    if (c + 1 < NCH) STAGE_LOAD(c + 1)
+#endif
+#ifndef ABL_NOMFMA
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const h4_t P = ld_op(lds, ax[a]), I = ld_op(lds, ax[a] + 16 * 8);
+      nx[a][0] = ssq4(P, nx[a][0]); nx[a][1] = ssq4(I, nx[a][1]);
+      asm volatile("" : "+v"(nx[a][0]), "+v"(nx[a][1]));  // evaluated here (else the operands stay alive to the end of the kernel)
+      cx[a][0] = __builtin_amdgcn_mfma_f32_16x16x16f16(I, I, cx[a][0], 0, 0, 0);
+      cx[a][1] = __builtin_amdgcn_mfma_f32_16x16x16f16(I, P, cx[a][1], 0, 0, 0);
+      asm volatile("" ::: "memory");  // bound the hoisting of the operand reads
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const h4_t U = ld_op(lds, ay[a]), I = ld_op(lds, ay[a] + 16 * PITCH * 8);
+      ny[a] = ssq4(U, ny[a]);
+      asm volatile("" : "+v"(ny[a]));
+      cy[a][0] = __builtin_amdgcn_mfma_f32_16x16x16f16(I, I, cy[a][0], 0, 0, 0);
+      cy[a][1] = __builtin_amdgcn_mfma_f32_16x16x16f16(I, U, cy[a][1], 0, 0, 0);
+      asm volatile("" ::: "memory");
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the chunk: the region may be overwritten
+  }
+
+#ifdef ABL_NOEPI
+  {
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc += cx[a][0].x + cx[a][1].y + cy[a][0].z + cy[a][1].w + nx[a][0] + nx[a][1] + ny[a];
+    if (acc == 12345.f) affs[tid] = acc;
+    return;
+  }
+#endif
+  // ---- the region is dead.  LDS now: per wave 8 accumulator blocks [16][17] (8704 B), then 1 / norm of the region pixels, then the
+  //      y dots [4][tile pixel] (they come out column-shaped and are stored row-shaped)
+  constexpr int CB = 16 * 17 * 4, WB = 8 * CB;
+  char* sC = lds + wave * WB;
+  float* sInv = (float*)(lds + 4 * WB);
+  float* sDy = (float*)(lds + 4 * WB + RH * PITCH * 4);
+  // squared norms: the four channel groups of a pixel sit in lanes li, li + 16, li + 32, li + 48
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float v = nx[a][p];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lg == 0) sInv[(16 + 4 * wave + a) * PITCH + 16 * p + li] = rnorm(v);
+    }
+    float v = ny[a];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (lg == 0) sInv[li * PITCH + 16 + 4 * wave + a] = rnorm(v);
+  }
+  // lane (j = li, q = lg) holds C[4q + r][j], r = 0..3 (rows = own pixel, columns = neighbour pixel): the blocks go to LDS whole and
+  // every pixel picks its sub-diagonal entries.  x products: this wave's rows 4 wave + a; lane (a = lane / 16, i = lane % 16) afterwards
+  const int la = lane >> 4;
+  float xd[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *(float*)(sC + (a * 2 + p) * CB + ((4 * lg + r) * 17 + li) * 4) = cx[a][p][r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int d = c_d[t];
+    const bool self = li >= d;
+    xd[t] = *(const float*)(sC + (la * 2 + (self ? 0 : 1)) * CB + (li * 17 + (self ? li - d : 16 + li - d)) * 4);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // y products: this wave's columns 4 wave + a; lane (a, i) holds the pixel (row i, column 4 wave + a)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *(float*)(sC + (a * 2 + p) * CB + ((4 * lg + r) * 17 + li) * 4) = cy[a][p][r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int d = c_d[t];
+    const bool self = li >= d;
+    sDy[t * NT + li * TW + 4 * wave + la] = *(const float*)(sC + (la * 2 + (self ? 0 : 1)) * CB + (li * 17 + (self ? li - d : 16 + li - d)) * 4);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // ---- lane = pixel (row tid / 16 = 4 wave + la, column li): normalise, store
+  const int ly = tid >> 4, lx = tid & 15;
+  const int py = y0 + ly, px = x0 + lx;
+#ifdef ABL_NOSTORE
+  if (py < 0) {
+#else
+  if (py < H && px < W) {
+#endif
+    const float io = sInv[(16 + ly) * PITCH + 16 + lx];
+    float* out = affs + (size_t)b * K * S + (size_t)py * W + px;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int d = c_d[t];
+      out[(size_t)(2 * t) * S] = sDy[t * NT + tid] * io * sInv[(16 + ly - d) * PITCH + 16 + lx];
+      out[(size_t)(2 * t + 1) * S] = xd[t] * io * sInv[(16 + ly) * PITCH + 16 + lx - d];
+    }
+  }
+}
+
+#define CK(x)                                                                 \
+  do {                                                                        \
+    hipError_t e_ = (x);                                                      \
+    if (e_ != hipSuccess) {                                                   \
+      printf("%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__);      \
+      return 1;                                                               \
+    }                                                                         \
+  } while (0)
+
+int main(int argc, char** argv) {
+  const int iters = argc > 1 ? atoi(argv[1]) : 50;
+  const int B = 8, H = 544, W = 544;
+  const size_t S = (size_t)H * W, ne = (size_t)B * D * S, na = (size_t)B * K * S;
+  std::vector<__half> he(ne);
+  unsigned long long s = 0x9E3779B97F4A7C15ull;
+  for (size_t i = 0; i < ne; ++i) {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    he[i] = __float2half(((float)((s >> 40) & 0xffff) / 32768.f - 1.f) * 1.5f);
+  }
+  __half* de;
+  float* da;
+  CK(hipMalloc(&de, ne * 2));
+  CK(hipMalloc(&da, na * 4));
+  CK(hipMemcpy(de, he.data(), ne * 2, hipMemcpyHostToDevice));
+  CK(hipMemset(da, 0xff, na * 4));
+  const int tiles_x = W / TW, tiles_y = H / TH, tpi = tiles_x * tiles_y, ntiles = tpi * B, tpx = (ntiles + 7) / 8;
+  CK(hipFuncSetAttribute((const void*)k_gram, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  auto launch = [&]() { hipLaunchKernelGGL(k_gram, dim3(tpx * 8), dim3(NT), LDS_BYTES, 0, de, da, B, H, W, tiles_x, tpi, ntiles, tpx); };
+  launch();
+  CK(hipDeviceSynchronize());
+  std::vector<float> ha(na);
+  CK(hipMemcpy(ha.data(), da, na * 4, hipMemcpyDeviceToHost));
+  // reference on sampled pixels (double accumulation of the f16 values)
+  const int dd[4] = {1, 3, 5, 9};
+  double worst = 0;
+  size_t checked = 0;
+  for (int smp = 0; smp < 4000; ++smp) {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    const int b = (s >> 33) % B, y = (s >> 20) % H, x = (s >> 44) % W;
+    const int yy = smp % 7 == 0 ? (smp % 2 ? 0 : H - 1) : y, xx = smp % 11 == 0 ? (smp % 2 ? 0 : W - 1) : x;
+    auto E = [&](int c, int y_, int x_) { return (double)__half2float(he[((size_t)b * D + c) * S + (size_t)y_ * W + x_]); };
+    auto nrm = [&](int y_, int x_) { double q = 0; for (int c = 0; c < D; ++c) q += E(c, y_, x_) * E(c, y_, x_); return fmax(sqrt(q), 1e-12); };
+    for (int t = 0; t < 4; ++t)
+      for (int ax = 0; ax < 2; ++ax) {
+        const int ny = ax == 0 ? (yy - dd[t] + H) % H : yy, nx = ax == 1 ? (xx - dd[t] + W) % W : xx;
+        double dot = 0;
+        for (int c = 0; c < D; ++c) dot += E(c, yy, xx) * E(c, ny, nx);
+        const double ref = dot / (nrm(yy, xx) * nrm(ny, nx));
+        const double got = ha[((size_t)b * K + 2 * t + ax) * S + (size_t)yy * W + xx];
+        worst = fmax(worst, fabs(ref - got));
+        ++checked;
+      }
+  }
+  printf("gram_mfma: %zu sampled affinities, max |gpu - reference| = %.3e\n", checked, worst);
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  for (int i = 0; i < 10; ++i) launch();
+  CK(hipEventRecord(a));
+  for (int i = 0; i < iters; ++i) launch();
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms;
+  CK(hipEventElapsedTime(&ms, a, b));
+  const double us = ms * 1e3 / iters, bytes = (double)ne * 2 + (double)na * 4;
+  printf("gram_mfma: B=%d D=%d %dx%d K=%d f16: %.1f us per launch, %.0f GB/s of the algorithmic %.0f MB (e once + affs)\n", B, D, H, W, K, us,
+         bytes / us / 1e3, bytes / 1e6);
+  return worst < 2e-3 ? 0 : 2;
+}
