@@ -9,6 +9,7 @@ Reference behaviour mirrored (file:line in the reference tree):
   * embedding_loss_norm1/5, ema_*, inf_*                        scripts_ac3ac4/loss/loss_embedding_mse.py:7-289
   * WeightedMSE normaliser                                      scripts_cvppp/loss/loss.py:112-119
 """
+import collections
 import collections.abc
 import ctypes
 import os
@@ -406,13 +407,45 @@ def activation_flags(activation):
         raise ValueError("activation must be one of %s (or FLAG_* bits), got %r" % (sorted(k for k in ACTIVATIONS if k), activation))
 
 
+_RANGE_MSG = "label ids must fit int32%s: relabel the segmentation first"
+_RANGE_CHECKS = collections.deque()  # (event, pinned flag) of range checks of GPU label tensors that have not been read back yet
+
+
+def check_label_ranges(block=True):
+    """Read back the deferred range checks of _labels_int32 (GPU labels wider than int32): raises ValueError if an earlier label
+    tensor held an id outside int32.  block=False only looks at checks whose copy has already arrived (no host sync); the
+    labels-in entry points poll that way on every call, so a bad id surfaces one or two calls later at the latest."""
+    while _RANGE_CHECKS:
+        ev, host = _RANGE_CHECKS[0]
+        if not block and not ev.query():
+            return
+        ev.synchronize()
+        _RANGE_CHECKS.popleft()
+        if bool(host.item()):
+            raise ValueError(_RANGE_MSG % " (found by the deferred range check of an earlier call)")
+
+
 def _labels_int32(labels):
-    """segmentation ids as the kernels take them (int32).  Wider ids are range-checked first: a silent cast would turn an id
-    >= 2^31 negative (background for BOTH_FOREGROUND) and make ids that agree modulo 2^32 compare equal."""
+    """segmentation ids as the kernels take them (int32).  Wider ids are range-checked: a silent cast would turn an id >= 2^31
+    negative (background for BOTH_FOREGROUND) and make ids that agree modulo 2^32 compare equal.  CPU tensors are checked at once;
+    for GPU tensors the check runs on the device and its flag comes back through pinned memory without a host sync
+    (check_label_ranges) -- ten blocking min / max round trips per training step was what the labels-in path was built to avoid.
+    Under stream capture the check is skipped (a graph cannot raise): validate the ids where they are produced."""
     if labels.dtype in (torch.int64, torch.uint64) and labels.numel():
-        lo, hi = int(labels.min()), int(labels.max())
-        if lo < -2 ** 31 or hi >= 2 ** 31:
-            raise ValueError("label ids must fit int32 (got %d .. %d): relabel the segmentation first" % (lo, hi))
+        l64 = labels.view(torch.int64) if labels.dtype == torch.uint64 else labels  # ids >= 2^63 come out negative: flagged too
+        if not labels.is_cuda:
+            lo, hi = int(l64.min()), int(l64.max())
+            if lo < -2 ** 31 or hi >= 2 ** 31:
+                raise ValueError(_RANGE_MSG % (" (got %d .. %d)" % (lo, hi)))
+        elif not torch.cuda.is_current_stream_capturing():
+            check_label_ranges(block=False)
+            top = l64 >> 31  # 0 or -1 for an id inside int32
+            bad = ((top != 0) & (top != -1)).any()
+            host = torch.empty((), dtype=torch.bool, pin_memory=True)
+            host.copy_(bad, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            _RANGE_CHECKS.append((ev, host))
     return labels.to(torch.int32).contiguous()
 
 

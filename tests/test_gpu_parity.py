@@ -282,6 +282,23 @@ def test_3d_26_neighbourhood_vs_oracle(pkg, dev, orc, synth):
     assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL
 
 
+def test_wide_label_ids_are_range_checked_without_a_host_sync(pkg, dev):
+    """GPU labels wider than int32: the range check runs on the device and is read back later (check_label_ranges); a bad id
+    raises there, a good tensor passes through unchanged; uint64 ids >= 2^63 are caught as well"""
+    op = pkg.affinity_op
+    pkg.check_label_ranges()
+    good = torch.tensor([[0, 5, 2 ** 31 - 1, -2 ** 31]], dtype=torch.int64, device=dev)
+    assert op._labels_int32(good).tolist() == [[0, 5, 2 ** 31 - 1, -2 ** 31]]
+    pkg.check_label_ranges()
+    op._labels_int32(torch.tensor([[0, 2 ** 31]], dtype=torch.int64, device=dev))  # does not raise here ...
+    with pytest.raises(ValueError, match="fit int32"):
+        pkg.check_label_ranges()                                                  # ... but here
+    op._labels_int32(torch.tensor([[1, -2 ** 31 - 1]], dtype=torch.int64, device=dev))
+    with pytest.raises(ValueError, match="fit int32"):
+        pkg.check_label_ranges()
+    pkg.check_label_ranges()  # the queue is empty again
+
+
 @pytest.mark.parametrize("case", ["n26_crop", "n26_circular", "subset_3d", "diag_2d_mask", "z1_volume"])
 def test_unit_box_stencils_vs_oracle(pkg, dev, orc, synth, monkeypatch, case):
     """stencils inside the unit box on the LDS-DMA box kernels (csrc/pea_box.h: X % 4 == 0, D = 16): the 26-neighbourhood with both
