@@ -56,6 +56,83 @@ __device__ __forceinline__ float ssq4(h4_t a, float acc) {
   return __builtin_amdgcn_fdot2((h2_t){a.z, a.w}, (h2_t){a.z, a.w}, acc, false);
 }
 
+// ---- after the channel loop (the staging buffers are dead; the caller's last barrier has passed): normalise and store
+__device__ __forceinline__ void gram_epilogue(char* lds, float* __restrict__ affs, f4 (&cx)[4][2], f4 (&cy)[4][2], float (&nx)[4][2],
+                                              float (&ny)[4], int b, int y0, int x0, int H, int W, size_t S, int tid, int wave, int lane,
+                                              int li, int lg) {
+  // ---- the region is dead.  LDS now: per wave 8 accumulator blocks [16][17] (8704 B), then 1 / norm of the region pixels, then the
+  //      y dots [4][tile pixel] (they come out column-shaped and are stored row-shaped)
+  constexpr int CB = 16 * 17 * 4, WB = 8 * CB;
+  char* sC = lds + wave * WB;
+  float* sInv = (float*)(lds + 4 * WB);
+  float* sDy = (float*)(lds + 4 * WB + RH * PITCH * 4);
+  // squared norms: the four channel groups of a pixel sit in lanes li, li + 16, li + 32, li + 48
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float v = nx[a][p];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lg == 0) sInv[(16 + 4 * wave + a) * PITCH + 16 * p + li] = rnorm(v);
+    }
+    float v = ny[a];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (lg == 0) sInv[li * PITCH + 16 + 4 * wave + a] = rnorm(v);
+  }
+  // lane (j = li, q = lg) holds C[4q + r][j], r = 0..3 (rows = own pixel, columns = neighbour pixel): the blocks go to LDS whole and
+  // every pixel picks its sub-diagonal entries.  x products: this wave's rows 4 wave + a; lane (a = lane / 16, i = lane % 16) afterwards
+  const int la = lane >> 4;
+  float xd[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *(float*)(sC + (a * 2 + p) * CB + ((4 * lg + r) * 17 + li) * 4) = cx[a][p][r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int d = c_d[t];
+    const bool self = li >= d;
+    xd[t] = *(const float*)(sC + (la * 2 + (self ? 0 : 1)) * CB + (li * 17 + (self ? li - d : 16 + li - d)) * 4);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // y products: this wave's columns 4 wave + a; lane (a, i) holds the pixel (row i, column 4 wave + a)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *(float*)(sC + (a * 2 + p) * CB + ((4 * lg + r) * 17 + li) * 4) = cy[a][p][r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int d = c_d[t];
+    const bool self = li >= d;
+    sDy[t * NT + li * TW + 4 * wave + la] = *(const float*)(sC + (la * 2 + (self ? 0 : 1)) * CB + (li * 17 + (self ? li - d : 16 + li - d)) * 4);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // ---- lane = pixel (row tid / 16 = 4 wave + la, column li): normalise, store
+  const int ly = tid >> 4, lx = tid & 15;
+  const int py = y0 + ly, px = x0 + lx;
+#ifdef ABL_NOSTORE
+  if (py < 0) {
+#else
+  if (py < H && px < W) {
+#endif
+    const float io = sInv[(16 + ly) * PITCH + 16 + lx];
+    float* out = affs + (size_t)b * K * S + (size_t)py * W + px;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int d = c_d[t];
+      out[(size_t)(2 * t) * S] = sDy[t * NT + tid] * io * sInv[(16 + ly - d) * PITCH + 16 + lx];
+      out[(size_t)(2 * t + 1) * S] = xd[t] * io * sInv[(16 + ly) * PITCH + 16 + lx - d];
+    }
+  }
+}
+
 __global__ __launch_bounds__(NT, 3) void k_gram(const __half* __restrict__ e, float* __restrict__ affs, int B, int H, int W,
                                                int tiles_x, int tiles_per_img, int ntiles, int tiles_per_xcd) {
   extern __shared__ f4 lds4[];
@@ -177,77 +254,114 @@ __global__ __launch_bounds__(NT, 3) void k_gram(const __half* __restrict__ e, fl
     return;
   }
 #endif
-  // ---- the region is dead.  LDS now: per wave 8 accumulator blocks [16][17] (8704 B), then 1 / norm of the region pixels, then the
-  //      y dots [4][tile pixel] (they come out column-shaped and are stored row-shaped)
-  constexpr int CB = 16 * 17 * 4, WB = 8 * CB;
-  char* sC = lds + wave * WB;
-  float* sInv = (float*)(lds + 4 * WB);
-  float* sDy = (float*)(lds + 4 * WB + RH * PITCH * 4);
-  // squared norms: the four channel groups of a pixel sit in lanes li, li + 16, li + 32, li + 48
+  gram_epilogue(lds, affs, cx, cy, nx, ny, b, y0, x0, H, W, S, tid, wave, lane, li, lg);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same kernel with an ASYNCHRONOUS staging path: buffer_load_dword ... lds.  A wave instruction moves one region row of one
+// 4-channel group -- lane (pair pp, channel c) fetches the two x-adjacent pixels 2pp, 2pp+1 of channel c -- so LDS holds
+// [group][row][pixel pair][4 channels][2 pixels]: a pixel's four channels are the same half of four adjacent dwords; an operand is
+// one ds_read_b128 + two v_perm_b32.  No staging registers, so a ring of THREE chunk buffers (rows 7 .. 31 only: the stencil
+// reaches 9 rows up): 3 x 27200 B = 81600 B, two workgroups per CU, one barrier per chunk, two chunks in flight.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr int R0 = 7, NR = RH - R0;                       // region rows kept: 7 .. 31
+constexpr int RP = 16 * 16 + 16;                          // row pitch: 16 pairs x 16 B + 16 (column blocks: 16 rows on 64 banks)
+constexpr int GP = NR * RP, CBUF = NG * GP;               // 6800, 27200
+constexpr int LDS_DMA = 3 * CBUF > LDS_BYTES ? 3 * CBUF : LDS_BYTES;
+constexpr int NDMA = NG * NR / 4;                         // 25 wave instructions per wave and chunk
+
+__device__ __forceinline__ h4_t ld_op_dma(const char* lds, int addr, unsigned sel) {
+  const u4 d = *(const u4*)(lds + addr);
+  u2 o;
+  o.x = __builtin_amdgcn_perm(d.y, d.x, sel);
+  o.y = __builtin_amdgcn_perm(d.w, d.z, sel);
+  return __builtin_bit_cast(h4_t, o);
+}
+
+__global__ __launch_bounds__(NT, 4) void k_gram_dma(const __half* __restrict__ e, float* __restrict__ affs, int B, int H, int W,
+                                                   int tiles_x, int tiles_per_img, int ntiles, int tiles_per_xcd) {
+  extern __shared__ f4 lds4[];
+  char* lds = (char*)lds4;
+  const int lin = (blockIdx.x % 8) * tiles_per_xcd + blockIdx.x / 8;
+  if (lin >= ntiles) return;
+  const int b = lin / tiles_per_img, rem = lin - b * tiles_per_img;
+  const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
+  const size_t S = (size_t)H * W;
+  const rsrc_t eB = mkbuf(e + (size_t)b * D * S);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 15, lg = lane >> 4;
+  const unsigned cs = (unsigned)(S * 2);
+
+  // this lane's part of a row: pixel pair pp, channel c of the group; rows above the tile need the right half only
+  const int pp = lane >> 2, cc = lane & 3;
+  int gx = x0 - 16 + 2 * pp;
+  gx += gx < 0 ? W : 0; gx -= gx >= W ? W : 0;
+  const unsigned vo_full = (unsigned)cc * cs + (unsigned)gx * 2u;
+  const unsigned vo_top = pp >= 8 ? vo_full : kOOB;
+#define DMA_CHUNK(c)                                                                                                        \
+  {                                                                                                                         \
+    const int buf_ = ((c) % 3) * CBUF;                                                                                      \
+    _Pragma("unroll 5") for (int n = 0; n < NDMA; ++n) {                                                                    \
+      const int idx = n * 4 + wave, G = idx / NR, rr = idx - G * NR;                                                        \
+      int gy = y0 - 16 + R0 + rr;                                                                                           \
+      gy += gy < 0 ? H : 0; gy -= gy >= H ? H : 0;                                                                          \
+      const unsigned so = (unsigned)((c) * CH + 4 * G) * cs + (unsigned)gy * (unsigned)W * 2u;                              \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(eB, (lds_ptr_t)(lds + buf_ + G * GP + rr * RP), 4, rr < 16 - R0 ? vo_top : vo_full, so, 0, 0); \
+    }                                                                                                                       \
+  }
+  DMA_CHUNK(0)
+  DMA_CHUNK(1)
+
+  // operand addresses inside a chunk buffer.  x blocks of tile row 4 wave + a: region row 16 + 4 wave + a, P = pairs 0..7, I = 8..15;
+  // y blocks of tile column 4 wave + a: pair 8 + (4 wave + a) / 2, half a & 1; U = region rows 0..15 (rows < 7 are not staged: the
+  // lanes read row 7 instead, their products are never used), I = rows 16..31
+  const unsigned selx = (li & 1) ? 0x07060302u : 0x05040100u;
+  int ax[4], ayu[4];
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
+    ax[a] = lg * GP + (16 - R0 + 4 * wave + a) * RP + (li >> 1) * 16;
+    ayu[a] = lg * GP + (li < R0 ? 0 : li - R0) * RP + (8 + (4 * wave + a) / 2) * 16;
+  }
+  f4 cx[4][2], cy[4][2];
+  float nx[4][2], ny[4];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      float v = nx[a][p];
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
-      if (lg == 0) sInv[(16 + 4 * wave + a) * PITCH + 16 * p + li] = rnorm(v);
+  for (int a = 0; a < 4; ++a) {
+    cx[a][0] = cx[a][1] = cy[a][0] = cy[a][1] = (f4){0.f, 0.f, 0.f, 0.f};
+    nx[a][0] = nx[a][1] = ny[a] = 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 2 < NCH) DMA_CHUNK(c + 2)
+    const char* cb = lds + (c % 3) * CBUF;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const h4_t P = ld_op_dma(cb, ax[a], selx), I = ld_op_dma(cb, ax[a] + 8 * 16, selx);
+      nx[a][0] = ssq4(P, nx[a][0]); nx[a][1] = ssq4(I, nx[a][1]);
+      asm volatile("" : "+v"(nx[a][0]), "+v"(nx[a][1]));
+      cx[a][0] = __builtin_amdgcn_mfma_f32_16x16x16f16(I, I, cx[a][0], 0, 0, 0);
+      cx[a][1] = __builtin_amdgcn_mfma_f32_16x16x16f16(I, P, cx[a][1], 0, 0, 0);
+      asm volatile("" ::: "memory");
     }
-    float v = ny[a];
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    if (lg == 0) sInv[li * PITCH + 16 + 4 * wave + a] = rnorm(v);
-  }
-  // lane (j = li, q = lg) holds C[4q + r][j], r = 0..3 (rows = own pixel, columns = neighbour pixel): the blocks go to LDS whole and
-  // every pixel picks its sub-diagonal entries.  x products: this wave's rows 4 wave + a; lane (a = lane / 16, i = lane % 16) afterwards
-  const int la = lane >> 4;
-  float xd[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) *(float*)(sC + (a * 2 + p) * CB + ((4 * lg + r) * 17 + li) * 4) = cx[a][p][r];
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int d = c_d[t];
-    const bool self = li >= d;
-    xd[t] = *(const float*)(sC + (la * 2 + (self ? 0 : 1)) * CB + (li * 17 + (self ? li - d : 16 + li - d)) * 4);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  // y products: this wave's columns 4 wave + a; lane (a, i) holds the pixel (row i, column 4 wave + a)
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) *(float*)(sC + (a * 2 + p) * CB + ((4 * lg + r) * 17 + li) * 4) = cy[a][p][r];
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int d = c_d[t];
-    const bool self = li >= d;
-    sDy[t * NT + li * TW + 4 * wave + la] = *(const float*)(sC + (la * 2 + (self ? 0 : 1)) * CB + (li * 17 + (self ? li - d : 16 + li - d)) * 4);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  // ---- lane = pixel (row tid / 16 = 4 wave + la, column li): normalise, store
-  const int ly = tid >> 4, lx = tid & 15;
-  const int py = y0 + ly, px = x0 + lx;
-#ifdef ABL_NOSTORE
-  if (py < 0) {
-#else
-  if (py < H && px < W) {
-#endif
-    const float io = sInv[(16 + ly) * PITCH + 16 + lx];
-    float* out = affs + (size_t)b * K * S + (size_t)py * W + px;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int d = c_d[t];
-      out[(size_t)(2 * t) * S] = sDy[t * NT + tid] * io * sInv[(16 + ly - d) * PITCH + 16 + lx];
-      out[(size_t)(2 * t + 1) * S] = xd[t] * io * sInv[(16 + ly) * PITCH + 16 + lx - d];
+    for (int a = 0; a < 4; ++a) {
+      const unsigned sely = (a & 1) ? 0x07060302u : 0x05040100u;
+      const h4_t U = ld_op_dma(cb, ayu[a], sely), I = ld_op_dma(cb, lg * GP + (16 - R0 + li) * RP + (8 + (4 * wave + a) / 2) * 16, sely);
+      ny[a] = ssq4(U, ny[a]);
+      asm volatile("" : "+v"(ny[a]));
+      cy[a][0] = __builtin_amdgcn_mfma_f32_16x16x16f16(I, I, cy[a][0], 0, 0, 0);
+      cy[a][1] = __builtin_amdgcn_mfma_f32_16x16x16f16(I, U, cy[a][1], 0, 0, 0);
+      asm volatile("" ::: "memory");
     }
   }
+#undef DMA_CHUNK
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the ring
+  gram_epilogue(lds, affs, cx, cy, nx, ny, b, y0, x0, H, W, S, tid, wave, lane, li, lg);
 }
 
 #define CK(x)                                                                 \
@@ -276,8 +390,13 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(de, he.data(), ne * 2, hipMemcpyHostToDevice));
   CK(hipMemset(da, 0xff, na * 4));
   const int tiles_x = W / TW, tiles_y = H / TH, tpi = tiles_x * tiles_y, ntiles = tpi * B, tpx = (ntiles + 7) / 8;
+#ifdef DMA_STAGE
+  CK(hipFuncSetAttribute((const void*)k_gram_dma, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA));
+  auto launch = [&]() { hipLaunchKernelGGL(k_gram_dma, dim3(tpx * 8), dim3(NT), LDS_DMA, 0, de, da, B, H, W, tiles_x, tpi, ntiles, tpx); };
+#else
   CK(hipFuncSetAttribute((const void*)k_gram, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   auto launch = [&]() { hipLaunchKernelGGL(k_gram, dim3(tpx * 8), dim3(NT), LDS_BYTES, 0, de, da, B, H, W, tiles_x, tpi, ntiles, tpx); };
+#endif
   launch();
   CK(hipDeviceSynchronize());
   std::vector<float> ha(na);
