@@ -354,6 +354,40 @@ def test_unit_box_stencils_vs_oracle(pkg, dev, orc, synth, monkeypatch, case):
     assert relmax(et2.grad.cpu().numpy(), et.grad.cpu().numpy()) < GRAD_RTOL
 
 
+def test_random_unit_box_stencils_vs_oracle(pkg, dev, orc, synth):
+    """seeded sweep over the unit-box kernels' domain: random subsets of the 26 displacements (both signs, duplicates excluded),
+    ragged Z / Y and X % 4 == 0 widths (partial tiles, one-tile images), both borders, all three normalisers, batch, mask"""
+    op, lib = pkg.affinity_op, pkg._lib.lib()
+    rng = np.random.default_rng(3026)
+    n26 = [[dz, dy, dx] for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dz, dy, dx) != (0, 0, 0)]
+    for it in range(10):
+        B = int(rng.integers(1, 3))
+        Z, Y, X = int(rng.integers(2, 7)), int(rng.integers(17, 60)), 4 * int(rng.integers(9, 30))
+        K = int(rng.integers(1, 27))
+        offs = [n26[i] for i in rng.permutation(26)[:K]]
+        border = int(rng.integers(0, 2))
+        norm = int(rng.integers(0, 3))
+        lam = [float(v) for v in rng.uniform(0.25, 2.0, K)]
+        S = Z * Y * X
+        e = synth.synth_embedding((B, 16, S), 700 + it).reshape(B, 16, Z, Y, X)
+        t = (synth.hash_uniform(np.arange(B * K * S, dtype=np.uint64), 800 + it) < 0.6).astype(np.float32).reshape(B, K, Z, Y, X)
+        w = (0.5 + synth.hash_uniform(np.arange(B * K * S, dtype=np.uint64), 900 + it)).astype(np.float32).reshape(B, K, Z, Y, X)
+        m = (synth.hash_uniform(np.arange(B * K * S, dtype=np.uint64), 1000 + it) < 0.9).astype(np.uint8).reshape(B, K, Z, Y, X) if it % 2 else None
+        spec = op.AffinitySpec(3, offs, lam, border, norm)
+        et = cu(e, dev).requires_grad_(True)
+        d_hip = op.make_desc(spec, et)
+        assert lib.pea_cross_supported(ctypes.byref(d_hip), 1) == 1, (it, offs)
+        loss, affs, parts = op.FusedAffinityMSE.apply(et, None, cu(t, dev), cu(w, dev), cu(m, dev), spec)
+        (loss * 1.5).backward()
+        d = orc.make_desc(B, 16, [Z, Y, X], offs, lam, border, norm, ndim=3)
+        o_affs, o_loss = orc.c_fwd(d, e, None, t, w, m)
+        o_grad, _ = orc.c_bwd(d, e, None, t, w, m, dloss=1.5)
+        ctx = "case %d: B=%d %dx%dx%d K=%d border=%d norm=%d mask=%s" % (it, B, Z, Y, X, K, border, norm, m is not None)
+        assert np.abs(affs.cpu().numpy() - o_affs).max() < AFFS_ATOL, ctx
+        np.testing.assert_allclose(parts.cpu().numpy(), o_loss[1:], rtol=LOSS_RTOL, atol=1e-7, err_msg=ctx)
+        assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL, ctx
+
+
 def test_random_shapes_and_stencils_vs_oracle(pkg, dev, orc, synth):
     """seeded sweep over ragged sizes, offset lists (both signs), borders, batch and D"""
     op = pkg.affinity_op
