@@ -87,7 +87,7 @@ int& g_pending_error() {
 
 // ---- loss finish ------------------------------------------------------------------------------------------------------------
 void launch_loss_finish(const KParams& P, LossState* st, float* loss_out, hipStream_t s) {
-  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, s, P, st, loss_out);
+  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64u * (unsigned)((P.K + 3) / 4)), 0, s, P, st, loss_out);
 }
 void launch_loss_state_init(LossState* st, int n, hipStream_t s) {
   const size_t words = (size_t)n * (sizeof(LossState) / 4);

@@ -87,45 +87,43 @@ __device__ __forceinline__ double loss_value(u64 lo_s, u64 mid_s, u64 hi_s, unsi
   return d;
 }
 
-// The finish, by ONE whole wave: four offsets per pass (lane = 16 * j + s: offset k0 + j, slot s), totals in offset order.
+// The finish: one workgroup of ceil(K / 4) waves, four offsets per wave (lane = 16 * j + s: offset 4 * wave + j, slot s), so every
+// accumulator word is requested in ONE round of loads (the one-wave form walked the offsets four at a time: three dependent round
+// trips at K = 10, 10 us per launch in the loss section's trace); the weighted total is summed in offset order by one lane.
 // Plain loads and plain zero stores: a kernel boundary lies between the adds and these reads.
-__device__ __forceinline__ void loss_finish_wave(const KParams& P, LossState* __restrict__ st, float* __restrict__ loss_out) {
-  const int lane = threadIdx.x & 63, s = lane & (kLossSlots - 1), j = lane >> 4;
+static __global__ __launch_bounds__(512) void k_loss_finish(const KParams P, LossState* __restrict__ st, float* __restrict__ loss_out) {
+  __shared__ double s_l[PEA_MAX_K];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, s = lane & (kLossSlots - 1), j = lane >> 4;
   const bool good = st->magic == kLossMagic;
-  double tot = 0.0;
-  for (int k0 = 0; k0 < P.K; k0 += 4) {  // uniform
-    const int k = k0 + j;
-    const bool on = k < P.K;
-    u64 v0 = 0, v1 = 0, v2 = 0;
-    unsigned fl = 0;
-    if (on) {
-      u64* a = st->acc[s][k];
-      v0 = a[0]; v1 = a[1]; v2 = a[2];
-      a[0] = 0; a[1] = 0; a[2] = 0;
-      if (s == 0) { fl = st->flags[k]; st->flags[k] = 0; }
-    }
-#pragma unroll
-    for (int o = 1; o < kLossSlots; o <<= 1) {  // the 16 slots of an offset sit in 16 adjacent lanes
-      v0 += __shfl_xor(v0, o, 64);
-      v1 += __shfl_xor(v1, o, 64);
-      v2 += __shfl_xor(v2, o, 64);
-      fl |= __shfl_xor(fl, o, 64);
-    }
-    double Li = on ? loss_value(v0, v1, v2, fl) * (double)P.inv_n[k] : 0.0;
-    if (!good) Li = __builtin_nan("");  // the state block was never initialised (pea_workspace_init): say so
-    if (on && s == 0) loss_out[1 + k] = (float)Li;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const double Lk = __shfl(Li, 16 * jj, 64);
-      if (k0 + jj < P.K) tot += (double)P.lam[k0 + jj] * Lk;
-    }
+  const int k = 4 * wave + j;
+  const bool on = k < P.K;
+  u64 v0 = 0, v1 = 0, v2 = 0;
+  unsigned fl = 0;
+  if (on) {
+    u64* a = st->acc[s][k];
+    v0 = a[0]; v1 = a[1]; v2 = a[2];
+    a[0] = 0; a[1] = 0; a[2] = 0;
+    if (s == 0) { fl = st->flags[k]; st->flags[k] = 0; }
   }
-  if (lane == 0) loss_out[0] = (float)tot;
-}
-
-// the separate launch
-static __global__ __launch_bounds__(64) void k_loss_finish(const KParams P, LossState* __restrict__ st, float* __restrict__ loss_out) {
-  loss_finish_wave(P, st, loss_out);
+#pragma unroll
+  for (int o = 1; o < kLossSlots; o <<= 1) {  // the 16 slots of an offset sit in 16 adjacent lanes
+    v0 += __shfl_xor(v0, o, 64);
+    v1 += __shfl_xor(v1, o, 64);
+    v2 += __shfl_xor(v2, o, 64);
+    fl |= __shfl_xor(fl, o, 64);
+  }
+  double Li = on ? loss_value(v0, v1, v2, fl) * (double)P.inv_n[k] : 0.0;
+  if (!good) Li = __builtin_nan("");  // the state block was never initialised (pea_workspace_init): say so
+  if (on && s == 0) {
+    loss_out[1 + k] = (float)Li;
+    s_l[k] = Li;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < P.K; ++i) tot += (double)P.lam[i] * s_l[i];
+    loss_out[0] = (float)tot;
+  }
 }
 
 // pea_workspace_init: zero `n` states and mark them initialised
