@@ -238,8 +238,11 @@ __global__ __launch_bounds__(kBoxTH* kBoxTW, 4) void k_fwd_box(const KParams P, 
 // ------------------------------------------------------------------------------------------------------------------
 // backward, self loss (both roles)
 // ------------------------------------------------------------------------------------------------------------------
+// LDS: the ring only (52 KB: THREE workgroups per CU at 72 VGPRs) -- the 1 / norm region starts out in the third chunk buffer, which
+// is first filled after the coefficients are done (as in k_bwd_xdma).
+constexpr int kBoxLdsBwd = 3 * kBoxCB;
 template <int D_T, bool CROP>
-__global__ __launch_bounds__(kBoxTH* kBoxTW, 4) void k_bwd_box(const KParams P, const BParams C, const float* __restrict__ xt,
+__global__ __launch_bounds__(kBoxTH* kBoxTW, 6) void k_bwd_box(const KParams P, const BParams C, const float* __restrict__ xt,
                                                                const float* __restrict__ invp, const float* __restrict__ gin,
                                                                const float* __restrict__ dloss, float* __restrict__ dx) {
   constexpr int TH = kBoxTH, TW = kBoxTW, NP = D_T / 2;
@@ -261,8 +264,8 @@ __global__ __launch_bounds__(kBoxTH* kBoxTW, 4) void k_bwd_box(const KParams P, 
   {
     const unsigned vn0 = box_item<CROP>(P, wave * 64 + lane, kBoxNQ, z, y0, x0, false);
     const unsigned vn1 = box_item<CROP>(P, 8 * 64 + lane, kBoxNQ, z, y0, x0, false);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(iB, (lds_ptr_t)(lds + kBoxSN + wave * 1024), 16, vn0, 0u, 0, 0);
-    if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(iB, (lds_ptr_t)(lds + kBoxSN + 8 * 1024), 16, vn1, 0u, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(iB, (lds_ptr_t)(lds + 2 * kBoxCB + wave * 1024), 16, vn0, 0u, 0, 0);
+    if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(iB, (lds_ptr_t)(lds + 2 * kBoxCB + 8 * 1024), 16, vn1, 0u, 0, 0);
   }
   PEA_BDMA(0, 0u)
 
@@ -290,18 +293,19 @@ __global__ __launch_bounds__(kBoxTH* kBoxTW, 4) void k_bwd_box(const KParams P, 
   PEA_BWAIT1()  // the 1 / norm region, chunk 0 and every g have landed
   const int own = kBoxRP * 4 + ((ly + 1) * kBoxRW + lx + 4) * 4;
   const char* const rb = lds + own - kBoxBias;
-  const float invo = *(const float*)(lds + kBoxSN + own);
+  const float invo = *(const float*)(lds + 2 * kBoxCB + own);
   const float inv_own = fabsf(invo);
   f2 c2[kBoxND / 2];
 #pragma unroll
   for (int s = 0; s < kBoxND; ++s) {
-    const float iq = fabsf(*(const float*)(rb + kBoxSN + kBoxBias + box_lds(s)));
+    const float iq = fabsf(*(const float*)(rb + 2 * kBoxCB + kBoxBias + box_lds(s)));
     const float v = c[s] * iq;
     if (s & 1) c2[s / 2].y = v;
     else c2[s / 2].x = v;
   }
 #pragma unroll
   for (int s = 0; s < kBoxND / 2; ++s) asm volatile("" : "+v"(c2[s]));
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the 1 / norm region is dead: the third buffer may be filled
   PEA_BDMA(2, 4u * ecs)
 
   f2 G[NP], eh[NP];

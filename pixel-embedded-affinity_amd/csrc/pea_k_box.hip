@@ -66,12 +66,10 @@ bool box_bwd(const KParams& P, const float* x, const float* inv, const float* g,
   const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kBoxTH * kBoxTW);
   if (P.border != PEA_BORDER_CIRCULAR) {
     constexpr auto kern = k_bwd_box<16, true>;
-    if (allow_lds<kern>(kBoxLds)) return false;
-    hipLaunchKernelGGL(kern, grid, blk, kBoxLds, s, P, C, x, inv, g, dl, dx);
+    hipLaunchKernelGGL(kern, grid, blk, kBoxLdsBwd, s, P, C, x, inv, g, dl, dx);
   } else {
     constexpr auto kern = k_bwd_box<16, false>;
-    if (allow_lds<kern>(kBoxLds)) return false;
-    hipLaunchKernelGGL(kern, grid, blk, kBoxLds, s, P, C, x, inv, g, dl, dx);
+    hipLaunchKernelGGL(kern, grid, blk, kBoxLdsBwd, s, P, C, x, inv, g, dl, dx);
   }
   return true;
 }
