@@ -151,9 +151,9 @@ bool bwd_self_h(const KParams& P, const __half* x, const float* inv, const float
     constexpr auto kern = k_bwd_xdma_h<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, kXP, true, WPE_>;          \
     PEA_LAUNCH(kern, grid, blk, (size_t)5 * PSU_ * 256, s, P, X.C, x, inv, g, affs, dl, dx)            \
   }
-      // (small planes: 35 KB per workgroup, and with the neighbour slots packed two to a register the kernel keeps to 80 VGPRs:
-      //  three workgroups per CU -- measured on one box against two: 314-316 against 316-318 us, the kernel is not occupancy-bound)
-      if (small) { if (crop) PEA_HPF(true, kXdmaPSUHS, 6) else PEA_HPF(false, kXdmaPSUHS, 6) }
+      // (87 VGPRs: the conversion's temporaries keep it above the 80 a third workgroup would need; small planes all the same --
+      //  less LDS per workgroup never hurts the other kernels sharing the CU in a multi-stream section)
+      if (small) { if (crop) PEA_HPF(true, kXdmaPSUHS, 4) else PEA_HPF(false, kXdmaPSUHS, 4) }
       else { if (crop) PEA_HPF(true, kXdmaPSUH, 4) else PEA_HPF(false, kXdmaPSUH, 4) }
 #undef PEA_HPF
       return true;

@@ -152,11 +152,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
   const unsigned pg = live ? po * 4u : 0xC0000000u;
   static_assert(XP % 2 == 0, "coefficients are kept two to a register pair");
   f2 cx2[XP / 2], cy2[XP / 2];  // pair k in half (k & 1) of element k / 2
-  // LDS slots of the neighbours, as byte offsets into the WORKING buffer (8 bytes per region pixel: < 2^16), the x pair's in the low
-  // and the y pair's in the high half of one register: ten registers instead of twenty, which is what takes the kernel from 87 to
-  // under 80 VGPRs -- three workgroups per CU on the small planes -- for one v_and / v_lshr per gather
-  unsigned axy[XP];
-  static_assert(2 * PS <= 65536, "a working-buffer offset fits 16 bits");
+  int ax[XP], ay[XP];
   const int vown = ((C.hy0 + ly) * TW + lx) * 4;   // byte offset of the own pixel in a PLANE (the 1 / norm plane); x 2 in W
   const int hrow = (C.QV * 4 + ly * C.SW) * 4;
 #pragma unroll
@@ -170,7 +166,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
     cx2[k / 2][k & 1] = gk;
     if (PF) proj = fmaf(gk, bl32(aB, k < C.npx ? o : kOOB, fzo + (unsigned)C.xgi[k] * fcs), proj);
     const int d = C.xd[k], c = lx + d;
-    axy[k] = (unsigned)(2 * ((unsigned)c < (unsigned)TW ? vown + d * 4 : hrow + (c & C.xm[k]) * 4));
+    ax[k] = (unsigned)c < (unsigned)TW ? vown + d * 4 : hrow + (c & C.xm[k]) * 4;
   }
 #pragma unroll
   for (int k = 0; k < XP; ++k) {
@@ -182,7 +178,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
     const float gk = bl32(gB, k < C.npy ? o : kOOB, fzo + (unsigned)C.ygi[k] * fcs);
     cy2[k / 2][k & 1] = gk;
     if (PF) proj = fmaf(gk, bl32(aB, k < C.npy ? o : kOOB, fzo + (unsigned)C.ygi[k] * fcs), proj);
-    axy[k] |= (unsigned)(2 * (vown + C.yd[k] * TW * 4)) << 16;
+    ay[k] = vown + C.yd[k] * TW * 4;
   }
   if (NP > 1) PEA_HDMA16(1, 2)
   // the 1 / norm plane, chunk 0 and g have landed (chunk 1 may still fly)
@@ -192,8 +188,8 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
   const float inv_own = fabsf(invo);
 #pragma unroll
   for (int k = 0; k < XP; ++k) {
-    cx2[k / 2][k & 1] *= fabsf(*(const float*)(W + PS + ((axy[k] & 0xffffu) >> 1)));
-    cy2[k / 2][k & 1] *= fabsf(*(const float*)(W + PS + (axy[k] >> 17)));
+    cx2[k / 2][k & 1] *= fabsf(*(const float*)(W + PS + ax[k]));
+    cy2[k / 2][k & 1] *= fabsf(*(const float*)(W + PS + ay[k]));
     if (k & 1) asm volatile("" : "+v"(cx2[k / 2]), "+v"(cy2[k / 2]));
   }
   lds_barrier();  // the 1 / norm plane is dead: the working planes may be written
@@ -218,17 +214,13 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
     f2 acc = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < XP; ++k) {
-      unsigned a_ = axy[k];
-      asm volatile("" : "+v"(a_));  // opaque: the unpacked address is made per use, not once per kernel (that would be the 20 registers again)
-      const f2 v = *(const f2*)(W + (a_ & 0xffffu));
+      const f2 v = *(const f2*)(W + 2 * ax[k]);
       acc = (k & 1) ? pk_fma_c<true>(cx2[k / 2], v, acc) : pk_fma_c<false>(cx2[k / 2], v, acc);
       if (k % 5 == 4) asm volatile("" ::: "memory");
     }
 #pragma unroll
     for (int k = 0; k < XP; ++k) {
-      unsigned a_ = axy[k];
-      asm volatile("" : "+v"(a_));
-      const f2 v = *(const f2*)(W + (a_ >> 16));
+      const f2 v = *(const f2*)(W + 2 * ay[k]);
       acc = (k & 1) ? pk_fma_c<true>(cy2[k / 2], v, acc) : pk_fma_c<false>(cy2[k / 2], v, acc);
       if (k % 5 == 4) asm volatile("" ::: "memory");
     }
