@@ -33,6 +33,7 @@ void env_load() {
   g_env.infer_xdma = env_int("PEA_INFER_XDMA", 1);
   g_env.bwd_pf = env_int("PEA_BWD_PF", 1);
   g_env.box = env_int("PEA_BOX", 1);
+  g_env.h16_hw = env_int("PEA_H16_HW", 1);
   g_env.zblk_y = env_int("PEA_ZBLK_Y", 0);
   g_env.zblk_x = env_int("PEA_ZBLK_X", 0);
 }

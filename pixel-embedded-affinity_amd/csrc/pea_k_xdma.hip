@@ -122,6 +122,17 @@ bool fwd_self_h(const KParams& P, const FwdArgs& A, hipStream_t s) {
   if (!plan(P, kXdmaPSUF, 1, &X) || X.C.nfz > 0 || P.K > kXP) return false;
   const size_t lds = (size_t)5 * kXdmaPSUF * 256;  // two f32 working planes + six half-size ring planes
   const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  if (env().h16_hw) {  // half-precision working buffer, v_dot2 gather: 48 VGPRs and 30 KB -- four workgroups per CU (five: 173 against 168 us)
+    const size_t ldsh = (size_t)4 * kXdmaPSUF * 256;
+    if (P.border != PEA_BORDER_CIRCULAR) {
+      constexpr auto kern = k_fwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, true, TRAIN, 8, true>;
+      PEA_LAUNCH(kern, grid, blk, ldsh, s, P, X.C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out)
+    } else {
+      constexpr auto kern = k_fwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, false, TRAIN, 8, true>;
+      PEA_LAUNCH(kern, grid, blk, ldsh, s, P, X.C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out)
+    }
+    return true;
+  }
   if (P.border != PEA_BORDER_CIRCULAR) {
     constexpr auto kern = k_fwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, true, TRAIN, 6>;
     PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out)
@@ -148,8 +159,13 @@ bool bwd_self_h(const KParams& P, const __half* x, const float* inv, const float
       const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd));
 #define PEA_HPF(CROP_, PSU_, WPE_)                                                                   \
   {                                                                                                  \
-    constexpr auto kern = k_bwd_xdma_h<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, kXP, true, WPE_>;          \
-    PEA_LAUNCH(kern, grid, blk, (size_t)5 * PSU_ * 256, s, P, X.C, x, inv, g, affs, dl, dx)            \
+    if (env().h16_hw) {                                                                              \
+      constexpr auto kern = k_bwd_xdma_h<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, kXP, true, WPE_, true>;  \
+      PEA_LAUNCH(kern, grid, blk, (size_t)5 * PSU_ * 256, s, P, X.C, x, inv, g, affs, dl, dx)          \
+    } else {                                                                                         \
+      constexpr auto kern = k_bwd_xdma_h<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, kXP, true, WPE_>;        \
+      PEA_LAUNCH(kern, grid, blk, (size_t)5 * PSU_ * 256, s, P, X.C, x, inv, g, affs, dl, dx)          \
+    }                                                                                                \
   }
       // (87 VGPRs: the conversion's temporaries keep it above the 80 a third workgroup would need; small planes all the same --
       //  less LDS per workgroup never hurts the other kernels sharing the CU in a multi-stream section)

@@ -14,6 +14,8 @@
 // 2 x 13 KB + 6 x 6.5 KB = 64 KB (two workgroups per CU), forward 2 x 7.5 KB + 6 x 3.75 KB = 37.5 KB (three).
 // Self loss / inference, 2D, X % 8 == 0 (an 8-pixel DMA item never straddles a row end), axis-aligned stencils, D in {16, 32, 64}.
 #pragma once
+#include <type_traits>
+
 #include "pea_xdma_pf.h"
 
 namespace pea {
@@ -98,12 +100,34 @@ __device__ __forceinline__ void convert_chunk(char* W, const char* R, int rbuf, 
   }
 }
 
+// f16 chunk `rbuf` of the ring -> a HALF-precision working buffer, the two channels of a pixel side by side (4 bytes per region
+// pixel): no conversion at all, half the bytes to write and a quarter of the bytes to gather -- the forward's per-pair work is
+// `dot += <own, v>`, `ssq += <v, v>` over the two channels, which is exactly v_dot2_f32_f16 (f16 products are exact in f32, the
+// accumulation is f32): one ds_read_b32 + two v_dot2 per pair, scalar accumulators (half the registers of the packed-f32 form).
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+template <int PS, int NT>
+__device__ __forceinline__ void interleave_chunk(char* W, const char* R, int rbuf, int qa) {
+  constexpr int PH = PS / 2;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int q = s * NT + (int)threadIdx.x;
+    if (q < qa) {
+      const h4_t h0 = *(const h4_t*)(R + (rbuf * 2) * PH + q * 8);
+      const h4_t h1 = *(const h4_t*)(R + (rbuf * 2 + 1) * PH + q * 8);
+      typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+      *(h8_t*)(W + q * 16) = (h8_t){h0.x, h1.x, h0.y, h1.y, h0.z, h1.z, h0.w, h1.w};
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // backward, self loss (both roles), f16 e / de
 // ------------------------------------------------------------------------------------------------------------------
 // PF: the projection first (pea_xdma_pf.h): `affs` = the raw cosine map of the forward; a chunk then finishes its two channels
 // (stored at once, in f16), there is no G array and no second read of the own pixel; WPE = 6 with the small planes.
-template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, bool PF = false, int WPE = 4>
+// HW: the working buffer stays in f16 (interleave_chunk: no conversion, half the LDS bytes written, a ds_read_b32 per pair instead of
+// a ds_read_b64); the FMAs take the halves directly (v_fma_mix_f32: f16 operand, f32 coefficient and accumulator -- the same arithmetic)
+template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, bool PF = false, int WPE = 4, bool HW = false>
 __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, const XParams C, const __half* __restrict__ xt,
                                                              const float* __restrict__ invp, const float* __restrict__ gin,
                                                              const float* __restrict__ affs, const float* __restrict__ dloss,
@@ -203,15 +227,33 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
   }
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
+    f2 o, acc = {0.f, 0.f};
+    if constexpr (HW) {
+      interleave_chunk<PS, NT>(W, R, ps % 3, C.QA);
+      lds_barrier();  // the working buffer holds chunk ps
+      const h2_t oh = *(const h2_t*)(W + vown);
+      o = (f2){(float)oh.x, (float)oh.y} * inv_own;
+#pragma unroll
+      for (int k = 0; k < XP; ++k) {
+        const h2_t v = *(const h2_t*)(W + ax[k]);
+        const float c = (k & 1) ? cx2[k / 2].y : cx2[k / 2].x;
+        acc.x = __builtin_fmaf((float)v.x, c, acc.x);
+        acc.y = __builtin_fmaf((float)v.y, c, acc.y);
+        if (k % 5 == 4) asm volatile("" ::: "memory");
+      }
+#pragma unroll
+      for (int k = 0; k < XP; ++k) {
+        const h2_t v = *(const h2_t*)(W + ay[k]);
+        const float c = (k & 1) ? cy2[k / 2].y : cy2[k / 2].x;
+        acc.x = __builtin_fmaf((float)v.x, c, acc.x);
+        acc.y = __builtin_fmaf((float)v.y, c, acc.y);
+        if (k % 5 == 4) asm volatile("" ::: "memory");
+      }
+    } else {
     convert_chunk<PS, NT>(W, R, ps % 3, C.QA);
     lds_barrier();  // the working buffer holds chunk ps
-    f2 o = *(const f2*)(W + 2 * vown);
+    o = *(const f2*)(W + 2 * vown);
     o = o * inv_own;
-    if (KEEP) {
-      eh[ps] = o;
-      asm volatile("" : "+v"(eh[ps]));
-    }
-    f2 acc = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < XP; ++k) {
       const f2 v = *(const f2*)(W + 2 * ax[k]);
@@ -223,6 +265,11 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
       const f2 v = *(const f2*)(W + 2 * ay[k]);
       acc = (k & 1) ? pk_fma_c<true>(cy2[k / 2], v, acc) : pk_fma_c<false>(cy2[k / 2], v, acc);
       if (k % 5 == 4) asm volatile("" ::: "memory");
+    }
+    }
+    if (KEEP) {
+      eh[ps] = o;
+      asm volatile("" : "+v"(eh[ps]));
     }
     if (PF) {  // this chunk's two channels are final
       bs_emb<__half, true>(dB, (acc.x - o.x * proj) * inv_own * dl, ph, hzo + (unsigned)(2 * ps) * hcs);
@@ -269,7 +316,8 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
 // ------------------------------------------------------------------------------------------------------------------
 // forward (self loss with TRAIN, or inference), f16 e; writes the f32 1 / norm plane for the backward.  Epilogue as k_fwd_xdma.
 // ------------------------------------------------------------------------------------------------------------------
-template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN, int WPE>
+// HW: the working buffer stays in f16 (interleave_chunk) and the gather runs on v_dot2_f32_f16
+template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN, int WPE, bool HW = false>
 __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, const XParams C, const __half* __restrict__ e,
                                                              const float* __restrict__ target, const float* __restrict__ weight,
                                                              const uint8_t* __restrict__ mask, float* __restrict__ affs,
@@ -279,11 +327,12 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
   constexpr int KMAX = kXP;
   constexpr int ITEMS = (KMAX * QP + NT - 1) / NT;
   static_assert(TW == 32 && D_T % 2 == 0 && QP % 64 == 0 && PS % 512 == 0, "lane mapping / channel pairs");
-  static_assert(KMAX * TP * 4 + KMAX * NSL * 4 <= 5 * PS, "the parked dot products fit the dead planes");
+  constexpr int WP = HW ? 1 : 2;  // planes' worth of working buffer (HW: 4 bytes per region pixel)
+  static_assert(KMAX * TP * 4 + KMAX * NSL * 4 <= (WP + 3) * PS, "the parked dot products fit the dead planes");
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   char* const W = lds;
-  char* const R = lds + 2 * PS;
+  char* const R = lds + WP * PS;
   float* sA = (float*)lds;                          // [K][TP] dot products, over the dead planes
   float* s_part = (float*)(lds + KMAX * TP * 4);    // [K][NSL]
   int tile, b, z, y0, x0;
@@ -329,11 +378,29 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
   else PEA_HWAIT0()
   if (NP > 2) PEA_HDMA16(2, 4)
 
-  f2 dot[kXP], ssq[kXP], oss = {0.f, 0.f};
+  // HW: scalar accumulators (the two channels of a chunk are summed by v_dot2); else packed over the two channels
+  typedef typename std::conditional<HW, float, f2>::type acc_t;
+  acc_t dot[kXP], ssq[kXP], oss;
+  if constexpr (HW) oss = 0.f; else oss = (f2){0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < kXP; ++k) { dot[k] = (f2){0.f, 0.f}; ssq[k] = (f2){0.f, 0.f}; }
+  for (int k = 0; k < kXP; ++k) {
+    if constexpr (HW) { dot[k] = 0.f; ssq[k] = 0.f; } else { dot[k] = (f2){0.f, 0.f}; ssq[k] = (f2){0.f, 0.f}; }
+  }
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
+    if constexpr (HW) {
+      interleave_chunk<PS, NT>(W, R, ps % 3, C.QA);
+      lds_barrier();
+      const h2_t o = *(const h2_t*)(W + vown);
+      oss = __builtin_amdgcn_fdot2(o, o, oss, false);
+#pragma unroll
+      for (int k = 0; k < kXP; ++k) {
+        const h2_t v = *(const h2_t*)(W + an[k]);
+        dot[k] = __builtin_amdgcn_fdot2(o, v, dot[k], false);
+        ssq[k] = __builtin_amdgcn_fdot2(v, v, ssq[k], false);
+        if (k % 5 == 4) asm volatile("" ::: "memory");
+      }
+    } else {
     convert_chunk<PS, NT>(W, R, ps % 3, C.QA);
     lds_barrier();
     const f2 o = *(const f2*)(W + 2 * vown);
@@ -344,6 +411,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
       dot[k] = __builtin_elementwise_fma(o, v, dot[k]);
       ssq[k] = __builtin_elementwise_fma(v, v, ssq[k]);
       if (k % 5 == 4) asm volatile("" ::: "memory");
+    }
     }
 #pragma unroll
     for (int k = 0; k < kXP; ++k) asm volatile("" : "+v"(dot[k]), "+v"(ssq[k]));
@@ -363,7 +431,8 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
   const int py = y0 + (tid_ >> 5), px = x0 + (tid_ & 31);
   const bool live = py < P.Y && px < P.X;
   const unsigned pe = live ? (unsigned)(py * P.X + px) * 4u : kOOB;
-  const float osum = oss.x + oss.y;
+  float osum;
+  if constexpr (HW) osum = oss; else osum = oss.x + oss.y;
   const float inv_eps = 1.0f / P.eps;
   const float inv_own = rnorm(osum, inv_eps);
   if (inv_out) bs32(iB, osum < P.eps * P.eps ? -inv_own : inv_own, pe, ezo);
@@ -371,7 +440,9 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
 #pragma unroll
   for (int k = 0; k < kXP; ++k) {
     if (k < C.nf) {
-      float a = (dot[k].x + dot[k].y) * inv_own * rnorm(ssq[k].x + ssq[k].y, inv_eps);
+      float dk, sk;
+      if constexpr (HW) { dk = dot[k]; sk = ssq[k]; } else { dk = dot[k].x + dot[k].y; sk = ssq[k].x + ssq[k].y; }
+      float a = dk * inv_own * rnorm(sk, inv_eps);
       if (CROP) {
         const int q = (C.fax[k] ? px : py) + C.fd[k];
         a = (unsigned)q < (unsigned)(C.fax[k] ? P.X : P.Y) ? a : 0.f;
