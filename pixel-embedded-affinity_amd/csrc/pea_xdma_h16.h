@@ -229,10 +229,14 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
   for (int ps = 0; ps < NP; ++ps) {
     f2 o, acc = {0.f, 0.f};
     if constexpr (HW) {
+      // (PEA_ABL_H_*: diagnostic builds of profiles/microbench/abl_bwd_h16.hip only -- timing with a phase compiled out)
+#ifndef PEA_ABL_H_NOILV
       interleave_chunk<PS, NT>(W, R, ps % 3, C.QA);
       lds_barrier();  // the working buffer holds chunk ps
+#endif
       const h2_t oh = *(const h2_t*)(W + vown);
       o = (f2){(float)oh.x, (float)oh.y} * inv_own;
+#ifndef PEA_ABL_H_NOGATHER
 #pragma unroll
       for (int k = 0; k < XP; ++k) {
         const h2_t v = *(const h2_t*)(W + ax[k]);
@@ -249,6 +253,9 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
         acc.y = __builtin_fmaf((float)v.y, c, acc.y);
         if (k % 5 == 4) asm volatile("" ::: "memory");
       }
+#else
+      acc = (f2){cx2[ps % (XP / 2)].x, cy2[ps % (XP / 2)].y};
+#endif
     } else {
     convert_chunk<PS, NT>(W, R, ps % 3, C.QA);
     lds_barrier();  // the working buffer holds chunk ps
@@ -272,8 +279,13 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
       asm volatile("" : "+v"(eh[ps]));
     }
     if (PF) {  // this chunk's two channels are final
-      bs_emb<__half, true>(dB, (acc.x - o.x * proj) * inv_own * dl, ph, hzo + (unsigned)(2 * ps) * hcs);
-      bs_emb<__half, true>(dB, (acc.y - o.y * proj) * inv_own * dl, ph, hzo + (unsigned)(2 * ps + 1) * hcs);
+#ifdef PEA_ABL_H_NOSTORE
+      if (acc.x == 12345.f)
+#endif
+      {
+        bs_emb<__half, true>(dB, (acc.x - o.x * proj) * inv_own * dl, ph, hzo + (unsigned)(2 * ps) * hcs);
+        bs_emb<__half, true>(dB, (acc.y - o.y * proj) * inv_own * dl, ph, hzo + (unsigned)(2 * ps + 1) * hcs);
+      }
     } else {
       if (!KEEP) {
         proj = fmaf(o.x, acc.x, fmaf(o.y, acc.y, proj));
@@ -286,8 +298,14 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
       // everyone is done with the working buffer and with ring buffer ps % 3; chunk ps + 1 has landed (chunk ps + 2 and, PF, the
       // stores of the last two chunks may still fly: vmcnt retires in order, pea_xdma_pf.h)
       const int nd = ps + 2 < NP ? 1 : 0, ns = PF ? 2 * (ps + 1 < 2 ? ps + 1 : 2) : 0;
+#ifdef PEA_ABL_H_NOSTORE
+      pf_wait(nd * npc);
+#else
       pf_wait(nd * npc + ns);
+#endif
+#ifndef PEA_ABL_H_NODMA
       if (ps + 3 < NP) PEA_HDMA16(ps % 3, 2 * ps + 6)
+#endif
     }
   }
 #undef PEA_HDMA16
