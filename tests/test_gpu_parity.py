@@ -1062,6 +1062,44 @@ def test_chunked_d64_forward_vs_oracle(pkg, dev, orc, synth, monkeypatch, case):
     assert np.abs(got[1] - ref[1]).max() < 2e-6 and abs(got[0] - ref[0]) <= 2e-6 * abs(ref[0])
 
 
+@pytest.mark.parametrize("D,shape,border", [(64, (72, 104), "circular"), (32, (50, 72), "crop"), (16, (37, 64), "circular")])
+def test_f16_cross_kernels_both_working_buffers(pkg, dev, orc, synth, monkeypatch, D, shape, border):
+    """f16 storage on the LDS-DMA cross kernels (csrc/pea_xdma_h16.h): the half-precision working buffer (forward on v_dot2_f32_f16,
+    backward on v_fma_mix_f32: the default) and the f32 one (PEA_H16_HW=0), each against the C oracle on the rounded inputs, and
+    against each other; training forward, projection-first backward (D >= 32) and inference"""
+    H, W = shape
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)[:8]
+    B = 2
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 90 + D)
+    e = e.astype(np.float16).astype(np.float32)
+    op = pkg.affinity_op
+    bd = pkg._lib.BORDER_CIRCULAR if border == "circular" else pkg._lib.BORDER_CROP_ZERO
+    spec = op.AffinitySpec(2, offsets, None, bd, pkg._lib.NORM_BX)
+
+    def run():
+        et = cu(e, dev).half().requires_grad_(True)
+        d_hip = op.make_desc(spec, et)
+        assert pkg._lib.lib().pea_cross_supported(ctypes.byref(d_hip), 0) == 1
+        loss, affs, _ = op.FusedAffinityMSE.apply(et, None, cu(t, dev), cu(w, dev), cu(m, dev), spec)
+        (loss * 0.75).backward()
+        inf = op.affinity_infer(et.detach(), None, spec)
+        return loss.item(), affs.cpu().numpy(), inf.cpu().numpy(), et.grad.float().cpu().numpy()
+
+    d = orc.make_desc(B, D, [1, H, W], offsets, None, bd, pkg._lib.NORM_BX, ndim=2)
+    o_affs, o_loss = orc.c_fwd(d, e, None, t, w, m)
+    o_grad, _ = orc.c_bwd(d, e, None, t, w, m, dloss=0.75)
+    res = {}
+    for hw in ("1", "0"):
+        monkeypatch.setenv("PEA_H16_HW", hw)
+        got = res[hw] = run()
+        assert np.abs(got[1].reshape(o_affs.shape) - o_affs).max() < AFFS_ATOL, hw
+        assert np.abs(got[2].reshape(o_affs.shape) - o_affs).max() < AFFS_ATOL, hw
+        assert abs(got[0] - o_loss[0]) <= LOSS_RTOL * o_loss[0], hw
+        assert relmax(got[3].reshape(o_grad.shape), o_grad) < 2e-3, hw  # the gradient is stored in half precision
+    assert np.abs(res["1"][1] - res["0"][1]).max() < 2e-6
+    assert relmax(res["1"][3], res["0"][3]) < 2e-3
+
+
 def test_plain_c_consumer_of_the_abi(tmp_path):
     """examples/abi_demo.c: the library driven from plain C (gcc, HIP runtime for memory, no Python / torch in the process)
     against a scalar double-precision restatement of the reference's op sequence written out in the program"""
