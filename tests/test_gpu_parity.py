@@ -1100,6 +1100,28 @@ def test_f16_cross_kernels_both_working_buffers(pkg, dev, orc, synth, monkeypatc
     assert relmax(res["1"][3], res["0"][3]) < 2e-3
 
 
+@pytest.mark.parametrize("scale", [1e-3, 3e-5, 1e-6])
+def test_f16_denormal_embeddings(pkg, dev, orc, synth, scale):
+    """f16 storage with embeddings so small that most or all halves are DENORMAL numbers: the cosine does not depend on the scale,
+    and the v_dot2_f32_f16 forward must not flush them (it does not: measured 2e-7 against the oracle at every scale)"""
+    op = pkg.affinity_op
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)[:8]
+    B, D, H, W = 1, 64, 48, 72
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 5)
+    e16 = (e * scale).astype(np.float16)
+    ef = e16.astype(np.float32)
+    assert ((np.abs(ef) < 6.1e-5) & (ef != 0)).sum() > (0.04 if scale > 1e-4 else 0.9) * ef.size
+    spec = op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX)
+    d = orc.make_desc(B, D, [1, H, W], offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX, ndim=2)
+    o_affs, o_loss = orc.c_fwd(d, ef, None, t, w, m)
+    et = torch.from_numpy(e16).to(dev).requires_grad_(True)
+    loss, affs, _ = op.FusedAffinityMSE.apply(et, None, cu(t, dev), cu(w, dev), cu(m, dev), spec)
+    assert np.abs(affs.cpu().numpy().reshape(o_affs.shape) - o_affs).max() < AFFS_ATOL
+    assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+    inf = op.affinity_infer(et.detach(), None, spec)
+    assert np.abs(inf.cpu().numpy().reshape(o_affs.shape) - o_affs).max() < AFFS_ATOL
+
+
 def test_plain_c_consumer_of_the_abi(tmp_path):
     """examples/abi_demo.c: the library driven from plain C (gcc, HIP runtime for memory, no Python / torch in the process)
     against a scalar double-precision restatement of the reference's op sequence written out in the program"""
