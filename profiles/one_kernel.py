@@ -49,6 +49,13 @@ fns = {
     "bwd": lambda: L.pea_affinity_bwd(ctypes.byref(desc), P(E), None, P(G), P(one), P(dE), None, st),
     "inf": lambda: L.pea_affinity_infer(ctypes.byref(desc), P(E), None, P(affs), st),
 }
+INV = torch.empty(B, H, W, device=dev)
+LSB = L.pea_labels_scratch_bytes(ctypes.byref(desc))
+LSCR = torch.empty(max(LSB, 4) // 4, device=dev)
+# the two-launch labels step (labels-in forward on the cross kernels + cross backward) and the forward / backward pair with the plane
+fns["labels2"] = lambda: L.pea_affinity_fwd_bwd_labels_ex(ctypes.byref(desc), P(E), None, P(LAB), P(WTAB), 5, P(affs), P(lossv), None, P(dE),
+                                                           P(work), wsb, P(LSCR), LSB, st)
+fns["fwd_ex"] = lambda: L.pea_affinity_fwd_ex(ctypes.byref(desc), P(E), None, P(T), P(Wt), P(M), P(affs), P(G), P(INV), P(lossv), P(work), wsb, st)
 if which == "bwd":
     fns["fwd"]()
 for _ in range(iters):
