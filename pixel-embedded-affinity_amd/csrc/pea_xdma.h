@@ -628,12 +628,11 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
   static_assert(TW == 32 && D_T % 2 == 0 && QP % 64 == 0, "lane mapping / channel pairs");
   constexpr int NW = NT / 64;
   static_assert(KMAX * TP * 4 + KMAX * NSL * 4 <= 6 * PS && KMAX <= kXK, "the parked dot products fit the ring");
-  static_assert(!LAB || 2 * KMAX * TP * 4 + KMAX * NW * 4 <= 6 * PS, "labels-in: a and g parked side by side");
+
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   float* sA = (float*)lds;                          // [K][TP] dot products, laid over the ring once it is dead
-  float* sG = (float*)(lds + KMAX * TP * 4);        // LAB: [K][TP] d loss / d affs beside them
-  float* s_part = (float*)(lds + (LAB ? 2 : 1) * KMAX * TP * 4);  // [K][NSL]  (LAB: [K][NW])
+  float* s_part = (float*)(lds + KMAX * TP * 4);    // [K][NSL]
   int tile, b, z, y0, x0;
   if (!xdma_tile<TH, TW>(C, P, tile, b, z, y0, x0)) return;
   const size_t S = (size_t)P.S;
@@ -859,41 +858,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
     bs32(mkbuf(inv_other_out + (size_t)b * S), csum < P.eps * P.eps ? -inv_c : inv_c, pe, ezo);
   }
   lds_barrier();  // every lane is done with the ring: sA goes over it
-  if constexpr (LAB) {
-    // target, mask, weight of every pair from two labels (pea_fused_labels.h PEA_LAB_PAIR: the same rules, the same order of
-    // operations); the neighbour's label is UNWRAPPED: a neighbour outside the image has none (inside = false)
-    const bool pad = LA.lflags & PEA_TGT_PADDING, fg = LA.lflags & PEA_TGT_BOTH_FOREGROUND, msk = LA.lflags & PEA_TGT_MASK_INSIDE;
-    const float* wt_b = LA.wtab + 2 * (size_t)b * P.K;
-    const int lown = *(const int*)(lds + 6 * PS + vown);
-    // the pixel's coordinates, derived again from an opaque copy of the lane id: kept from the top of the kernel they would be
-    // two more registers alive across the channel loop, and the 80-VGPR budget has none to spare (a spill otherwise)
-    int tid_ = (int)threadIdx.x;
-    asm volatile("" : "+v"(tid_));
-    const int py = y0 + (tid_ >> 5), px = x0 + (tid_ & 31);
-    const bool live = py < P.Y && px < P.X;
-#pragma unroll
-    for (int k = 0; k < kXP; ++k) {
-      if (k < C.nf) {  // uniform
-        const int ch = C.fi[k];
-        const int q = (C.fax[k] ? px : py) + C.fd[k];
-        const bool inside = (unsigned)q < (unsigned)(C.fax[k] ? P.X : P.Y);
-        const int lnb = *(const int*)(lds + 6 * PS + an[k]);
-        const bool eq = lown == lnb && (!fg || (lown > 0 && lnb > 0));
-        const float t = (inside ? eq : pad) ? 1.f : 0.f;
-        const float m = (msk && !inside) ? 0.f : 1.f;
-        const float w = t != 0.f ? wt_b[2 * ch] : wt_b[2 * ch + 1];
-        const bool exists = live && (!CROP || inside);
-        const float a = exists ? (dot[k].x + dot[k].y) * inv_own * rnorm(ssq[k].x + ssq[k].y, inv_eps) : 0.f;
-        const float rr = a * m - t * m;
-        const float wr = exists ? w * rr : 0.f;
-        sA[ch * TP + (int)threadIdx.x] = act_affs(a, af);
-        sG[ch * TP + (int)threadIdx.x] = C.gs[ch] * wr * m;
-        const float red = wave_sum63(wr * rr);
-        if (lane == 63) s_part[ch * NW + wave] = red;
-        asm volatile("" ::: "memory");  // one pair at a time (80 VGPRs: the scheduler otherwise hoists every label read)
-      }
-    }
-  } else {
+  {
 #pragma unroll
   for (int k = 0; k < kXP; ++k) {
     if (k < C.nf) {  // uniform
@@ -927,9 +892,54 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
     const int sl = isl[it];
     const f4 a4 = *(const f4*)(sA + sl * TP + iqd[it] * 4);
     const unsigned so = ezo + (unsigned)sl * ecs;
-    if constexpr (LAB) {  // everything was evaluated per pixel: two row stores
-      if (has_a) bs128<true>(aB, a4, ivo[it], so);
-      if (has_g) bs128<false>(gB, *(const f4*)(sG + sl * TP + iqd[it] * 4), ivo[it], so);
+    if constexpr (LAB) {
+      // target, mask, weight of the quad's four pairs from their labels (pea_fused_labels.h PEA_LAB_PAIR: the same rules, the same
+      // order of operations) -- here in the store walk, per quad like the tensor path's epilogue, not per pixel after the channel
+      // loop (that form spent 47 % more vector-ALU instructions than the tensor forward and parked g beside a).  The neighbour's
+      // label is UNWRAPPED: a neighbour outside the image has none (inside = false).
+      const bool pad = LA.lflags & PEA_TGT_PADDING, fg = LA.lflags & PEA_TGT_BOTH_FOREGROUND, msk = LA.lflags & PEA_TGT_MASK_INSIDE;
+      const float* wt_b = LA.wtab + 2 * (size_t)b * P.K;
+      const float w1 = wt_b[2 * sl], w0 = wt_b[2 * sl + 1], gs = C.gs[sl];
+      const int ax_ = C.oax[sl], od_ = C.od[sl];
+      const int l4 = iqd[it] * 4, qr = l4 / TW, qc = l4 % TW;
+      const char* const lp = lds + 6 * PS;
+      const int rown = ((C.hy0 + qr) * TW) * 4;
+      typedef int i4 __attribute__((ext_vector_type(4)));
+      const i4 lo = *(const i4*)(lp + rown + qc * 4);
+      i4 ln;
+      if (ax_ == 1) {  // uniform: along x, element by element (inside the tile row or in its strip)
+        const int hr = (C.QV * 4 + qr * C.SW) * 4, fm = od_ < 0 ? C.SW - 1 : 31;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cc = qc + j + od_;
+          ln[j] = *(const int*)(lp + ((unsigned)cc < (unsigned)TW ? rown + cc * 4 : hr + (cc & fm) * 4));
+        }
+      } else {
+        ln = *(const i4*)(lp + rown + od_ * TW * 4 + qc * 4);
+      }
+      const bool lv = ivo[it] != kOOB;
+      float acc = 0.f;
+      f4 g4, o4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = (ax_ == 1 ? igx[it] + j : igy[it]) + od_;
+        const bool inside = (unsigned)q < (unsigned)(ax_ == 1 ? P.X : P.Y);
+        const bool eq = lo[j] == ln[j] && (!fg || (lo[j] > 0 && ln[j] > 0));
+        const float t = (inside ? eq : pad) ? 1.f : 0.f;
+        const float m = (msk && !inside) ? 0.f : 1.f;
+        const float w = t != 0.f ? w1 : w0;
+        const bool exists = lv && (!CROP || inside);
+        const float a = exists ? a4[j] : 0.f;
+        const float rr = a * m - t * m;
+        const float wr = exists ? w * rr : 0.f;
+        o4[j] = act_affs(a, af);
+        g4[j] = gs * wr * m;
+        acc = fmaf(wr, rr, acc);
+      }
+      if (has_a) bs128<true>(aB, o4, ivo[it], so);
+      if (has_g) bs128<false>(gB, g4, ivo[it], so);
+      const float red = wave_sum63(acc);
+      if ((threadIdx.x & 63) == 63) s_part[sl * NSL + (iqd[it] >> 6)] = red;
       continue;
     }
     if (has_a) {
@@ -965,7 +975,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
       if ((int)threadIdx.x < P.K) {
         float v = 0.f;
 #pragma unroll
-        for (int s = 0; s < (LAB ? NW : NSL); ++s) v += s_part[threadIdx.x * (LAB ? NW : NSL) + s];
+        for (int s = 0; s < NSL; ++s) v += s_part[threadIdx.x * NSL + s];
         loss_accumulate(st, tile, threadIdx.x, v);
       }
     }
