@@ -27,7 +27,7 @@ struct Env {
   int infer_xdma;     // PEA_INFER_XDMA=0: inference (affs only) on k_fwd_tiled / the chunked kernels instead of the LDS-DMA forward
   int bwd_pf;         // PEA_BWD_PF=0: never the projection-first backward (pea_xdma_pf.h); 2: also at D = 16 (where it loses)
   int fwd_wg3;        // PEA_FWD_WG3=0: the 2-workgroups-per-CU forward
-  int h16_hw;         // PEA_H16_HW=0: the f16 forward with the f32 working buffer (packed-f32 gather) instead of the f16 one (v_dot2)
+  int h16_hw;         // PEA_H16_HW=0: the f16 kernels with the f32 working buffer (packed-f32 gather) instead of the f16 one (v_dot2 / v_fma_mix)
   int box;            // PEA_BOX=0: unit-box stencils (the 26-neighbourhood) on the tiled kernels instead of pea_box.h
   int zblk_y, zblk_x; // PEA_ZBLK_Y / PEA_ZBLK_X: tiles per block of the z-fastest walk of 3D volumes (0: the default 4 x 2; Y < 0: plane-major)
 };

@@ -12,6 +12,11 @@
 //     ds_read_b64 per pair (256 B/clk) instead of the planar ds_read2st64_b32 (128 B/clk).
 // Two barriers per chunk instead of one (converted / consumed); the second workgroup of the CU fills them.  LDS: backward
 // 2 x 13 KB + 6 x 6.5 KB = 64 KB (two workgroups per CU), forward 2 x 7.5 KB + 6 x 3.75 KB = 37.5 KB (three).
+// HW (the default since the end of round 3, PEA_H16_HW=0 switches back): the working buffer itself stays in f16 -- [pixel][2 channels]
+// halves written by an interleave step without any conversion.  The forward's per-pair work over the chunk's two channels
+// (dot += <own, v>, ssq += <v, v>) is then v_dot2_f32_f16: scalar accumulators, 48 VGPRs, 30 KB, four workgroups per CU, 193 -> 167 us
+// at B=8 x 64 x 544^2; the backward takes the halves with v_fma_mix_f32 (305 -> 300 us).  Products of two halves are exact in f32 and
+// the accumulation is f32 either way; f16 denormals are not flushed (tests/test_gpu_parity.py::test_f16_denormal_embeddings).
 // Self loss / inference, 2D, X % 8 == 0 (an 8-pixel DMA item never straddles a row end), axis-aligned stencils, D in {16, 32, 64}.
 #pragma once
 #include <type_traits>
