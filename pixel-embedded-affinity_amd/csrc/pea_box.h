@@ -16,7 +16,8 @@
 //   backward: the neighbour at displacement d carries the coefficient g_{o = d}(p) + g_{o = -d}(p + d) (role A of the offset d and
 //             role B of the offset -d), times 1 / |e(p + d)| from the staged 1 / norm plane of the forward: 26 coefficients, two to
 //             a register pair (pk_fma_c), G(p) = sum_d c_d e(p + d) per channel pair, d e = (G - ehat <ehat, G>) / |e|.
-// LDS: 3 x 17 KB ring + 9 KB 1 / norm region (+ the parked dot products over the ring) = 63 KB: two workgroups per CU.
+// LDS: forward 3 x 17 KB ring, the parked dot products over it, 9 KB of region norms = 63 KB (two workgroups per CU); backward the
+// ring alone, 52 KB (three workgroups per CU at 72 VGPRs: the staged 1 / norm region starts out in the third chunk buffer).
 // f32 storage, D = 16, X % 4 == 0, 16-byte aligned planes; CIRCULAR and CROP_ZERO borders.
 #pragma once
 #include "pea_xdma.h"
