@@ -506,17 +506,32 @@ class LabelsAffinityMSE(torch.autograd.Function):
                                             "stencil too wide): use gen_targets + the tensor API")
             _lib.check(rc, "pea_affinity_fwd_bwd_labels")
         ctx.de_unit, ctx.desc = de_unit, d
+        ctx.again = (e_c, o_c, lab, wtab, flags)  # for a second backward over a retained graph (references only: nothing is copied)
         loss, per_offset = loss_vec[0], loss_vec[1:]
         ctx.mark_non_differentiable(affs, per_offset)
         return loss, affs, per_offset
 
     @staticmethod
+    def _unit_gradient_again(ctx):
+        """the gradient for grad_output = 1 once more (the first backward handed its buffer over, scaled in place): the step is run
+        again on the saved inputs -- a retained graph is the rare case, and keeping a pristine copy would cost every step 150 MB"""
+        e_c, o_c, lab, wtab, flags = ctx.again
+        d, L = ctx.desc, _lib.lib()
+        with _on_device(e_c.device):
+            loss_vec = torch.empty(1 + d.K, dtype=torch.float32, device=e_c.device)
+            work, wsb = workspace(e_c.device, d)
+            de_unit = torch.empty_like(e_c)
+            _lib.check(L.pea_affinity_fwd_bwd_labels_ex(ctypes.byref(d), _ptr(e_c), _ptr(o_c), _ptr(lab), _ptr(wtab), flags, None,
+                                                        _ptr(loss_vec), None, _ptr(de_unit), _ptr(work), wsb, None, 0, _stream()),
+                       "pea_affinity_fwd_bwd_labels")
+        return de_unit
+
+    @staticmethod
     def backward(ctx, dloss, _daffs, _dvec):
         if not ctx.needs_input_grad[0] or dloss is None:
             return None, None, None, None, None, None
-        if ctx.de_unit is None:
-            raise RuntimeError("the labels-in step hands its gradient buffer to the first backward; for a second backward "
-                               "over a retained graph use gen_targets + embedding_loss")
+        if ctx.de_unit is None:  # a second backward over a retained graph
+            ctx.de_unit = LabelsAffinityMSE._unit_gradient_again(ctx)
         de, ctx.de_unit = ctx.de_unit, None
         with _on_device(de.device):
             dl = dloss.to(device=de.device, dtype=torch.float32).contiguous()

@@ -510,6 +510,25 @@ def test_second_backward_over_retained_graph(pkg, dev, synth):
     assert relmax(g2.cpu().numpy(), 2.0 * g1.cpu().numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("shape", [(64, 128), (544, 544)])
+def test_labels_step_second_backward_over_retained_graph(pkg, dev, synth, shape):
+    """the labels-in step hands its gradient buffer to the first backward (scaled in place); a second backward over a retained graph
+    runs the step again on the saved inputs: twice the grad_output, twice the gradient, and the first result is left alone
+    (one-launch kernel on the small shape, the two-launch cross path on the large one)"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    H, W = shape
+    B = 1 if H > 100 else 2
+    e = synth.synth_embedding((B, 16, H, W), 48)
+    lab = torch.from_numpy(synth.synth_labels(B, (1, H, W), 49)[:, 0].copy()).to(dev)
+    et = cu(e, dev).requires_grad_(True)
+    loss, affs, _ = pkg.embedding_loss_from_labels(et, lab, pkg.WeightedMSE(), offsets)
+    (g1,) = torch.autograd.grad(loss * 0.5, et, retain_graph=True)
+    keep = g1.clone()
+    (g2,) = torch.autograd.grad(loss, et)
+    assert torch.equal(g1, keep)
+    assert relmax(g2.cpu().numpy(), 2.0 * keep.cpu().numpy()) < 1e-6
+
+
 @pytest.mark.parametrize("ema", [False, True])
 def test_tiled_d32_vs_oracle(pkg, dev, orc, synth, ema):
     """D = 32 (BBBC039V1 backbone) through the LDS-tiled kernels: 16x32 tiles, 128 B of LDS per
