@@ -152,10 +152,21 @@ class _TensorSection(torch.autograd.Function):
             losses = rows[:, 0]
             total = (losses * wdev).sum()
         ctx.grads, ctx.n_embs = grads, len(embs)
+        ctx.again = (_TensorSection, (specs, weights, ema_embedding, tensors) + tuple(embs))  # references only (a second backward)
         ctx.mark_non_differentiable(pred, losses)
         return total, pred, losses
 
     backward = staticmethod(lambda ctx, dtotal, _dp, _dl: _section_backward(ctx, dtotal))
+
+
+class _Rerun(object):
+    """stands in for the autograd context when a section is computed again for a second backward over a retained graph"""
+
+    def set_materialize_grads(self, value):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
 
 
 def _section_backward(ctx, dtotal):
@@ -163,8 +174,12 @@ def _section_backward(ctx, dtotal):
     if dtotal is None:
         return (None, None, None, None) + (None,) * n
     if ctx.grads is None:
-        raise RuntimeError("the loss section hands its gradient buffers to the first backward; for a second backward over a "
-                           "retained graph use cvppp_loss_section_composed (one autograd node per loss)")
+        # the first backward took the gradient buffers (scaled in place): a second backward over a retained graph computes the
+        # section again on the saved inputs -- the rare case pays, not every step
+        cls, args = ctx.again
+        stub = _Rerun()
+        cls.forward(stub, *args)
+        ctx.grads = stub.grads
     grads, ctx.grads = ctx.grads, None
     L = _lib.lib()
     dev = grads[0].device
@@ -487,6 +502,7 @@ class _LabelsSection(torch.autograd.Function):
             losses = rows[:, 0]
             total = (losses * wdev).sum()
         ctx.grads, ctx.n_embs = grads, len(embs)
+        ctx.again = (_LabelsSection, (specs, weights, ema_embedding, label_cfg) + tuple(embs))
         ctx.mark_non_differentiable(pred, losses)
         return total, pred, losses
 

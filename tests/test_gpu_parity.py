@@ -870,6 +870,32 @@ def test_loss_section_node_equals_composed(pkg, dev, synth):
     np.testing.assert_allclose(res[1][4], res[0][4], rtol=1e-5)
 
 
+def test_loss_section_second_backward_over_retained_graph(pkg, dev, synth):
+    """the one-node sections (tensor path and labels-in) hand their gradient buffers to the first backward; a second backward over
+    a retained graph computes the section again: twice the grad_output, twice every gradient, the first results untouched"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    nb_half, B, D, H, W = 2, 2, 16, 96, 96
+    e, ema, t, w, m, emds, downs = _section_inputs(synth, offsets, nb_half, B, D, H, W, 137)
+    crit = pkg.WeightedMSE()
+    lab = synth.synth_labels(B, (1, H, W), 138)[:, 0]
+    labs = [torch.from_numpy(np.ascontiguousarray(lab[:, ::2 ** j, ::2 ** j])).to(dev) for j in range(5)]
+    for which in ("tensor", "labels"):
+        et = cu(e, dev).requires_grad_(True)
+        emd_t = [cu(x, dev).requires_grad_(True) for x in emds]
+        if which == "tensor":
+            loss, _, _ = pkg.cvppp_loss_section(et, emd_t, cu(ema, dev), cu(t, dev), cu(w, dev), cu(m, dev), [cu(x, dev) for x in downs],
+                                                crit, offsets, nb_half)
+        else:
+            loss, _, _ = pkg.cvppp_loss_section_from_labels(et, emd_t, cu(ema, dev), labs[0], labs[1:], crit, offsets, nb_half)
+        leaves = [et] + emd_t
+        g1 = torch.autograd.grad(loss * 0.5, leaves, retain_graph=True)
+        keep = [g.clone() for g in g1]
+        g2 = torch.autograd.grad(loss, leaves)
+        for a, k, b in zip(g1, keep, g2):
+            assert torch.equal(a, k), which
+            assert relmax(b.cpu().numpy(), 2.0 * k.cpu().numpy()) < 1e-6, which
+
+
 def test_3d_loss_section_variants_agree(pkg, dev, orc, synth):
     """scripts_ac3ac4/main.py:219-231 (norm5 self + EMA cross + four norm1 heads): call-by-call composition, one autograd
     node on the tensor path, and the labels-in section must agree"""
