@@ -57,7 +57,20 @@ def sources():
 
 
 def build(force=False, verbose=False, jobs=None):
-    """Compile csrc/*.hip -> csrc/libpea_hip.so for gfx950: one object per file, compiled in parallel, one link."""
+    """Compile csrc/*.hip -> csrc/libpea_hip.so for gfx950: one object per file, compiled in parallel, one link.
+    Serialised across processes by a lock file: the ranks of a multi-GPU job all import the package at once, and if the library
+    is stale each of them would otherwise write the same object files."""
+    import fcntl
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(os.path.join(OBJ_DIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose, jobs)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose, jobs):
     srcs = sources()
     hdrs = [HEADER] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     newest_hdr = max(os.path.getmtime(h) for h in hdrs)
