@@ -236,6 +236,12 @@ int pea_affinity_bwd_ex2(const PeaDesc* desc, const void* e, const void* e_other
   if (!e_other) {
     if (accumulate) return PEA_E_UNSUPPORTED;  // de += is implemented for the detached second operand's role-A backward only
     // self loss: the LDS-DMA cross kernel when the 1 / norm plane came along and the stencil is axis-aligned
+    // a 3D stencil inside the unit box with a step along z (norm1): the box backward serves the z neighbours from LDS where the
+    // cross backward gathers them from global memory -- 1.34 against 1.91 ms on a 24 x 1024^2 sub-volume (profiles/exp_3d_norm1.py;
+    // the forward stays on the cross kernels: 1.25 against 1.54 ms, the box forward walks all 26 displacements whatever K is)
+    bool zstep = false;
+    for (int i = 0; i < P.K; ++i) zstep |= P.off[i][0] != 0;
+    if (dt == PEA_F32 && zstep && box_bwd(P, (const float*)e, inv_norm, g, dloss, (float*)de, s)) return hip_rc();
     if (dt == PEA_F32 && xdma_bwd_self(P, (const float*)e, inv_norm, g, affs, dloss, (float*)de, s)) return hip_rc();
     if (dt == PEA_F16 && xdma_bwd_self_h(P, e, inv_norm, g, affs, dloss, de, s)) return hip_rc();
     if (dt == PEA_F32 && box_bwd(P, (const float*)e, inv_norm, g, dloss, (float*)de, s)) return hip_rc();
