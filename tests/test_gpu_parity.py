@@ -354,6 +354,31 @@ def test_unit_box_stencils_vs_oracle(pkg, dev, orc, synth, monkeypatch, case):
     assert relmax(et2.grad.cpu().numpy(), et.grad.cpu().numpy()) < GRAD_RTOL
 
 
+def test_norm1_cross_forward_with_box_backward(pkg, dev, orc, synth, monkeypatch):
+    """the reference's norm1 table (one step along z, y, x) is axis-aligned AND inside the unit box: its forward runs on the 3D cross
+    kernel, its backward on the unit-box kernel (the 1 / norm plane of the one feeds the other); against the C oracle, and against
+    the cross backward (PEA_BOX=0)"""
+    op = pkg.affinity_op
+    offs = [[-1, 0, 0], [0, -1, 0], [0, 0, -1]]
+    B, D, Z, Y, X = 2, 16, 6, 40, 72
+    e, t, w = synth.synth_inputs_3d(B, D, Z, Y, X, offs, 61)
+    spec = op.AffinitySpec(3, offs, [2.0, 1.0, 1.0], pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
+    d = orc.make_desc(B, D, [Z, Y, X], offs, [2.0, 1.0, 1.0], orc.BORDER_CROP_ZERO, orc.NORM_CROPPED)
+    o_affs, o_loss = orc.c_fwd(d, e, None, t, w, None)
+    o_grad, _ = orc.c_bwd(d, e, None, t, w, None, dloss=1.25)
+    grads = []
+    for box in ("1", "0"):
+        monkeypatch.setenv("PEA_BOX", box)
+        et = cu(e, dev).requires_grad_(True)
+        loss, affs, parts = op.FusedAffinityMSE.apply(et, None, cu(t, dev), cu(w, dev), None, spec)
+        (loss * 1.25).backward()
+        assert np.abs(affs.cpu().numpy() - o_affs).max() < AFFS_ATOL
+        np.testing.assert_allclose(parts.cpu().numpy(), o_loss[1:], rtol=LOSS_RTOL)
+        assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL, box
+        grads.append(et.grad.cpu().numpy())
+    assert relmax(grads[0], grads[1]) < 1e-5
+
+
 def test_random_unit_box_stencils_vs_oracle(pkg, dev, orc, synth):
     """seeded sweep over the unit-box kernels' domain: random subsets of the 26 displacements (both signs, duplicates excluded),
     ragged Z / Y and X % 4 == 0 widths (partial tiles, one-tile images), both borders, all three normalisers, batch, mask"""
