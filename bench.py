@@ -35,6 +35,10 @@ B_PER_GPU, D, H, W = 8, 16, 544, 544
 # --config: the headline workload (c2 = BASELINE.json configs[1], the default and the only one the driver runs) and the other
 # single-GPU shapes of BASELINE.json / SURVEY.md section 8d, each through the same step / roofline / cpu_baseline code
 CONFIGS = {
+    "c1": dict(what="BASELINE configs[0]: CVPPP A1 single image, embedding_loss fwd+bwd, the shipped K=10 stencil", ndim=2, B=1, D=16, dims=(544, 544),
+               shifts=[1, 3, 5, 9, 27], K=10, f16=False),
+    "c1k8": dict(what="BASELINE configs[0]: CVPPP A1 single image, embedding_loss fwd+bwd, 8 affinity offsets (offsets[:8])", ndim=2, B=1, D=16,
+                 dims=(544, 544), shifts=[1, 3, 5, 9, 27], K=8, f16=False),
     "c2": dict(what="BASELINE configs[1]: CVPPP A1 embedding_loss fwd+bwd", ndim=2, B=8, D=16, dims=(544, 544), shifts=[1, 3, 5, 9, 27], K=10, f16=False),
     "c3": dict(what="BASELINE configs[2]: BBBC039V1 embedding_loss fwd+bwd (per-GPU share of B=32 over 4 GPUs)", ndim=2, B=8, D=32, dims=(704, 704),
                shifts=[1, 3, 5, 9, 11], K=10, f16=False),
@@ -147,6 +151,7 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
         loss, affs, _ = op.FusedAffinityMSE.apply(E, None, T, Wt, M, spec)
         pkg.backward(loss)  # loss.backward() seeded with a cached ones-scalar (no per-step fill kernel)
 
+    settle = settle_gpu(step)
     for _ in range(max(args.warmup, 3)):
         step()
     fence()
@@ -159,6 +164,14 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    # the same step started with plain loss.backward() -- what a drop-in caller of INTEGRATION.md section 2 executes (autograd seeds
+    # the scalar's backward with a ones_like fill kernel); untimed for `value`, reported beside it
+    def step_seed():
+        E.grad = None
+        loss, affs, _ = op.FusedAffinityMSE.apply(E, None, T, Wt, M, spec)
+        loss.backward()
+
+    dt_seed = wall_time_s(step_seed, fence, args.steps)
     npx = B * int(np.prod(dims))
     value = world * npx * args.steps / dt / 1e6
     if rank != 0:
@@ -173,9 +186,9 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
     work = torch.empty(max(wsb, 4) // 4, device=dev)
     assert L.pea_workspace_init(ctypes.c_void_p(work.data_ptr()), wsb, None) == 0  # the loss-state block: prepared once
     P = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    fwd = lambda: L.pea_affinity_fwd_ex(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(affs), P(G), P(INV), P(lossv), P(work), wsb, st)
-    bwd = lambda: L.pea_affinity_bwd_ex2(ctypes.byref(desc), P(Ed), None, P(G), P(INV), P(affs), P(one), P(dE), None, st)
+    cur = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # (read per call: the graph capture runs on its own stream)
+    fwd = lambda: L.pea_affinity_fwd_ex(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(affs), P(G), P(INV), P(lossv), P(work), wsb, cur())
+    bwd = lambda: L.pea_affinity_bwd_ex2(ctypes.byref(desc), P(Ed), None, P(G), P(INV), P(affs), P(one), P(dE), None, cur())
     in_step_times_ms(fwd, bwd, 3)
     kf, kb = in_step_times_ms(fwd, bwd, max(10, min(args.steps, 50)))
     ab = algorithmic_bytes_per_px(Dm, K, 2 if c["f16"] else 4, mask=M is not None)
@@ -189,7 +202,11 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
         "data": "synthetic",
         "config": {"workload": "%s: B=%d per GPU x D=%d x %s, K=%d offsets" % (c["what"], B, Dm, "x".join(str(v) for v in dims), K),
                    "images_per_gpu": B, "embedding_dim": Dm, "dims": dims, "offsets": K, "sharding": "batch across ranks, no data-path collective"},
+        "ms_per_step_autograd_seed": round(dt_seed / args.steps * 1e3, 5), "settle_steps": settle,
         "kernel_ms": {"fwd": round(kf, 5), "bwd": round(kb, 5)},
+        # the launch floor as a number: the entry points' launches (forward + loss finish + backward) captured in a
+        # HIP graph and replayed back to back -- no Python, no ctypes, no autograd between them
+        "graph_replay_ms": graph_replay_ms(fwd, bwd, max(20, min(args.steps, 200))),
         "cross_kernels": {"fwd": int(L.pea_cross_supported(ctypes.byref(desc), 0)), "bwd": int(L.pea_cross_supported(ctypes.byref(desc), 1))},
         "roofline": {"bound": "hbm", "kernel": "pea_affinity_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.config, dom) if B == c["B"] else None,
@@ -199,13 +216,112 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
     if world == 1 and not args.no_cpu_baseline:
         # bounded sample: one image (2D) / one 24 x 256 x 256 block of the sub-volume (3D), same op sequence on the host cores
         if c["ndim"] == 2:
-            out["cpu_baseline"] = cpu_baseline(offsets, Ed[:1].float().cpu(), T[:1].cpu(), Wt[:1].cpu(), M[:1].cpu(), what="1 image of the batch")
+            out["cpu_baseline"] = cpu_baseline(offsets, Ed[:1].float().cpu(), T[:1].cpu(), Wt[:1].cpu(), M[:1].cpu(),
+                                               what="the image" if B == 1 else "1 image of the batch")
+            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["best_cpu_value"], 1)  # vs the faster CPU line
+        elif c["stencil"] == "n26":
+            sl = (slice(0, 1), slice(None), slice(None), slice(0, 256), slice(0, 256))
+            out["cpu_baseline"] = cpu_baseline_generic3d(offsets, Ed[sl].float().cpu().contiguous(), T[sl].cpu().contiguous(), Wt[sl].cpu().contiguous(),
+                                                         what="a 24x256x256 block of the sub-volume with the 26-neighbourhood (K=26)")
         else:
             sl = (slice(0, 1), slice(None), slice(None), slice(0, 256), slice(0, 256))
             out["cpu_baseline"] = cpu_baseline(None, Ed[sl].float().cpu().contiguous(), T[:, :12][sl].cpu().contiguous(), Wt[:, :12][sl].cpu().contiguous(),
                                                None, shifts3d=pkg.utils.affinity_ours.NORM5_SHIFTS,
                                                what="a 24x256x256 block of the sub-volume with the norm5 stencil (K=12)")
     return out
+
+
+def settle_gpu(step, budget_s=1.5):
+    """untimed, before the warm-up steps: a GPU that has just been handed over idles at its lowest clocks and the first few hundred
+    launches also pay the allocator's and the library's first-touch costs; a 20-step timing started cold reads 25-30 % slow.  Run
+    batches of 20 steps until two consecutive batches agree within 2 % (at most budget_s).  Returns the steps spent."""
+    settle, prev, t_start = 0, None, time.perf_counter()
+    while time.perf_counter() - t_start < budget_s:
+        ts = time.perf_counter()
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        cur = time.perf_counter() - ts
+        settle += 20
+        if prev is not None and abs(cur - prev) <= 0.02 * prev:
+            break
+        prev = cur
+    return settle
+
+
+def wall_time_s(step, fence, steps, warm=5):
+    """host wall time of `steps` calls of step() between two fences (this rank)"""
+    for _ in range(warm):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    return time.perf_counter() - t0
+
+
+def graph_replay_ms(fwd, bwd, iters):
+    """fwd(); bwd() (C-ABI launches on the current stream) captured once in a HIP graph; average duration of a replay, replays
+    queued back to back (HIP events around the batch).  None if the capture fails."""
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fwd(); bwd()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            assert fwd() == 0 and bwd() == 0
+        for _ in range(5):
+            g.replay()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            g.replay()
+        b.record()
+        b.synchronize()
+        return round(a.elapsed_time(b) / iters, 5)
+    except Exception:  # noqa: BLE001 -- an extra field, never the headline
+        return None
+
+
+def cpu_baseline_generic3d(offsets, e, t, w, what):
+    """a 3D stencil the torch restatement has no op sequence for (the 26-neighbourhood): the oracle's C restatement with OpenMP over
+    the host cores on a bounded block, CROP_ZERO border and cropped normaliser like the GPU line it sits beside"""
+    orc = ge.load_oracle()
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    en, tn, wn = (np.ascontiguousarray(x.numpy()) for x in (e, t, w))
+    B, Dm = en.shape[:2]
+    d = orc.make_desc(B, Dm, list(en.shape[2:]), [list(o) for o in offsets], None, orc.BORDER_CROP_ZERO, orc.NORM_CROPPED, 1e-12, 0, ndim=3)
+
+    def once():
+        t0 = time.perf_counter()
+        orc.c_fwd(d, en, None, tn, wn, None)
+        orc.c_bwd(d, en, None, tn, wn, None)
+        return time.perf_counter() - t0
+
+    prev = orc.c_set_threads(cores)
+    once()
+    dco = min(once() for _ in range(2))
+    orc.c_set_threads(1)
+    sub = (slice(0, 1), slice(None), slice(None), slice(0, 64), slice(0, 64))
+    e1, t1, w1 = (np.ascontiguousarray(x[sub]) for x in (en, tn, wn))
+    d1 = orc.make_desc(1, Dm, list(e1.shape[2:]), [list(o) for o in offsets], None, orc.BORDER_CROP_ZERO, orc.NORM_CROPPED, 1e-12, 0, ndim=3)
+    t0 = time.perf_counter()
+    orc.c_fwd(d1, e1, None, t1, w1, None)
+    orc.c_bwd(d1, e1, None, t1, w1, None)
+    d1t = time.perf_counter() - t0
+    orc.c_set_threads(prev)
+    px = B * int(np.prod(en.shape[2:]))
+    v = round(px / dco / 1e6, 4)
+    return {"value": v, "unit": "Mpx/s", "cores": cores, "kind": "port",
+            "sample": "best of 2 fwd + bwd of %s, oracle/pea_oracle.c with OpenMP (%d threads), %.2f s" % (what, cores, dco),
+            "c_omp": {"value": v, "unit": "Mpx/s", "cores": cores, "kind": "port", "sample": "the same run"},
+            "c_1thread": {"value": round(int(np.prod(e1.shape[2:])) / d1t / 1e6, 4), "unit": "Mpx/s", "cores": 1, "kind": "port",
+                          "sample": "one fwd + bwd of a 24x64x64 block, oracle/pea_oracle.c, 1 thread, %.2f s" % d1t},
+            "best_cpu_value": v}
 
 
 def event_time_ms(fn, iters):
@@ -379,7 +495,20 @@ def main():
         if shared:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            # RCCL over xGMI.  This branch has never run on this pool (one GPU per box): a rendezvous or communicator failure must end
+            # the process with a one-line reason and a non-zero code -- not hang until the driver's limit -- and is not retried in place
+            import datetime
+            try:
+                dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=180))
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)  # first collective: builds the communicator (rings over xGMI)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError("all_reduce of ones over %d ranks returned %r" % (world, probe.item()))
+            except Exception as ex:  # noqa: BLE001
+                sys.stderr.write("bench.py: rank %d: RCCL init / first all-reduce failed: %r\n" % (rank, ex))
+                sys.stderr.flush()
+                os._exit(3)
 
     pkg = ge.load_package()
     synth = __import__("importlib").import_module(ge.PKG_NAME + ".utils.synth")
@@ -415,17 +544,7 @@ def main():
     # Settle first (untimed, before the W warm-up steps): a GPU that has just been handed over idles at its lowest clocks
     # and the first few hundred launches also pay the allocator's and the library's first-touch costs; a 20-step timing
     # started cold reads 25-30 % slow.  Run batches of 20 steps until two consecutive batches agree within 2 % (<= 1.5 s).
-    settle, prev, t_start = 0, None, time.perf_counter()
-    while time.perf_counter() - t_start < 1.5:
-        ts = time.perf_counter()
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
-        cur = time.perf_counter() - ts
-        settle += 20
-        if prev is not None and abs(cur - prev) <= 0.02 * prev:
-            break
-        prev = cur
+    settle = settle_gpu(step)
     for _ in range(args.warmup):
         step()
     fence()
@@ -440,6 +559,18 @@ def main():
         dt = float(tmax.item())
     px_per_step = world * B * H * W
     value = px_per_step * args.steps / dt / 1e6
+    # the same step started with plain loss.backward(): what a drop-in caller executes -- autograd seeds a
+    # scalar's backward with a ones_like fill kernel (about 5 us); reported beside the headline, never in place of it
+    def step_seed():
+        E.grad = None
+        loss, affs, _ = pkg.embedding_loss(E, T, Wt, M, crit, offsets)
+        loss.backward()
+
+    dt_seed = wall_time_s(step_seed, fence, args.steps)
+    if dist is not None:
+        tmax = torch.tensor([dt_seed], dtype=torch.float64, device="cpu" if shared else dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt_seed = float(tmax.item())
     train = None
     if not args.no_train:
         try:
@@ -464,9 +595,10 @@ def main():
         one = torch.ones((), device=dev)
         P = lambda x: ctypes.c_void_p(x.data_ptr())
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        cur = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # (read per call: the graph capture runs on its own stream)
         INV = torch.empty(B, H, W, device=dev)  # 1 / norm plane: written by the forward, staged by the cross backward
-        fwd = lambda: L.pea_affinity_fwd_ex(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(affs), P(G), P(INV), P(lossv), P(work), wsb, st)
-        bwd = lambda: L.pea_affinity_bwd_ex2(ctypes.byref(desc), P(Ed), None, P(G), P(INV), P(affs), P(one), P(dE), None, st)
+        fwd = lambda: L.pea_affinity_fwd_ex(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(affs), P(G), P(INV), P(lossv), P(work), wsb, cur())
+        bwd = lambda: L.pea_affinity_bwd_ex2(ctypes.byref(desc), P(Ed), None, P(G), P(INV), P(affs), P(one), P(dE), None, cur())
         affs2 = torch.empty_like(affs)  # (the other entry points get their own map: `affs` is an input of the backward)
         inf = lambda: L.pea_affinity_infer(ctypes.byref(desc), P(Ed), None, P(affs2), st)
         # the labels-in training step (embedding_loss_from_labels): same outputs from the int32 label image, no t / w / m
@@ -558,10 +690,13 @@ def main():
             # pixels are counted on the padded tensor the op processes (544^2 per CVPPP image); the same rate in
             # images and in pixels of the un-padded 530x500 image
             "settle_steps": settle,
+            "ms_per_step_autograd_seed": round(dt_seed / args.steps * 1e3, 5),
+            "value_autograd_seed": round(px_per_step * args.steps / dt_seed / 1e6, 2),
             **(train or {}),
             "images_per_s_op_only": round(value * 1e6 / (H * W), 1),
             "value_530x500_equiv": round(value * (530 * 500) / (H * W), 2),
             "kernel_ms": {k: round(v, 5) for k, v in kt.items()},
+            "graph_replay_ms": graph_replay_ms(fwd, bwd, max(20, min(args.steps, 200))),
             "kernel_sum_mpx_s": round(B * H * W / ((kt["fwd"] + kt["bwd"]) * 1e-3) / 1e6, 1),
             "infer_mpx_s": round(B * H * W / (kt["infer"] * 1e-3) / 1e6, 1),
             "labels_step_mpx_s": round(B * H * W / (kt["labels_step"] * 1e-3) / 1e6, 1),

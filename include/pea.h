@@ -186,7 +186,9 @@ int pea_inv_norm(const PeaDesc *desc, const void *e, float *inv_norm_out, void *
  * (backward == 0) or the backward (backward == 1, given the 1 / norm plane): the cross kernels for axis-aligned stencils, the
  * unit-box kernels (csrc/pea_box.h) for stencils with |dz|, |dy|, |dx| <= 1 such as the 26-neighbourhood; backward == 2: the cross
  * loss with a detached second operand (forward and role-A backward, given the two planes); else 0 (the tiled / direct kernels
- * run).  A caller uses it to decide whether to allocate the 1 / norm plane. */
+ * run).  A caller uses it to decide whether to allocate the 1 / norm plane.  backward == 3: 1 when pea_affinity_bwd_ex2 READS the
+ * raw affinity map for this descriptor (the projection-first kernels at D > 16, csrc/pea_xdma_pf.h; the z-march backward of 3D
+ * volumes, csrc/pea_zmarch.h): a caller that hands `affs` over must then keep the forward's map unmodified until the backward. */
 int pea_cross_supported(const PeaDesc *desc, int backward);
 
 /* The backward of the full-resolution pair of the training loop in one launch: g is what pea_affinity_fwd wrote for the self

@@ -13,6 +13,7 @@ import collections
 import collections.abc
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -265,7 +266,9 @@ class FusedAffinityMSE(torch.autograd.Function):
         ctx.has_other = o_c is not None
         # the raw cosine map is an input of the projection-first backward (pea_affinity_bwd_ex2): saved like an input, so autograd's
         # version counter catches an in-place edit of the returned map (affs.relu_()) between forward and backward
-        raw = affs if (inv is not None and o_c is None and spec.act == 0) else None
+        # -- and only where the backward reads it (pea_cross_supported mode 3: the projection-first kernels at D > 16, the z-march
+        # backward of 3D volumes): elsewhere saving it would turn a harmless affs.relu_() before backward() into a RuntimeError
+        raw = affs if (inv is not None and o_c is None and spec.act == 0 and cross_supported(d, 3)) else None
         ctx.save_for_backward(e_c, o_c, g, inv, raw)
         loss, per_offset = loss_vec[0], loss_vec[1:]  # views of a buffer that is not itself returned
         ctx.mark_non_differentiable(affs, per_offset)
@@ -409,18 +412,22 @@ def activation_flags(activation):
 
 _RANGE_MSG = "label ids must fit int32%s: relabel the segmentation first"
 _RANGE_CHECKS = collections.deque()  # (event, pinned flag) of range checks of GPU label tensors that have not been read back yet
+_RANGE_LOCK = threading.Lock()       # the reference drives replicas from nn.DataParallel threads: the queue is shared
 
 
 def check_label_ranges(block=True):
     """Read back the deferred range checks of _labels_int32 (GPU labels wider than int32): raises ValueError if an earlier label
     tensor held an id outside int32.  block=False only looks at checks whose copy has already arrived (no host sync); the
     labels-in entry points poll that way on every call, so a bad id surfaces one or two calls later at the latest."""
-    while _RANGE_CHECKS:
-        ev, host = _RANGE_CHECKS[0]
-        if not block and not ev.query():
-            return
+    while True:
+        with _RANGE_LOCK:
+            if not _RANGE_CHECKS:
+                return
+            ev, host = _RANGE_CHECKS[0]
+            if not block and not ev.query():
+                return
+            _RANGE_CHECKS.popleft()
         ev.synchronize()
-        _RANGE_CHECKS.popleft()
         if bool(host.item()):
             raise ValueError(_RANGE_MSG % " (found by the deferred range check of an earlier call)")
 
@@ -441,11 +448,15 @@ def _labels_int32(labels):
             check_label_ranges(block=False)
             top = l64 >> 31  # 0 or -1 for an id inside int32
             bad = ((top != 0) & (top != -1)).any()
-            host = torch.empty((), dtype=torch.bool, pin_memory=True)
-            host.copy_(bad, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            _RANGE_CHECKS.append((ev, host))
+            # the flag starts out False (never garbage) and the event is recorded on the stream the copy was queued on: the current
+            # stream of the LABELS' device, which need not be the current device
+            host = torch.zeros((), dtype=torch.bool).pin_memory()
+            with torch.cuda.device(labels.device):
+                host.copy_(bad, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(labels.device))
+            with _RANGE_LOCK:
+                _RANGE_CHECKS.append((ev, host))
     return labels.to(torch.int32).contiguous()
 
 
@@ -506,7 +517,10 @@ class LabelsAffinityMSE(torch.autograd.Function):
                                             "stencil too wide): use gen_targets + the tensor API")
             _lib.check(rc, "pea_affinity_fwd_bwd_labels")
         ctx.de_unit, ctx.desc = de_unit, d
-        ctx.again = (e_c, o_c, lab, wtab, flags)  # for a second backward over a retained graph (references only: nothing is copied)
+        # for a second backward over a retained graph: saved like inputs (freed after a non-retained backward, version-checked on a
+        # retained one), nothing is copied
+        ctx.save_for_backward(e_c, o_c, lab, wtab)
+        ctx.lflags = flags
         loss, per_offset = loss_vec[0], loss_vec[1:]
         ctx.mark_non_differentiable(affs, per_offset)
         return loss, affs, per_offset
@@ -515,7 +529,8 @@ class LabelsAffinityMSE(torch.autograd.Function):
     def _unit_gradient_again(ctx):
         """the gradient for grad_output = 1 once more (the first backward handed its buffer over, scaled in place): the step is run
         again on the saved inputs -- a retained graph is the rare case, and keeping a pristine copy would cost every step 150 MB"""
-        e_c, o_c, lab, wtab, flags = ctx.again
+        e_c, o_c, lab, wtab = ctx.saved_tensors
+        flags = ctx.lflags
         d, L = ctx.desc, _lib.lib()
         with _on_device(e_c.device):
             loss_vec = torch.empty(1 + d.K, dtype=torch.float32, device=e_c.device)

@@ -85,8 +85,11 @@ constexpr size_t kStateBytes = sizeof(LossState);
 int run_fwd(const KParams& P, FwdArgs A, hipStream_t s) {
   const bool self = A.eo == A.e;
   bool launched = false;
-  if (A.train) launched = self ? xdma_fwd_self(P, A, s) : xdma_fwd_other(P, A, s);
-  else if (self) launched = xdma_fwd_self(P, A, s);
+  if (self) launched = zmarch_fwd(P, A, s);  // 3D volumes whose stencil steps along z (norm5 / norm1): pea_zmarch.h
+  if (!launched) {
+    if (A.train) launched = self ? xdma_fwd_self(P, A, s) : xdma_fwd_other(P, A, s);
+    else if (self) launched = xdma_fwd_self(P, A, s);
+  }
   if (!launched && self) launched = box_fwd(P, A, s);
   if (!launched) {
     // 1 / norm planes: the tiled D = 16 self forward writes its plane while it stages; everything else gets k_inv_norm
@@ -200,6 +203,11 @@ int pea_affinity_fwd(const PeaDesc* desc, const void* e, const void* e_other, co
 int pea_cross_supported(const PeaDesc* desc, int backward) {
   if (validate(desc)) return 0;
   const KParams P = make_params(desc);
+  if (backward == 3) {  // does pea_affinity_bwd_ex2 READ the raw affinity map for this descriptor (self loss)?
+    if (zmarch_bwd_supported(P, desc->dtype)) return 1;
+    return (env().bwd_pf && !(P.flags & kActMask) && (P.D > 16 || env().bwd_pf == 2) && xdma_cross_supported(P, desc->dtype, 1)) ? 1 : 0;
+  }
+  if (backward == 1 && zmarch_bwd_supported(P, desc->dtype)) return 1;
   if (xdma_cross_supported(P, desc->dtype, backward)) return 1;
   return (backward == 0 || backward == 1) && box_supported(P, desc->dtype) ? 1 : 0;
 }
@@ -241,6 +249,7 @@ int pea_affinity_bwd_ex2(const PeaDesc* desc, const void* e, const void* e_other
     // the forward stays on the cross kernels: 1.25 against 1.54 ms, the box forward walks all 26 displacements whatever K is)
     bool zstep = false;
     for (int i = 0; i < P.K; ++i) zstep |= P.off[i][0] != 0;
+    if (dt == PEA_F32 && zstep && zmarch_bwd(P, (const float*)e, inv_norm, g, affs, dloss, (float*)de, s)) return hip_rc();
     if (dt == PEA_F32 && zstep && box_bwd(P, (const float*)e, inv_norm, g, dloss, (float*)de, s)) return hip_rc();
     if (dt == PEA_F32 && xdma_bwd_self(P, (const float*)e, inv_norm, g, affs, dloss, (float*)de, s)) return hip_rc();
     if (dt == PEA_F16 && xdma_bwd_self_h(P, e, inv_norm, g, affs, dloss, de, s)) return hip_rc();

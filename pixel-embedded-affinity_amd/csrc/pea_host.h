@@ -3,6 +3,7 @@
 // The library is built from several .hip files compiled in parallel (one per kernel family; a single file took 1 m 47 s):
 //   pea_abi.hip        the extern "C" entry points of include/pea.h: validation, descriptor -> KParams, dispatch
 //   pea_k_xdma.hip     LDS-DMA cross kernels (pea_xdma.h): the training forward / backward of axis-aligned stencils
+//   pea_k_zmarch.hip   z-march kernels (pea_zmarch.h): 3D volumes with axis-aligned stencils that step along z (norm5 / norm1)
 //   pea_k_box.hip      unit-box stencils (pea_box.h): the 26-neighbourhood of a 3D volume through an LDS-DMA ring of 3-plane boxes
 //   pea_k_tiled.hip    LDS-tiled box kernels (pea_tiled.h, pea_chunked.h): diagonal stencils, f16 storage, inference
 //   pea_k_labels.hip   the labels-in training step (pea_fused_labels.h) and the label-weight tables
@@ -29,6 +30,11 @@ struct Env {
   int fwd_wg3;        // PEA_FWD_WG3=0: the 2-workgroups-per-CU forward
   int h16_hw;         // PEA_H16_HW=0: the f16 kernels with the f32 working buffer (packed-f32 gather) instead of the f16 one (v_dot2 / v_fma_mix)
   int box;            // PEA_BOX=0: unit-box stencils (the 26-neighbourhood) on the tiled kernels instead of pea_box.h
+  int zmarch;         // PEA_ZMARCH=0: 3D volumes with z offsets on the tile-per-plane cross kernels (pea_xdma.h) instead of the z-march
+                      //   kernels (pea_zmarch.h); 2: the march also on volumes with fewer tile columns than CUs
+  int zseg;           // PEA_ZSEG=n: planes per segment of a tile column (0: whole columns where there are enough of them)
+  int walk2d;         // PEA_WALK2D=n: 2D images walk strips of n tiles in x down y (0: row-major)
+  int lds_pad;        // PEA_LDS_PAD=bytes: extra dynamic LDS on the cross kernels' launches (occupancy experiments)
   int zblk_y, zblk_x; // PEA_ZBLK_Y / PEA_ZBLK_X: tiles per block of the z-fastest walk of 3D volumes (0: the default 4 x 2; Y < 0: plane-major)
 };
 const Env& env();
@@ -110,6 +116,12 @@ bool tiled_fwd(const KParams& P, const FwdArgs& A, hipStream_t s, bool* wrote_in
 void direct_fwd(const KParams& P, const FwdArgs& A, hipStream_t s);
 void launch_inv_norm(const KParams& P, int dtype, const void* e, float* inv, hipStream_t s);
 int xdma_cross_supported(const KParams& P, int dtype, int mode);
+// z-march kernels (pea_k_zmarch.hip): f32, D = 16, CROP_ZERO, z offsets in {-1 .. -4}; the backward needs the 1 / norm plane and
+// the raw affinity map of the forward
+bool zmarch_fwd(const KParams& P, const FwdArgs& A, hipStream_t s);
+bool zmarch_bwd_supported(const KParams& P, int dtype);
+bool zmarch_bwd(const KParams& P, const float* x, const float* inv, const float* g, const float* affs, const float* dl, float* dx,
+                hipStream_t s);
 // unit-box stencils (pea_k_box.hip): f32, D = 16, self loss; the backward needs the forward's 1 / norm plane
 bool box_supported(const KParams& P, int dtype);
 bool box_fwd(const KParams& P, const FwdArgs& A, hipStream_t s);

@@ -34,6 +34,10 @@ void env_load() {
   g_env.bwd_pf = env_int("PEA_BWD_PF", 1);
   g_env.box = env_int("PEA_BOX", 1);
   g_env.h16_hw = env_int("PEA_H16_HW", 1);
+  g_env.zmarch = env_int("PEA_ZMARCH", 1);
+  g_env.zseg = env_int("PEA_ZSEG", 0);
+  g_env.walk2d = env_int("PEA_WALK2D", 0);
+  g_env.lds_pad = env_int("PEA_LDS_PAD", 0);
   g_env.zblk_y = env_int("PEA_ZBLK_Y", 0);
   g_env.zblk_x = env_int("PEA_ZBLK_X", 0);
 }

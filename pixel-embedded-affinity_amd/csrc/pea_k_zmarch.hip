@@ -1,0 +1,99 @@
+// pea_k_zmarch.hip -- launchers of the z-march kernels (pea_zmarch.h): 3D volumes whose axis-aligned stencil steps along z
+// (embedding_loss_norm5 / norm1, scripts_ac3ac4/loss/loss_embedding_mse.py:7-27, 143-194).  One translation unit of libpea_hip.so.
+#include "pea_host.h"
+#include "pea_zmarch.h"
+
+namespace pea {
+
+namespace {
+
+constexpr int kTH = 16, kTW = 32;
+constexpr int kPSUB = 52;  // backward: the two-sided +-27 cross in whole 64-quad blocks (13 KB planes, 78 KB of ring)
+constexpr int kPSUF = 32;  // forward: the one-sided cross in 8 KB planes (48 KB of ring)
+
+struct ZPlan { XParams C; ZMParams M; size_t lds; };
+
+// mode 0: backward (both roles), 1: forward.  The tile walk of xdma_tile is reused with the SEGMENT in the place of z: blocks of
+// 8 x 4 tile columns (one XCD's 32 workgroups: a 128 x 128 pixel block whose halos are shared out of that XCD's L2), the
+// segments of a block one after the other.
+bool plan(const KParams& P, int mode, ZPlan* out) {
+  static thread_local PlanCache<ZPlan, 8> cache;
+  return cache.get(P, mode * 1024 + env().zmarch * 64 + env().zseg, out, [&](ZPlan* p) {
+    if (!env().zmarch || !plan_zmarch(P, &p->M)) return false;
+    if (!plan_xdma(P, kTH, kTW, mode ? kPSUF : kPSUB, &p->C, &p->lds, mode)) return false;
+    XParams& C = p->C;
+    if (mode == 0 && (C.npx > 8 || C.npy > 8)) return false;
+    if (mode == 1 && P.K > kXP + 2) return false;
+    const long long cols = (long long)P.B * C.tiles_per_plane;
+    // one workgroup per CU: whole columns when there are enough of them for two rounds, else segments of >= 8 planes
+    int nseg = 1;
+    if (env().zseg > 0) nseg = (P.Z + env().zseg - 1) / env().zseg;
+    else if (cols < 2 * device_cus()) nseg = (int)std::min<long long>((2 * device_cus() + cols - 1) / cols, std::max(1, P.Z / 8));
+    // a volume that small keeps the tile-per-plane kernels (two workgroups per CU, no warm-up planes); PEA_ZMARCH=2 forces the march
+    if (env().zmarch < 2 && cols * nseg < device_cus()) return false;
+    p->M.nseg = nseg;
+    p->M.zseg = (P.Z + nseg - 1) / nseg;
+    p->M.nseg = (P.Z + p->M.zseg - 1) / p->M.zseg;
+    C.zrun = p->M.nseg;
+    C.zgy = env().zblk_y > 0 ? env().zblk_y : 8;
+    C.zgx = env().zblk_x > 0 ? env().zblk_x : 4;
+    const long long nt = cols * p->M.nseg;
+    if (nt > 0x7fffff00LL) return false;
+    C.ntiles = (int)nt;
+    C.tiles_per_xcd = (C.ntiles + kXcd - 1) / kXcd;
+    return true;
+  });
+}
+
+#define PEA_LAUNCH(kern, grid, blk, lds, s, ...)              \
+  {                                                           \
+    if (allow_lds<kern>(lds)) return false;                   \
+    hipLaunchKernelGGL(kern, grid, blk, lds, s, __VA_ARGS__); \
+  }
+
+}  // namespace
+
+// forward / inference of the self loss on a 3D volume (f32, D = 16, CROP_ZERO, every z offset in {-1 .. -4}); true = launched
+bool zmarch_fwd(const KParams& P, const FwdArgs& A, hipStream_t s) {
+  if (env().force_direct || !env().fwd_xdma || A.eo != A.e || A.dtype != PEA_F32) return false;
+  if (!A.train && !env().infer_xdma) return false;
+  const float* e = (const float*)A.e;
+  if (misaligned(e, 16) || misaligned(A.t, 16) || misaligned(A.w, 16) || misaligned(A.affs, 16) || misaligned(A.gout, 16) ||
+      misaligned(A.m, 4) || misaligned(A.inv_out, 4))
+    return false;
+  if (A.train && ((P.tbs | P.wbs | P.mbs) & 3)) return false;
+  ZPlan Z;
+  if (!plan(P, 1, &Z)) return false;
+  const dim3 grid((unsigned)(Z.C.tiles_per_xcd * kXcd)), blk(kTH * kTW);
+  if (A.train) {
+    constexpr auto kern = k_fwd_zm<kTH, kTW, kPSUF, true>;
+    PEA_LAUNCH(kern, grid, blk, Z.lds, s, P, Z.C, Z.M, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out)
+  } else {
+    constexpr auto kern = k_fwd_zm<kTH, kTW, kPSUF, false>;
+    PEA_LAUNCH(kern, grid, blk, Z.lds, s, P, Z.C, Z.M, e, (const float*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr, A.affs,
+               (float*)nullptr, (LossState*)nullptr, (float*)nullptr)
+  }
+  return true;
+}
+
+// would zmarch_bwd take this descriptor (given the 1 / norm plane and the raw affinity map)?
+bool zmarch_bwd_supported(const KParams& P, int dtype) {
+  if (env().force_direct || !env().bwd_xdma || dtype != PEA_F32 || (P.flags & kActMask)) return false;
+  ZPlan Z;
+  return plan(P, 0, &Z);
+}
+
+// backward of the self loss: needs the forward's 1 / norm plane AND its raw affinity map (the z channels are read)
+bool zmarch_bwd(const KParams& P, const float* x, const float* inv, const float* g, const float* affs, const float* dl, float* dx,
+                hipStream_t s) {
+  if (!inv || !affs || !zmarch_bwd_supported(P, PEA_F32)) return false;
+  if (misaligned(x, 16) || misaligned(inv, 16) || misaligned(g, 4) || misaligned(affs, 4) || misaligned(dx, 4)) return false;
+  ZPlan Z;
+  if (!plan(P, 0, &Z)) return false;
+  const dim3 grid((unsigned)(Z.C.tiles_per_xcd * kXcd)), blk(kTH * kTW);
+  constexpr auto kern = k_bwd_zm<kTH, kTW, kPSUB>;
+  PEA_LAUNCH(kern, grid, blk, Z.lds, s, P, Z.C, Z.M, x, inv, g, affs, dl, dx)
+  return true;
+}
+
+}  // namespace pea

@@ -122,9 +122,11 @@ __device__ __forceinline__ bool xdma_tile(const CP& C, const KParams& P, int& ti
   const int lin = (bid % kXcd) * C.tiles_per_xcd + bid / kXcd;
   if (lin >= C.ntiles) return false;
   int plane, rem;
-  if (C.zrun > 1) {
+  if (C.zrun >= 1) {
     // walk: blocks of kGY x kGX tiles; inside a block z, then y, then x fastest -- the tiles in flight on an XCD (64) are a few
-    // planes of one block: the z neighbours were staged 1-4 planes ago, the in-plane halos are shared inside the block
+    // planes of one block: the z neighbours were staged 1-4 planes ago, the in-plane halos are shared inside the block.
+    // zrun == 1 (2D images, PEA_WALK2D): the same walk without a z run -- strips of kGX tiles walked down y, so that the tiles in
+    // flight on an XCD share their y halos out of its L2
     const int kGY = C.zgy, kGX = C.zgx;
     const int per_b = C.tiles_per_plane * C.zrun;
     b = lin / per_b;

@@ -152,17 +152,63 @@ class _TensorSection(torch.autograd.Function):
             losses = rows[:, 0]
             total = (losses * wdev).sum()
         ctx.grads, ctx.n_embs = grads, len(embs)
-        ctx.again = (_TensorSection, (specs, weights, ema_embedding, tensors) + tuple(embs))  # references only (a second backward)
+        _stash_again(ctx, _TensorSection, (specs, weights, ema_embedding, tensors) + tuple(embs))
         ctx.mark_non_differentiable(pred, losses)
         return total, pred, losses
 
     backward = staticmethod(lambda ctx, dtotal, _dp, _dl: _section_backward(ctx, dtotal))
 
 
+def _stash_again(ctx, cls, args):
+    """keep a section's arguments for a second backward over a retained graph: every tensor goes through save_for_backward (freed
+    after a non-retained backward, version-checked on a retained one -- a plain ctx attribute would keep ~150 MB of embeddings alive
+    until the loss tensor is dropped and miss in-place edits); the nesting and the non-tensor values stay on ctx"""
+    flat = []
+
+    def enc(x):
+        if isinstance(x, torch.Tensor):
+            flat.append(x)
+            return ("T", len(flat) - 1)
+        if isinstance(x, (list, tuple)):
+            return ("L" if isinstance(x, list) else "U", [enc(v) for v in x])
+        if isinstance(x, dict):
+            return ("D", [(k, enc(v)) for k, v in x.items()])
+        if isinstance(x, _LabelCfg):
+            return ("C", enc([x.labels, x.lflags, x.gen_flags, x.has_mask, x.tables]))
+        return ("V", x)
+
+    ctx.again = (cls, enc(tuple(args)))
+    ctx.save_for_backward(*flat)
+
+
+def _unstash_again(ctx):
+    flat = ctx.saved_tensors
+
+    def dec(t):
+        kind, v = t
+        if kind == "T":
+            return flat[v]
+        if kind == "L":
+            return [dec(i) for i in v]
+        if kind == "U":
+            return tuple(dec(i) for i in v)
+        if kind == "D":
+            return {k: dec(i) for k, i in v}
+        if kind == "C":
+            return _LabelCfg(*dec(v))
+        return v
+
+    cls, tree = ctx.again
+    return cls, dec(tree)
+
+
 class _Rerun(object):
     """stands in for the autograd context when a section is computed again for a second backward over a retained graph"""
 
     def set_materialize_grads(self, value):
+        pass
+
+    def save_for_backward(self, *tensors):
         pass
 
     def mark_non_differentiable(self, *tensors):
@@ -176,7 +222,7 @@ def _section_backward(ctx, dtotal):
     if ctx.grads is None:
         # the first backward took the gradient buffers (scaled in place): a second backward over a retained graph computes the
         # section again on the saved inputs -- the rare case pays, not every step
-        cls, args = ctx.again
+        cls, args = _unstash_again(ctx)
         stub = _Rerun()
         cls.forward(stub, *args)
         ctx.grads = stub.grads
@@ -281,7 +327,8 @@ def cvppp_loss_section(embedding, emds, ema_embedding, target, weightmap, affs_m
         return loss, pred, _section_parts(losses, weights, self_emb, cross_emb)
     loss, pred, parts = cvppp_loss_section_composed(embedding, emds, ema_embedding, target, weightmap, affs_mask, downs, criterion,
                                                     offsets, nb_half, affs0_weight, dis_mode, deep_weight, self_emb, cross_emb)
-    return loss, (finish_pred_2d_(pred) if relu_pred else pred), parts
+    # (out of place: the composed path's `pred` may be saved for its loss' backward -- the projection-first kernel reads the raw map)
+    return loss, (torch.relu(pred) if relu_pred else pred), parts
 
 
 def cvppp_loss_section_composed(embedding, emds, ema_embedding, target, weightmap, affs_mask, downs, criterion, offsets, nb_half,
@@ -502,7 +549,7 @@ class _LabelsSection(torch.autograd.Function):
             losses = rows[:, 0]
             total = (losses * wdev).sum()
         ctx.grads, ctx.n_embs = grads, len(embs)
-        ctx.again = (_LabelsSection, (specs, weights, ema_embedding, label_cfg) + tuple(embs))
+        _stash_again(ctx, _LabelsSection, (specs, weights, ema_embedding, label_cfg) + tuple(embs))
         ctx.mark_non_differentiable(pred, losses)
         return total, pred, losses
 

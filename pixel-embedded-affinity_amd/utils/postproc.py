@@ -30,6 +30,9 @@ def fill_border_relu_(pred, shift=1, relu=True):
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         _lib.check(_lib.lib().pea_fill_border_relu(ctypes.c_void_p(pred.data_ptr()), B, K, Z, Y, X, int(shift),
                                                    1 if relu else 0, st), "pea_fill_border_relu")
+    # the kernel writes through data_ptr(): tell autograd, so that a map saved for a backward (the raw cosines of the
+    # projection-first backward, affinity_op.FusedAffinityMSE) raises "modified by an inplace operation" instead of miscomputing
+    torch.autograd.graph.increment_version(pred)
     return pred
 
 

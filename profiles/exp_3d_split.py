@@ -42,7 +42,7 @@ for name, nd, B, offs in cases:
     assert L.pea_workspace_init(ctypes.c_void_p(work.data_ptr()), wsb, None) == 0  # the loss-state block: prepared once
     dE = torch.empty_like(E); one = torch.ones((), device=dev)
     fns = {"fwd": lambda: L.pea_affinity_fwd_ex(ctypes.byref(desc), P(E), None, P(T), P(Wt), None, P(affs), P(G), P(INV), P(lossv), P(work), wsb, st),
-           "bwd": lambda: L.pea_affinity_bwd_ex(ctypes.byref(desc), P(E), None, P(G), P(INV), P(one), P(dE), None, st)}
+           "bwd": lambda: L.pea_affinity_bwd_ex2(ctypes.byref(desc), P(E), None, P(G), P(INV), P(affs), P(one), P(dE), None, st)}
     out = ["cross fwd/bwd %d/%d" % (L.pea_cross_supported(ctypes.byref(desc), 0), L.pea_cross_supported(ctypes.byref(desc), 1))]
     for kn, fn in fns.items():
         for _ in range(3): assert fn() == 0

@@ -1,0 +1,145 @@
+"""GPU (-m gpu): the z-march kernels (csrc/pea_zmarch.h: k_fwd_zm, k_bwd_zm) -- 3D volumes whose axis-aligned stencil steps along z
+(embedding_loss_norm5 / norm1, scripts_ac3ac4/loss/loss_embedding_mse.py:7-27, 143-194) -- against the CPU oracle and against the
+tile-per-plane cross kernels they replace on large volumes.  PEA_ZMARCH=2 forces the march on volumes with fewer tile columns than
+CUs (the sizes the oracle finishes in seconds); PEA_ZSEG cuts the columns into segments (warm-up planes, contributor planes, drain).
+
+Tolerances as in test_gpu_parity.py: affs abs 1e-5, loss rel 1e-5, grads rel-to-max 1e-4."""
+import ctypes
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import __graft_entry__ as ge
+
+pytestmark = pytest.mark.gpu
+AFFS_ATOL, LOSS_RTOL, GRAD_RTOL = 1e-5, 1e-5, 1e-4
+NORM5 = [1, 1, 1, 2, 3, 3, 3, 9, 9, 4, 27, 27]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def synth():
+    ge.load_package()
+    return importlib.import_module(ge.PKG_NAME + ".utils.synth")
+
+
+def cu(a, dev):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def relmax(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _march_on(pkg, spec, et):
+    """the backward of this descriptor reads the raw affinity map: the z-march kernel (D = 16) is what runs"""
+    d = pkg.affinity_op.make_desc(spec, et.detach())
+    return pkg._lib.lib().pea_cross_supported(ctypes.byref(d), 3) == 1
+
+
+@pytest.mark.parametrize("shape,zseg", [((2, 6, 48, 96), 0), ((1, 5, 64, 132), 0), ((1, 9, 43, 96), 0), ((1, 13, 48, 96), 5),
+                                        ((2, 11, 50, 100), 3), ((1, 24, 48, 128), 8), ((1, 7, 64, 96), 1)])
+def test_zmarch_norm5_vs_oracle(pkg, dev, orc, synth, monkeypatch, shape, zseg):
+    """embedding_loss_norm5 (12 axis offsets: z 1-4, y / x 1, 3, 9, 27; CROP_ZERO, cropped normaliser, affs0_weight on the first three)
+    through the march: whole columns (zseg 0) and segments of 1 - 8 planes -- a segment shorter than the window (1, 3) has warm-up and
+    contributor planes on both sides of every plane it owns; ragged tiles in y and x; zero-norm pixels (the clamp branch)"""
+    B, Z, Y, X = shape
+    monkeypatch.setenv("PEA_ZMARCH", "2")
+    if zseg:
+        monkeypatch.setenv("PEA_ZSEG", str(zseg))
+    offs = orc.norm_offsets(NORM5)
+    e, t, w = synth.synth_inputs_3d(B, 16, Z, Y, X, offs, 31 + Z)
+    e[0, :, Z // 2, 3, 5] = 0.0
+    e[-1, :, Z - 1, Y - 1, X - 1] = 1e-14
+    e[0, :, 0, 17, 40] = 0.0
+    et = cu(e, dev).requires_grad_(True)
+    spec = pkg.AffinitySpec(3, offs, orc.affs0_lambda_3d(12, 2, 3), pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
+    assert _march_on(pkg, spec, et)
+    loss, affs = pkg.embedding_loss_norm5(et, cu(t, dev), cu(w, dev), pkg.WeightedMSE(), affs0_weight=2)
+    (loss * 0.25).backward()
+    inf = pkg.inf_embedding_loss_norm5(et.detach())
+    d = orc.desc_3d(e, NORM5, orc.affs0_lambda_3d(12, 2, 3))
+    o_affs, o_loss = orc.c_fwd(d, e, None, t, w, None)
+    o_grad, _ = orc.c_bwd(d, e, None, t, w, None, dloss=0.25)
+    assert np.abs(affs.cpu().numpy() - o_affs).max() < AFFS_ATOL
+    assert np.abs(inf.cpu().numpy() - o_affs).max() < AFFS_ATOL
+    assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+    assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL
+    # against the tile-per-plane cross kernels (z neighbours gathered from global memory): the same arithmetic in another order
+    monkeypatch.setenv("PEA_ZMARCH", "0")
+    e2 = cu(e, dev).requires_grad_(True)
+    assert not _march_on(pkg, spec, e2)
+    loss2, affs2 = pkg.embedding_loss_norm5(e2, cu(t, dev), cu(w, dev), pkg.WeightedMSE(), affs0_weight=2)
+    (loss2 * 0.25).backward()
+    assert np.abs(affs.cpu().numpy() - affs2.cpu().numpy()).max() < 2e-6
+    assert relmax(et.grad.cpu().numpy(), e2.grad.cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("shift,zseg", [(1, 0), (2, 0), (1, 4)])
+def test_zmarch_norm1_vs_oracle(pkg, dev, orc, synth, monkeypatch, shift, zseg):
+    """embedding_loss_norm1 (one step along z, y, x; shift 1 and 2): only one of the window's four z slots carries a coefficient"""
+    B, Z, Y, X = 2, 10, 40, 72
+    monkeypatch.setenv("PEA_ZMARCH", "2")
+    monkeypatch.setenv("PEA_BOX", "0")  # (the unit-box backward otherwise takes shift 1)
+    if zseg:
+        monkeypatch.setenv("PEA_ZSEG", str(zseg))
+    sh = [shift] * 3
+    offs = orc.norm_offsets(sh)
+    e, t, w = synth.synth_inputs_3d(B, 16, Z, Y, X, offs, 77 + shift)
+    et = cu(e, dev).requires_grad_(True)
+    spec = pkg.AffinitySpec(3, offs, orc.affs0_lambda_3d(3, 1.5, 1), pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
+    assert _march_on(pkg, spec, et)
+    loss, affs = pkg.embedding_loss_norm1(et, cu(t, dev), cu(w, dev), pkg.WeightedMSE(), affs0_weight=1.5, shift=shift)
+    loss.backward()
+    d = orc.desc_3d(e, sh, orc.affs0_lambda_3d(3, 1.5, 1))
+    o_affs, o_loss = orc.c_fwd(d, e, None, t, w, None)
+    o_grad, _ = orc.c_bwd(d, e, None, t, w, None)
+    assert np.abs(affs.cpu().numpy() - o_affs).max() < AFFS_ATOL
+    assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+    assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL
+
+
+def test_zmarch_reruns_are_bit_identical_and_dloss_is_linear(pkg, dev, orc, synth, monkeypatch):
+    """size-independent properties on a volume large enough for the default dispatch (no switch): two runs agree bit for bit (integer
+    loss atomics, no float atomics anywhere), the gradient is linear in grad_output, and the batch is additive (the sharding identity)"""
+    B, Z, Y, X = 2, 16, 256, 512            # 2 x 16 x 16 = 512 tile columns: the march runs by default
+    offs = orc.norm_offsets(NORM5)
+    g = torch.Generator(device=dev).manual_seed(5)
+    E = torch.randn(B, 16, Z, Y, X, generator=g, device=dev)
+    T = (torch.rand(B, 12, Z, Y, X, generator=g, device=dev) < 0.6).float()
+    Wt = torch.rand(B, 12, Z, Y, X, generator=g, device=dev) + 0.5
+    spec = pkg.AffinitySpec(3, offs, None, pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
+    assert _march_on(pkg, spec, E)
+
+    def run(e, t, w, scale):
+        x = e.clone().requires_grad_(True)
+        loss, affs = pkg.embedding_loss_norm5(x, t, w, pkg.WeightedMSE())
+        (loss * scale).backward()
+        return loss.item(), affs, x.grad
+
+    l1, a1, g1 = run(E, T, Wt, 1.0)
+    l2, a2, g2 = run(E, T, Wt, 1.0)
+    assert l1 == l2 and torch.equal(a1, a2) and torch.equal(g1, g2)
+    _, _, g3 = run(E, T, Wt, 0.5)
+    assert torch.allclose(g3 * 2.0, g1, rtol=1e-6, atol=0)
+    # one item alone: its loss terms carry the normaliser of a batch of one (twice the weight), its gradient likewise
+    la, aa, ga = run(E[:1], T[:1], Wt[:1], 1.0)
+    lb, ab, gb = run(E[1:], T[1:], Wt[1:], 1.0)
+    assert torch.equal(aa, a1[:1]) and torch.equal(ab, a1[1:])
+    assert abs((la + lb) * 0.5 - l1) <= 1e-6 * abs(l1)
+    assert relmax(ga.cpu().numpy() * 0.5, g1[:1].cpu().numpy()) < 1e-6 and relmax(gb.cpu().numpy() * 0.5, g1[1:].cpu().numpy()) < 1e-6
+    # a window of it against the oracle: the first planes (border slices), two tile rows, four tile columns
+    zs, ys, xs = slice(0, 9), slice(0, 64), slice(0, 128)
+    e_np = E[:1, :, zs, ys, xs].cpu().numpy().copy()
+    t_np, w_np = T[:1, :, zs, ys, xs].cpu().numpy().copy(), Wt[:1, :, zs, ys, xs].cpu().numpy().copy()
+    d = orc.desc_3d(e_np, NORM5)
+    o_affs, _ = orc.c_fwd(d, e_np, None, t_np, w_np, None)
+    # affs at a voxel depend on voxels at lower coordinates only: the window's map is the volume's map there
+    assert np.abs(a1[:1, :, zs, ys, xs].cpu().numpy() - o_affs).max() < AFFS_ATOL
