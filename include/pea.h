@@ -127,7 +127,8 @@ size_t pea_workspace_bytes(const PeaDesc *desc);
 int pea_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
 
 /* Re-read the PEA_* environment switches (they are read once, at the first call): PEA_FORCE_DIRECT, PEA_FWD_XDMA, PEA_BWD_XDMA,
- * PEA_LABELS_DUAL, PEA_FWD_WG3, PEA_INFER_XDMA, PEA_BWD_PF -- A/B and debugging switches; tests that change one call this. */
+ * PEA_LABELS_DUAL, PEA_FWD_WG3, PEA_INFER_XDMA, PEA_BWD_PF, PEA_BOX, PEA_H16_HW, PEA_ZMARCH, PEA_ZSEG, PEA_ZBLK_Y / _X, PEA_WALK2D,
+ * PEA_LDS_PAD -- A/B and debugging switches; tests that change one call this.  Memoised launch plans are dropped with it. */
 void pea_reload_env(void);
 
 /* Inference: affs[B,K,Z,Y,X] only.  e_other may be NULL. */

@@ -105,10 +105,15 @@ int run_fwd(const KParams& P, FwdArgs A, hipStream_t s) {
     A.inv_out = inv;
   }
   int rc = hip_rc();
-  if (rc) return rc;
-  if (A.train) {
+  if (!rc && A.train) {
     launch_loss_finish(P, A.st, A.loss_out, s);
     rc = hip_rc();
+  }
+  if (rc && A.train) {
+    // the state block must be ZERO between calls (pea_workspace_init's contract) and only the finish puts it back: after an error
+    // partials may have been queued without a finish -- prepare the block again, or every later loss on it would be offset
+    launch_loss_state_init(A.st, 1, s);
+    (void)hipGetLastError();
   }
   return rc;
 }

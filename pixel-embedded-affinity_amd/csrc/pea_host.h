@@ -5,7 +5,8 @@
 //   pea_k_xdma.hip     LDS-DMA cross kernels (pea_xdma.h): the training forward / backward of axis-aligned stencils
 //   pea_k_zmarch.hip   z-march kernels (pea_zmarch.h): 3D volumes with axis-aligned stencils that step along z (norm5 / norm1)
 //   pea_k_box.hip      unit-box stencils (pea_box.h): the 26-neighbourhood of a 3D volume through an LDS-DMA ring of 3-plane boxes
-//   pea_k_tiled.hip    LDS-tiled box kernels (pea_tiled.h, pea_chunked.h): diagonal stencils, f16 storage, inference
+//   pea_k_tiled.hip    LDS-tiled box kernels (pea_tiled.h, pea_chunked.h): what the cross / box / march kernels do not take -- diagonal
+//                      stencils wider than the unit box, unaligned tensors, X % 4 != 0, a second operand at D >= 32
 //   pea_k_labels.hip   the labels-in training step (pea_fused_labels.h) and the label-weight tables
 //   pea_k_direct.hip   global-memory kernels (pea_direct.h): the general fallback; loss finish; caller epilogues, stitcher
 //   pea_k_head.hip     the embedding head (pea_head.h) and target generation (pea_targets.h)
@@ -32,13 +33,15 @@ struct Env {
   int box;            // PEA_BOX=0: unit-box stencils (the 26-neighbourhood) on the tiled kernels instead of pea_box.h
   int zmarch;         // PEA_ZMARCH=0: 3D volumes with z offsets on the tile-per-plane cross kernels (pea_xdma.h) instead of the z-march
                       //   kernels (pea_zmarch.h); 2: the march also on volumes with fewer tile columns than CUs
+  int zm_nb;          // PEA_ZM_NB=4: the z-march backward with a ring of four buffers instead of three (measured: 2 % slower)
   int zseg;           // PEA_ZSEG=n: planes per segment of a tile column (0: whole columns where there are enough of them)
   int walk2d;         // PEA_WALK2D=n: 2D images walk strips of n tiles in x down y (0: row-major)
   int lds_pad;        // PEA_LDS_PAD=bytes: extra dynamic LDS on the cross kernels' launches (occupancy experiments)
   int zblk_y, zblk_x; // PEA_ZBLK_Y / PEA_ZBLK_X: tiles per block of the z-fastest walk of 3D volumes (0: the default 4 x 2; Y < 0: plane-major)
 };
 const Env& env();
-void env_reload();  // pea_reload_env(): tests that change a switch call it
+void env_reload();          // pea_reload_env(): tests that change a switch call it
+unsigned env_generation();  // bumped by every env_reload(): memoised plans that baked a switch in (PEA_ZBLK_*, PEA_WALK2D, ..) are dropped
 
 inline bool misaligned(const void* p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
 int& g_pending_error();  // per thread: an error met while preparing a launch (allow_lds), reported by the next hip_rc()
@@ -71,8 +74,13 @@ struct PlanCache {
   struct Ent { KParams key; int mode; bool ok, used; PLAN plan; };
   Ent ent[N] = {};
   int next = 0;
+  unsigned gen = 0;
   template <typename F>
   bool get(const KParams& P, int mode, PLAN* out, F&& make) {
+    if (gen != env_generation()) {  // a switch changed since these plans were made
+      for (int i = 0; i < N; ++i) ent[i].used = false;
+      gen = env_generation();
+    }
     for (int i = 0; i < N; ++i)
       if (ent[i].used && ent[i].mode == mode && memcmp(&ent[i].key, &P, sizeof(KParams)) == 0) {
         if (ent[i].ok) *out = ent[i].plan;

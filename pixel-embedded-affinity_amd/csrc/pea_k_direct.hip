@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -36,6 +37,7 @@ void env_load() {
   g_env.h16_hw = env_int("PEA_H16_HW", 1);
   g_env.zmarch = env_int("PEA_ZMARCH", 1);
   g_env.zseg = env_int("PEA_ZSEG", 0);
+  g_env.zm_nb = env_int("PEA_ZM_NB", 3);
   g_env.walk2d = env_int("PEA_WALK2D", 0);
   g_env.lds_pad = env_int("PEA_LDS_PAD", 0);
   g_env.zblk_y = env_int("PEA_ZBLK_Y", 0);
@@ -46,10 +48,13 @@ const Env& env() {
   std::call_once(g_env_once, env_load);
   return g_env;
 }
+namespace { std::atomic<unsigned> g_env_gen{1}; }
 void env_reload() {
   (void)env();
   env_load();
+  g_env_gen.fetch_add(1, std::memory_order_relaxed);
 }
+unsigned env_generation() { return g_env_gen.load(std::memory_order_relaxed); }
 
 // CUs of the CURRENT device (asked every time: the reference runs replicas under nn.DataParallel threads, one device each, so a
 // process-wide cache of the first device's answer would be wrong for the others)

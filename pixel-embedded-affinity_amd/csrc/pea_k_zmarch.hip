@@ -14,16 +14,20 @@ constexpr int kPSUF = 32;  // forward: the one-sided cross in 8 KB planes (48 KB
 struct ZPlan { XParams C; ZMParams M; size_t lds; };
 
 // mode 0: backward (both roles), 1: forward.  The tile walk of xdma_tile is reused with the SEGMENT in the place of z: blocks of
-// 8 x 4 tile columns (one XCD's 32 workgroups: a 128 x 128 pixel block whose halos are shared out of that XCD's L2), the
-// segments of a block one after the other.
+// tile columns (one XCD's 32 workgroups march through one block: its halos are shared out of that XCD's L2), the segments of a
+// block one after the other.
 bool plan(const KParams& P, int mode, ZPlan* out) {
   static thread_local PlanCache<ZPlan, 8> cache;
-  return cache.get(P, mode * 1024 + env().zmarch * 64 + env().zseg, out, [&](ZPlan* p) {
+  return cache.get(P, mode * 4096 + env().zm_nb * 1024 + env().zmarch * 64 + env().zseg, out, [&](ZPlan* p) {
     if (!env().zmarch || !plan_zmarch(P, &p->M)) return false;
     if (!plan_xdma(P, kTH, kTW, mode ? kPSUF : kPSUB, &p->C, &p->lds, mode)) return false;
     XParams& C = p->C;
     if (mode == 0 && (C.npx > 8 || C.npy > 8)) return false;
     if (mode == 1 && P.K > kXP + 2) return false;
+    // forward: a ring of eight buffers (16 planes) + the parked dot products [kXP + 2][tile] + the loss partials
+    if (mode == 1) p->lds = (size_t)16 * kPSUF * 256 + (size_t)(kXP + 2) * kTH * kTW * 4 + 256;
+    // backward: the ring of three (PEA_ZM_NB=4: four) two-plane buffers + the waves' blocks of prefetched g / a values
+    else p->lds = (size_t)2 * (env().zm_nb == 4 ? 4 : 3) * kPSUB * 256 + (size_t)(kTH * kTW / 64) * kZmG * 256;
     const long long cols = (long long)P.B * C.tiles_per_plane;
     // one workgroup per CU: whole columns when there are enough of them for two rounds, else segments of >= 8 planes
     int nseg = 1;
@@ -35,8 +39,11 @@ bool plan(const KParams& P, int mode, ZPlan* out) {
     p->M.zseg = (P.Z + nseg - 1) / nseg;
     p->M.nseg = (P.Z + p->M.zseg - 1) / p->M.zseg;
     C.zrun = p->M.nseg;
-    C.zgy = env().zblk_y > 0 ? env().zblk_y : 8;
-    C.zgx = env().zblk_x > 0 ? env().zblk_x : 4;
+    // blocks of 16 x 2 tile columns (256 rows x 64 pixels; an XCD's 32 workgroups = one block): measured best of nineteen shapes on
+    // the 24 x 1024^2 sub-volume -- 8 x 4 (the squarest) is 9 % / 3 % slower for forward / backward: with 32 tile columns across,
+    // every XCD then walks its own block ROW in step with the others, 512 KB apart (profiles/r4_zm_blocks.txt)
+    C.zgy = env().zblk_y > 0 ? env().zblk_y : 16;
+    C.zgx = env().zblk_x > 0 ? env().zblk_x : 2;
     const long long nt = cols * p->M.nseg;
     if (nt > 0x7fffff00LL) return false;
     C.ntiles = (int)nt;
@@ -91,8 +98,13 @@ bool zmarch_bwd(const KParams& P, const float* x, const float* inv, const float*
   ZPlan Z;
   if (!plan(P, 0, &Z)) return false;
   const dim3 grid((unsigned)(Z.C.tiles_per_xcd * kXcd)), blk(kTH * kTW);
-  constexpr auto kern = k_bwd_zm<kTH, kTW, kPSUB>;
-  PEA_LAUNCH(kern, grid, blk, Z.lds, s, P, Z.C, Z.M, x, inv, g, affs, dl, dx)
+  if (env().zm_nb == 4) {
+    constexpr auto kern = k_bwd_zm<kTH, kTW, kPSUB, 4>;
+    PEA_LAUNCH(kern, grid, blk, Z.lds, s, P, Z.C, Z.M, x, inv, g, affs, dl, dx)
+  } else {
+    constexpr auto kern = k_bwd_zm<kTH, kTW, kPSUB, 3>;
+    PEA_LAUNCH(kern, grid, blk, Z.lds, s, P, Z.C, Z.M, x, inv, g, affs, dl, dx)
+  }
   return true;
 }
 

@@ -1,6 +1,6 @@
 // pea_xdma.h -- backward for AXIS-ALIGNED in-plane stencils (every offset moves along y or along x only: the CVPPP /
 // BBBC039V1 multi_offset(neighbor=4) tables, the in-plane AC3/AC4 tables), the whole stencil served from LDS, staged by
-// LDS-DMA.  Included by pea_hip.hip only.
+// LDS-DMA.  Included by pea_k_xdma.hip (and, for the staging geometry and the tile walk, by pea_box.h / pea_zmarch.h).
 //
 // Why a second backward next to k_bwd_tiled (pea_tiled.h): that kernel stages a (TH+2h) x (TW+2h) BOX of 64-byte
 // pixels through registers; at h = 9 one 32x32 tile fills the CU's 160 KB (one workgroup per CU: staging, gather and

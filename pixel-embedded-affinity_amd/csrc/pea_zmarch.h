@@ -30,6 +30,15 @@ namespace pea {
 
 constexpr int kZS = 4;  // longest step along z the window covers
 
+// how many (neighbour, channel pair) LDS reads the compiler may batch in the gather loops (a fence every N pairs; 0: no fence).
+// Diagnostic builds (profiles/build_variant.sh) override them to A/B on one box.
+#ifndef PEA_ZMV_BFENCE
+#define PEA_ZMV_BFENCE 2
+#endif
+#ifndef PEA_ZMV_FFENCE
+#define PEA_ZMV_FFENCE 0
+#endif
+
 struct ZMParams {
   int zch[kZS];    // channel of the offset (-s, 0, 0), s = 1 .. kZS; -1: not in the table
   int zseg, nseg;  // planes per segment, segments per tile column
@@ -49,70 +58,143 @@ struct ZMParams {
 template <int JO, int D_>
 struct ZmSlot { static constexpr int v = ((JO - D_) % kZS + kZS) % kZS; };
 
-// one staged plane z of the segment: in-plane pairs from the LDS cross, z pairs from the window; finishes plane z - 4
-template <int JO, int TH, int TW, int PSU>
+// one staged plane z of the segment: in-plane pairs from the LDS cross, z pairs from the window; finishes plane z - 4.
+//
+// The ring never stops: a plane is NINE items -- I (its 1 / norm plane, one LDS plane) and the chunks C0 .. C7 -- for a ring of
+// NB = 3 or 4 buffers; item i of the plane whose step is JO (mod 4) lives in buffer (9 JO + i) mod NB (a compile-time constant: the
+// steps are unrolled four to a turn), and while an item is worked on, the NB - 1 behind it are in flight -- the last of a plane
+// already the NEXT plane's.  The g / a values a plane's coefficients are made of (16 in-plane pairs, 4 + 4 z values per lane) are
+// prefetched the same way: one-dword LDS-DMA into a private [value][lane] block per wave (no registers: the window leaves none),
+// requested together with the next plane's I.  Buffers beyond the 64 KB a ds_read immediate reaches get their addresses formed
+// per chunk.
+// Every staged plane issues the SAME sequence of vector-memory instructions per wave (planes beyond the volume, and the plane
+// after the last, are requested at out-of-range offsets; a gradient that is not due is stored at one), so the hand-offs are
+// literal s_waitcnt vmcnt(N), N = what may still fly behind the item waited for (zm_bwd_wait):
+//     item i: [2 stores of plane z - 4, i >= 1]; W_i: item i + 1 has landed; barrier; request item i + NB (of the next plane from
+//     i + NB >= 9 on; item 0 = I, 2 instructions, + G, 24)
+// NB = 4: W_I, W_0, W_1: 12; W_2 .. W_4, W_7: 14; W_5, W_6: 36.   NB = 3: 6, 6, 8 .. 8, W_6: 30, W_7: 8.
+// The first step requests its items 0 .. NB - 1 itself, with the stores a previous plane would have had in between.
+constexpr int kZmG = 24;  // prefetched values per lane: 8 + 8 in-plane pairs, 4 g and 4 a of the z offsets
+
+constexpr int zm_bwd_st(int j) { return ((j % 9) + 9) % 9 != 0 ? 2 : 0; }          // stores while item j is worked on
+constexpr int zm_bwd_sz(int m) { return ((m % 9) + 9) % 9 == 0 ? 2 + kZmG : 4; }   // instructions of the request of item m
+// vmcnt of W_i: everything issued after the request of item i + 1 (made after item i + 1 - NB) and before W_i
+constexpr int zm_bwd_wait(int NB, int i) {
+  int n = 0;
+  for (int j = i + 2 - NB; j <= i; ++j) n += zm_bwd_st(j);
+  for (int j = i + 2 - NB; j <= i - 1; ++j) n += zm_bwd_sz(j + NB);
+  return n;
+}
+static_assert(zm_bwd_wait(4, 0) == 12 && zm_bwd_wait(4, 3) == 14 && zm_bwd_wait(4, 6) == 36 && zm_bwd_wait(4, 7) == 36 &&
+              zm_bwd_wait(4, 8) == 14 && zm_bwd_wait(3, 0) == 6 && zm_bwd_wait(3, 1) == 6 && zm_bwd_wait(3, 2) == 8 &&
+              zm_bwd_wait(3, 7) == 30 && zm_bwd_wait(3, 8) == 8, "the hand-off counts derived by hand");
+
+template <int JO, int TH, int TW, int PSU, int NB>
 __device__ __forceinline__ void zm_bwd_full(const KParams& P, const XParams& C, const ZMParams& M, char* lds, const rsrc_t xB,
                                             const rsrc_t iB, const rsrc_t gB, const rsrc_t aB, const rsrc_t dB, const int z,
-                                            const bool fin, const float dl, const unsigned ecs, const unsigned YX4, const unsigned vo0,
-                                            const unsigned vo1, const int wbase, const int w1, const unsigned pe, const int px,
-                                            const int py, const int vown, const int (&ax)[8], const int (&ay)[8],
-                                            f2 (&Eh)[8][kZS], f2 (&Pd)[8][kZS], float (&prj)[kZS], float (&ivs)[kZS]) {
-  constexpr int PS = PSU * 256, NP = 8, XP = 8;
-  const unsigned ezo = (unsigned)z * YX4;
-  lds_barrier();  // every wave is done with the previous plane's last chunk: the ring is free
-  PEA_ZM_DMA(iB, 4 * PS, ezo)
-  PEA_ZM_DMA(xB, 0, ezo)
-  PEA_ZM_DMA(xB, PS, ezo + ecs)
-  // ---- g of every in-plane pair (role A at p, role B at p - o), of the z offsets (at p: both roles), and their raw cosines
-  // (the offsets are the same for every plane; derived from OPAQUE copies so that the compiler does not hoist all sixteen of them
-  //  out of the march and keep -- spill -- them: a few integer operations per load instead)
-  unsigned pe_o = pe;
-  int px_o = px, py_o = py;
-  asm volatile("" : "+v"(pe_o), "+v"(px_o), "+v"(py_o));
-  const unsigned pg = pe_o != kOOB ? pe_o : 0xC0000000u;  // dead lanes: stays out of range when a small displacement is added
-  float cx[XP], cy[XP];
-#pragma unroll
-  for (int k = 0; k < XP; ++k) {
-    const int go = C.xgo[k];
-    const bool out = (unsigned)(px_o + go) >= (unsigned)P.X;
-    cx[k] = bl32(gB, (k < C.npx && !out) ? pg + (unsigned)(go * 4) : kOOB, ezo + (unsigned)C.xgi[k] * ecs);
+                                            const bool first, const bool nxt, const bool fin, const float dl, const unsigned ecs,
+                                            const unsigned YX4, const unsigned vo0, const unsigned vo1, const int wbase, const int w1,
+                                            const int gwave, const int glane, const unsigned pe, const int px, const int py,
+                                            const int vown, const int (&ax)[8], const int (&ay)[8], f2 (&Eh)[8][kZS],
+                                            f2 (&Pd)[8][kZS], float (&prj)[kZS], float (&ivs)[kZS]) {
+  constexpr int PS = PSU * 256, NP = 8, XP = 8, GB = 2 * NB * PS;  // the g / a blocks sit behind the ring
+  constexpr int JN = (JO + 1) % 4;                                 // the next plane's step
+#define PEA_ZMB_BUF(jo_, item_) ((9 * (jo_) + (item_)) % NB)
+  const bool here = z < P.Z, there = nxt && z + 1 < P.Z;  // the plane / the next one exists (else: every request out of range)
+  const unsigned ezo = (unsigned)(here ? z : 0) * YX4;
+  const unsigned ezn = (unsigned)(there ? z + 1 : 0) * YX4;
+// one chunk (two planes) into ring buffer `buf`
+#define PEA_ZMB_CHUNK(buf, so_, v0_, v1_)                                                                                        \
+  {                                                                                                                              \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (2 * (buf)) * PS + wbase), 16, v0_, so_, 0, 0);               \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (2 * (buf)) * PS + w1), 16, v1_, so_, 0, 0);                  \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (2 * (buf) + 1) * PS + wbase), 16, v0_, (so_) + ecs, 0, 0);   \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (2 * (buf) + 1) * PS + w1), 16, v1_, (so_) + ecs, 0, 0);      \
   }
+// I (the 1 / norm plane, into plane 0 of buffer `buf`) and G (kZmG one-dword DMA instructions into the wave's block) of the plane
+// at plane offset so_; en_: the plane exists
+#define PEA_ZMB_IG(buf, so_, v0_, v1_, en_)                                                                                      \
+  {                                                                                                                              \
+    /* (per-lane offsets from OPAQUE copies made HERE, afresh for every four requests: hoisted to the top of the plane or out */ \
+    /*  of the march, or merely computed all at once ahead of the 24 requests, they would be kept -- spilled -- beside the    */ \
+    /*  window) */                                                                                                               \
+    unsigned pe_o = pe;                                                                                                          \
+    int px_o = px, py_o = py;                                                                                                    \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(iB, (lds_ptr_t)(lds + (2 * (buf)) * PS + wbase), 16, v0_, so_, 0, 0);               \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(iB, (lds_ptr_t)(lds + (2 * (buf)) * PS + w1), 16, v1_, so_, 0, 0);                  \
+    _Pragma("unroll") for (int k = 0; k < XP; ++k) {                                                                             \
+      if (k % 4 == 0) asm volatile("" : "+v"(pe_o), "+v"(px_o));                                                                 \
+      const unsigned pg = pe_o != kOOB ? pe_o : 0xC0000000u; /* dead lanes: out of range also with a displacement added */      \
+      const int go = C.xgo[k];                                                                                                   \
+      const bool out = (unsigned)(px_o + go) >= (unsigned)P.X;                                                                   \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(gB, (lds_ptr_t)(lds + GB + gwave + k * 256), 4,                                   \
+                                               ((en_) && k < C.npx && !out) ? pg + (unsigned)(go * 4) : kOOB,                    \
+                                               (so_) + (unsigned)C.xgi[k] * ecs, 0, 0);                                          \
+    }                                                                                                                            \
+    _Pragma("unroll") for (int k = 0; k < XP; ++k) {                                                                             \
+      if (k % 4 == 0) asm volatile("" : "+v"(pe_o), "+v"(py_o));                                                                 \
+      const unsigned pg = pe_o != kOOB ? pe_o : 0xC0000000u;                                                                     \
+      const int go = C.ygo[k];                                                                                                   \
+      const bool out = (unsigned)(py_o + go) >= (unsigned)P.Y;                                                                   \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(gB, (lds_ptr_t)(lds + GB + gwave + (XP + k) * 256), 4,                            \
+                                               ((en_) && k < C.npy && !out) ? pg + (unsigned)(go * P.X * 4) : kOOB,              \
+                                               (so_) + (unsigned)C.ygi[k] * ecs, 0, 0);                                          \
+    }                                                                                                                            \
+    asm volatile("" : "+v"(pe_o));                                                                                               \
+    _Pragma("unroll") for (int s = 0; s < kZS; ++s) {                                                                            \
+      const int ch = M.zch[s];                                                                                                   \
+      const unsigned vz = ((en_) && ch >= 0) ? pe_o : kOOB;                                                                      \
+      const unsigned sz = (so_) + (unsigned)(ch >= 0 ? ch : 0) * ecs;                                                            \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(gB, (lds_ptr_t)(lds + GB + gwave + (2 * XP + s) * 256), 4, vz, sz, 0, 0);         \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(aB, (lds_ptr_t)(lds + GB + gwave + (2 * XP + kZS + s) * 256), 4, vz, sz, 0, 0);   \
+    }                                                                                                                            \
+  }
+#define PEA_ZMB_ST2() \
+  { bs32<true>(dB, 0.f, kOOB, 0u); bs32<true>(dB, 0.f, kOOB, 0u); }
+// request item `it_` (0: I + G, else chunk it_ - 1) of the plane with step jo_ at plane offset so_
+#define PEA_ZMB_ITEM(jo_, it_, so_, v0_, v1_, en_)                                                                   \
+  {                                                                                                                  \
+    if ((it_) == 0) PEA_ZMB_IG(PEA_ZMB_BUF(jo_, 0), so_, v0_, v1_, en_)                                              \
+    else PEA_ZMB_CHUNK(PEA_ZMB_BUF(jo_, it_), (so_) + (unsigned)(2 * ((it_) - 1)) * ecs, v0_, v1_)                   \
+  }
+  const unsigned vh0 = here ? vo0 : kOOB, vh1 = here ? vo1 : kOOB;
+  if (first) {  // the pipeline's head: items 0 .. NB - 1
+#pragma unroll
+    for (int m = 0; m < NB - 1; ++m) {
+      PEA_ZMB_ITEM(JO, m, ezo, vh0, vh1, here)
+      PEA_ZMB_ST2()
+    }
+    PEA_ZM_WAIT(zm_bwd_wait(NB, 8));
+    PEA_ZMB_ITEM(JO, NB - 1, ezo, vh0, vh1, here)
+  }
+  // ---- I-proc: coefficient of a pair = g * 1 / |e(q)|, two pairs to a register pair (pk_fma_c selects the half)
+  constexpr int bI = PEA_ZMB_BUF(JO, 0);
+  constexpr int boI = (bI % 2) * 2 * PS;
+  int hiI = (bI / 2) * 4 * PS;
+  if (bI >= 2) asm volatile("" : "+v"(hiI));
+  const float invo = *(const float*)(lds + boI + (vown + hiI));
+  const float inv_own = fabsf(invo);
+  const char* gp = lds + GB + glane;
+  f2 ccx[XP / 2], ccy[XP / 2];
 #pragma unroll
   for (int k = 0; k < XP; ++k) {
-    const int go = C.ygo[k];
-    const bool out = (unsigned)(py_o + go) >= (unsigned)P.Y;
-    cy[k] = bl32(gB, (k < C.npy && !out) ? pg + (unsigned)(go * P.X * 4) : kOOB, ezo + (unsigned)C.ygi[k] * ecs);
+    const float vx = *(const float*)(gp + k * 256) * fabsf(*(const float*)(lds + boI + (ax[k] + hiI)));
+    const float vy = *(const float*)(gp + (XP + k) * 256) * fabsf(*(const float*)(lds + boI + (ay[k] + hiI)));
+    if (k & 1) { ccx[k / 2].y = vx; ccy[k / 2].y = vy; }
+    else { ccx[k / 2].x = vx; ccy[k / 2].x = vy; }
   }
   float gz[kZS], az[kZS];
 #pragma unroll
   for (int s = 0; s < kZS; ++s) {
-    const int ch = M.zch[s];
-    const unsigned vz = ch >= 0 ? pe_o : kOOB;
-    const unsigned so = ezo + (unsigned)(ch >= 0 ? ch : 0) * ecs;
-    gz[s] = bl32(gB, vz, so);
-    az[s] = bl32(aB, vz, so);
-  }
-  PEA_ZM_DMA(xB, 2 * PS, ezo + 2u * ecs)
-  PEA_ZM_DMA(xB, 3 * PS, ezo + 3u * ecs)
-  PEA_ZM_WAIT(4);  // inv, chunk 0, g, a have landed (chunk 1's four DMA instructions may still fly)
-  const float invo = *(const float*)(lds + 4 * PS + vown);
-  const float inv_own = fabsf(invo);
-  // coefficient of a pair = g * 1 / |e(q)|, two pairs to a register pair (pk_fma_c selects the half: hipcc would otherwise keep
-  // every coefficient twice, as (f2){c, c})
-  f2 ccx[XP / 2], ccy[XP / 2];
-#pragma unroll
-  for (int k = 0; k < XP; ++k) {
-    const float vx = cx[k] * fabsf(*(const float*)(lds + 4 * PS + ax[k]));
-    const float vy = cy[k] * fabsf(*(const float*)(lds + 4 * PS + ay[k]));
-    if (k & 1) { ccx[k / 2].y = vx; ccy[k / 2].y = vy; }
-    else { ccx[k / 2].x = vx; ccy[k / 2].x = vy; }
+    gz[s] = *(const float*)(gp + (2 * XP + s) * 256);
+    az[s] = *(const float*)(gp + (2 * XP + kZS + s) * 256);
   }
 #pragma unroll
   for (int k = 0; k < XP / 2; ++k) asm volatile("" : "+v"(ccx[k]), "+v"(ccy[k]));
   const f2 gz01 = {gz[0], gz[1]}, gz23 = {gz[2], gz[3]};
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the inv plane is dead: buffer 2 may be filled
-  PEA_ZM_DMA(xB, 4 * PS, ezo + 4u * ecs)
-  PEA_ZM_DMA(xB, 5 * PS, ezo + 5u * ecs)
+  PEA_ZM_WAIT(zm_bwd_wait(NB, 0));  // W_I: C0 has landed; the 1 / norm plane is dead: its buffer may be filled
+  const unsigned vn0 = there ? vo0 : kOOB, vn1 = there ? vo1 : kOOB;
+  PEA_ZMB_ITEM(JO, NB, ezo, vh0, vh1, here)
   // <ehat, G> of the pending planes: role B of plane z - d through offset d is g_d(z) a_d(z)
   float projF = prj[JO] + gz[kZS - 1] * az[kZS - 1];
   prj[ZmSlot<JO, 1>::v] = fmaf(gz[0], az[0], prj[ZmSlot<JO, 1>::v]);
@@ -120,32 +202,35 @@ __device__ __forceinline__ void zm_bwd_full(const KParams& P, const XParams& C, 
   prj[ZmSlot<JO, 3>::v] = fmaf(gz[2], az[2], prj[ZmSlot<JO, 3>::v]);
   if (ivs[JO] < 0.f) projF = 0.f;  // clamp branch of F.normalize
   const float scF = fabsf(ivs[JO]) * dl;
-  const unsigned pf = fin ? pe_o : kOOB;
+  const unsigned pf = fin ? pe : kOOB;
   const unsigned fzo = (unsigned)(fin ? z - kZS : 0) * YX4;
   float pcur = 0.f;
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
-    const int bo = (ps % 3) * 2 * PS;
+    const int buf = PEA_ZMB_BUF(JO, ps + 1);  // compile-time after unrolling
+    const int bo = (buf % 2) * 2 * PS;
+    int hi = (buf / 2) * 4 * PS;
+    if (buf >= 2) asm volatile("" : "+v"(hi));
     f2 o;
-    o.x = *(const float*)(lds + bo + vown);
-    o.y = *(const float*)(lds + bo + PS + vown);
+    o.x = *(const float*)(lds + bo + (vown + hi));
+    o.y = *(const float*)(lds + bo + PS + (vown + hi));
     o = o * inv_own;
     f2 acc = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < XP; ++k) {
       f2 v;
-      v.x = *(const float*)(lds + bo + ax[k]);
-      v.y = *(const float*)(lds + bo + PS + ax[k]);
+      v.x = *(const float*)(lds + bo + (ax[k] + hi));
+      v.y = *(const float*)(lds + bo + PS + (ax[k] + hi));
       acc = (k & 1) ? pk_fma_c<true>(ccx[k / 2], v, acc) : pk_fma_c<false>(ccx[k / 2], v, acc);
-      if (k % 2 == 1) asm volatile("" ::: "memory");  // bound the ds_read hoisting
+      if (k % PEA_ZMV_BFENCE == PEA_ZMV_BFENCE - 1) asm volatile("" ::: "memory");  // bound the ds_read hoisting
     }
 #pragma unroll
     for (int k = 0; k < XP; ++k) {
       f2 v;
-      v.x = *(const float*)(lds + bo + ay[k]);
-      v.y = *(const float*)(lds + bo + PS + ay[k]);
+      v.x = *(const float*)(lds + bo + (ay[k] + hi));
+      v.y = *(const float*)(lds + bo + PS + (ay[k] + hi));
       acc = (k & 1) ? pk_fma_c<true>(ccy[k / 2], v, acc) : pk_fma_c<false>(ccy[k / 2], v, acc);
-      if (k % 2 == 1) asm volatile("" ::: "memory");
+      if (k % PEA_ZMV_BFENCE == PEA_ZMV_BFENCE - 1) asm volatile("" ::: "memory");
     }
     // z pairs, role A: the window (the slot of plane z - 4 is JO itself)
     acc = pk_fma_c<false>(gz01, Eh[ps][ZmSlot<JO, 1>::v], acc);
@@ -165,108 +250,24 @@ __device__ __forceinline__ void zm_bwd_full(const KParams& P, const XParams& C, 
     Pd[ps][JO] = acc;
     Eh[ps][JO] = o;
     asm volatile("" : "+v"(Pd[ps][JO]), "+v"(Eh[ps][JO]), "+v"(pcur));  // the chunk's sums exist before its barrier
-    if (ps + 1 < NP) {
-      // chunk ps + 1 has landed; what may still fly: the DMA of chunk ps + 2 (4) and this chunk's two stores
-      if (ps + 2 < NP) PEA_ZM_WAIT(6);
-      else PEA_ZM_WAIT(2);
-      if (ps + 3 < NP) {
-        PEA_ZM_DMA(xB, bo, ezo + (unsigned)(2 * ps + 6) * ecs)
-        PEA_ZM_DMA(xB, bo + PS, ezo + (unsigned)(2 * ps + 7) * ecs)
-      }
-    }
+    // the next item has landed; everyone is done with this buffer; refill it with the item NB behind
+    PEA_ZM_WAIT(zm_bwd_wait(NB, ps + 1));
+    if (ps + 1 + NB < 9) PEA_ZMB_ITEM(JO, ps + 1 + NB, ezo, vh0, vh1, here)
+    else PEA_ZMB_ITEM(JN, ps + 1 + NB - 9, ezn, vn0, vn1, there)
   }
   prj[JO] = pcur;
   ivs[JO] = invo;
-}
-
-// a plane that is not staged: warm-up (z < zb: fills the window), contributor (ze <= z < Z: role B into the pending planes) or
-// drain (z >= Z: nothing to add); finishes plane z - 4 where that is a plane of the segment.  The own pixel is taken in two halves
-// of eight channels (a fence between them): sixteen loaded values on top of the window do not fit the register file.
-template <int JO>
-__device__ __forceinline__ void zm_bwd_light(const KParams& P, const ZMParams& M, const rsrc_t xB, const rsrc_t iB, const rsrc_t gB,
-                                             const rsrc_t aB, const rsrc_t dB, const int z, const int zb, const int ze, const float dl,
-                                             const unsigned ecs, const unsigned YX4, const unsigned pe, f2 (&Eh)[8][kZS],
-                                             f2 (&Pd)[8][kZS], float (&prj)[kZS], float (&ivs)[kZS]) {
-  constexpr int NP = 8, HP = NP / 2;
-  const bool exists = z >= 0 && z < P.Z;  // uniform
-  unsigned pe_o = pe;
-  asm volatile("" : "+v"(pe_o));
-  const unsigned pz = exists ? pe_o : kOOB;
-  const unsigned ezo = (unsigned)(exists ? z : 0) * YX4;
-  const float invo = bl32(iB, pz, ezo);
-  const float inv_own = fabsf(invo);
-  if (z < zb) {  // warm-up: the window only
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      f2 o[HP];
-#pragma unroll
-      for (int q = 0; q < HP; ++q) {
-        o[q].x = bl32(xB, pz, ezo + (unsigned)(2 * (h * HP + q)) * ecs);
-        o[q].y = bl32(xB, pz, ezo + (unsigned)(2 * (h * HP + q) + 1) * ecs);
-      }
-#pragma unroll
-      for (int q = 0; q < HP; ++q) {
-        Eh[h * HP + q][JO] = o[q] * inv_own;
-        Pd[h * HP + q][JO] = (f2){0.f, 0.f};
-      }
-      asm volatile("" ::: "memory");
-    }
-    prj[JO] = 0.f;
-    ivs[JO] = invo;
-    return;
-  }
-  float gz[kZS], az[kZS];
-#pragma unroll
-  for (int s = 0; s < kZS; ++s) {
-    const int ch = M.zch[s];
-    const unsigned vz = ch >= 0 ? pz : kOOB;
-    const unsigned so = ezo + (unsigned)(ch >= 0 ? ch : 0) * ecs;
-    gz[s] = bl32(gB, vz, so);
-    az[s] = bl32(aB, vz, so);
-  }
-  float projF = prj[JO] + gz[kZS - 1] * az[kZS - 1];
-  prj[ZmSlot<JO, 1>::v] = fmaf(gz[0], az[0], prj[ZmSlot<JO, 1>::v]);
-  prj[ZmSlot<JO, 2>::v] = fmaf(gz[1], az[1], prj[ZmSlot<JO, 2>::v]);
-  prj[ZmSlot<JO, 3>::v] = fmaf(gz[2], az[2], prj[ZmSlot<JO, 3>::v]);
-  if (ivs[JO] < 0.f) projF = 0.f;
-  const float scF = fabsf(ivs[JO]) * dl;
-  const f2 gz01 = {gz[0], gz[1]}, gz23 = {gz[2], gz[3]};
-  const int zf = z - kZS;
-  const bool fin = zf >= zb && zf < ze;
-  const unsigned pf = fin ? pe_o : kOOB;
-  const unsigned fzo = (unsigned)(fin ? zf : 0) * YX4;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    f2 o[HP];
-#pragma unroll
-    for (int q = 0; q < HP; ++q) {
-      o[q].x = bl32(xB, pz, ezo + (unsigned)(2 * (h * HP + q)) * ecs);
-      o[q].y = bl32(xB, pz, ezo + (unsigned)(2 * (h * HP + q) + 1) * ecs);
-    }
-#pragma unroll
-    for (int q = 0; q < HP; ++q) {
-      const int ps = h * HP + q;
-      const f2 oh = o[q] * inv_own;
-      Pd[ps][ZmSlot<JO, 1>::v] = pk_fma_c<false>(gz01, oh, Pd[ps][ZmSlot<JO, 1>::v]);
-      Pd[ps][ZmSlot<JO, 2>::v] = pk_fma_c<true>(gz01, oh, Pd[ps][ZmSlot<JO, 2>::v]);
-      Pd[ps][ZmSlot<JO, 3>::v] = pk_fma_c<false>(gz23, oh, Pd[ps][ZmSlot<JO, 3>::v]);
-      const f2 Gf = pk_fma_c<true>(gz23, oh, Pd[ps][JO]);
-      const float vx = (Gf.x - Eh[ps][JO].x * projF) * scF, vy = (Gf.y - Eh[ps][JO].y * projF) * scF;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), dB, pf, fzo + (unsigned)(2 * ps) * ecs, kAuxNT);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), dB, pf, fzo + (unsigned)(2 * ps + 1) * ecs, kAuxNT);
-      Pd[ps][JO] = (f2){0.f, 0.f};
-      Eh[ps][JO] = oh;
-    }
-    asm volatile("" ::: "memory");
-  }
-  prj[JO] = 0.f;
-  ivs[JO] = invo;
+#undef PEA_ZMB_CHUNK
+#undef PEA_ZMB_IG
+#undef PEA_ZMB_ST2
+#undef PEA_ZMB_ITEM
+#undef PEA_ZMB_BUF
 }
 
 // xt: e [B, 16, S]; invp: its signed 1 / norm plane [B, S] (the forward's); gin: d loss / d affs [B, K, S]; affs: the RAW cosines
 // [B, K, S] (only the z channels are read).  C: plan_xdma mode 0 with the tile walk set up by the host (zrun = nseg: xdma_tile's
 // "z" is the segment).  Grid: tiles_per_xcd * 8 workgroups of TH * TW lanes, ONE per CU (launch bounds: 2 waves per SIMD).
-template <int TH, int TW, int PSU>
+template <int TH, int TW, int PSU, int NB>
 __global__ __launch_bounds__(TH* TW, 2) void k_bwd_zm(const KParams P, const XParams C, const ZMParams M, const float* __restrict__ xt,
                                                        const float* __restrict__ invp, const float* __restrict__ gin,
                                                        const float* __restrict__ affs, const float* __restrict__ dloss,
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(TH* TW, 2) void k_bwd_zm(const KParams P, const XPa
     ax[k] = (unsigned)c < (unsigned)TW ? vown + d * 4 : hrow + (c & C.xm[k]) * 4;
     ay[k] = vown + C.yd[k] * TW * 4;
   }
+  const int gwave = wave * (kZmG * 256), glane = gwave + lane * 4;  // the wave's block of prefetched g / a values: [value][lane]
   f2 Eh[8][kZS], Pd[8][kZS];
   float prj[kZS], ivs[kZS];
 #pragma unroll
@@ -332,29 +334,44 @@ __global__ __launch_bounds__(TH* TW, 2) void k_bwd_zm(const KParams P, const XPa
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) { Eh[ps][j] = (f2){0.f, 0.f}; Pd[ps][j] = (f2){0.f, 0.f}; }
   }
-#define PEA_ZM_STEP(JO_, zz)                                                                                                   \
-  {                                                                                                                            \
-    const int z_ = (zz);                                                                                                       \
-    if (z_ < ze + kZS) {                                                                                                       \
-      if (z_ >= zb && z_ < ze)                                                                                                 \
-        zm_bwd_full<JO_, TH, TW, PSU>(P, C, M, lds, xB, iB, gB, aB, dB, z_, z_ - kZS >= zb, dl, ecs, YX4, vo0, vo1, wbase, w1, \
-                                      pe, px, py, vown, ax, ay, Eh, Pd, prj, ivs);                                             \
-      else if (z_ >= 0 || z_ >= zb)                                                                                            \
-        zm_bwd_light<JO_>(P, M, xB, iB, gB, aB, dB, z_, zb, ze, dl, ecs, YX4, pe, Eh, Pd, prj, ivs);                           \
-    }                                                                                                                          \
+  // Every step is a staged plane, four steps to a turn with NO branch between them (any other control flow between the steps made
+  // the register allocator copy the window at the joins: 44 - 426 spilled registers).  The steps run from zs = max(zb - 4, 0) --
+  // the segment's warm-up planes, staged like any other, their gradients not stored -- to at least ze + 3: planes ze .. ze + 3 are
+  // the contributors (role B into the segment's last planes) and, where they lie beyond the volume (every request out of range:
+  // zeros), the drain; the step count is rounded up to a multiple of four with more such empty planes.
+  const int zs = max(zb - kZS, 0);
+  const int zt = zs + (ze + kZS - zs + 3) / 4 * 4;
+#define PEA_ZM_FULL(JO_, zz)                                                                                                     \
+  zm_bwd_full<JO_, TH, TW, PSU, NB>(P, C, M, lds, xB, iB, gB, aB, dB, (zz), (zz) == zs, (zz) + 1 < zt, (zz) - kZS >= zb && (zz) - kZS < ze, \
+                                dl, ecs, YX4, vo0, vo1, wbase, w1, gwave, glane, pe, px, py, vown, ax, ay, Eh, Pd, prj, ivs);
+  for (int z = zs; z < zt; z += 4) {
+    PEA_ZM_FULL(0, z)
+    PEA_ZM_FULL(1, z + 1)
+    PEA_ZM_FULL(2, z + 2)
+    PEA_ZM_FULL(3, z + 3)
   }
-  for (int zq = zb - kZS; zq < ze + kZS; zq += kZS) {
-    PEA_ZM_STEP(0, zq)
-    PEA_ZM_STEP(1, zq + 1)
-    PEA_ZM_STEP(2, zq + 2)
-    PEA_ZM_STEP(3, zq + 3)
-  }
-#undef PEA_ZM_STEP
+#undef PEA_ZM_FULL
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last plane's look-ahead DMA (out-of-range: zeros) has drained
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // forward (training: affs, g, loss, the 1 / norm plane; inference: affs)
 // ------------------------------------------------------------------------------------------------------------------
+// LDS: a ring of EIGHT two-channel buffers (16 planes of PS bytes = one plane's eight chunks: chunk c lives in buffer c in every
+// plane) that never stops: while chunk c of plane z is gathered, the seven chunks behind it are in flight -- chunks c + 1 .. 7 of
+// this plane and 0 .. c - 1 of the NEXT.  (One workgroup per CU has nobody to hide its latency behind: what it keeps in flight is
+// what it gets.  A ring of four buffers -- 48 KB in flight -- staged the sub-volume's 6 GB at 4.9 TB/s = 1.15 ms before a single
+// output byte; PMC: waves parked 49 % of their cycles, TA 55 % busy.)  The K dot products are parked in their own [K][tile pixel]
+// array behind the ring.  The upper four buffers lie beyond the 64 KB a ds_read immediate reaches: their addresses are formed per
+// chunk (one add per read; hoisted out of the march they would cost eleven registers beside the window).
+// Every staged plane issues the SAME sequence of vector-memory instructions per wave (absent operands and the plane after the last
+// are requested at an out-of-range offset), so every hand-off is a literal s_waitcnt vmcnt(N):
+//     T  : 3 * ITEMS loads (target, weight, mask quads of the plane's items)
+//     c  : gather chunk c; wait W_c for chunk c + 1; barrier; 4 DMA instructions: chunk c of the NEXT plane into the same buffer
+//     E  : 1 + 2 * ITEMS stores (the 1 / norm plane, affs and g quads)
+// W_c, c <= 6, waits for DMA issued in the previous plane: behind it are the chunks c + 2 .. 7 of this plane, E (7), T (9) and the
+// chunks 0 .. c - 1 of the next: six chunks (24) + 16 -> vmcnt(40); W_7 (chunk 0 of the next plane): six chunks -> vmcnt(24).
+// The first plane of a segment issues its eight chunks and a dummy E itself.
 template <int TH, int TW, int PSU, bool TRAIN>
 __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XParams C, const ZMParams M, const float* __restrict__ e,
                                                        const float* __restrict__ target, const float* __restrict__ weight,
@@ -362,13 +379,14 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
                                                        float* __restrict__ gout, LossState* __restrict__ st,
                                                        float* __restrict__ inv_out) {
   constexpr int D_T = 16, NT = TH * TW, PS = PSU * 256, NP = D_T / 2, TP = NT, QP = TP / 4, NSL = QP / 64;
-  constexpr int KMAX = kXP + 2, ITEMS = (KMAX * QP + NT - 1) / NT;
+  constexpr int KMAX = kXP + 2, ITEMS = (KMAX * QP + NT - 1) / NT, RING = 16 * PS;
+  constexpr int NLD = 3 * ITEMS, NST = 1 + 2 * ITEMS;  // T, E
   static_assert(TW == 32 && QP % 64 == 0, "lane mapping");
-  static_assert(KMAX * TP * 4 + KMAX * NSL * 4 <= 6 * PS && KMAX <= kXK, "the parked dot products fit the ring");
+  static_assert(KMAX <= kXK && 8 * PS == 65536, "the lower four buffers end where the ds_read immediate does");
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
-  float* sA = (float*)lds;                        // [K][TP] dot products, laid over the ring once a plane's chunks are done
-  float* s_part = (float*)(lds + KMAX * TP * 4);  // [K][NSL]
+  float* sA = (float*)(lds + RING);                      // [K][TP] dot products of the plane
+  float* s_part = (float*)(lds + RING + KMAX * TP * 4);  // [K][NSL]
   int tile, b, seg, y0, x0;
   if (!xdma_tile<TH, TW>(C, P, tile, b, seg, y0, x0)) return;
   const int zb = seg * M.zseg, ze = min(zb + M.zseg, P.Z);
@@ -448,6 +466,20 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) W[ps][j] = (f2){0.f, 0.f};
   }
+  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // the loss: lane k < K of wave 0 sums the workgroup's partials of offset k over the planes it marches through (a fixed order:
+  // bit-reproducible) and adds the sum to the integer accumulators ONCE at the end -- per plane, the 128-bit conversion and the
+  // atomics made wave 0 late for the next plane's first barrier, and reading the partials cost a barrier of its own
+  const bool lane_k = wave == 0 && (int)threadIdx.x < P.K;
+  float lacc = 0.f;
+// the DMA of one chunk (two planes) into ring buffer `buf`, from plane offset `so_`, with the given per-lane offsets
+#define PEA_ZMF_CHUNK(buf, so_, v0_, v1_)                                                                                       \
+  {                                                                                                                              \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (2 * (buf)) * PS + wbase), 16, v0_, so_, 0, 0);               \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (2 * (buf)) * PS + w1), 16, v1_, so_, 0, 0);                  \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (2 * (buf) + 1) * PS + wbase), 16, v0_, (so_) + ecs, 0, 0);   \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (2 * (buf) + 1) * PS + w1), 16, v1_, (so_) + ecs, 0, 0);      \
+  }
 
 #define PEA_ZMF_STEP(JO, zz)                                                                                                   \
   {                                                                                                                            \
@@ -466,62 +498,63 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
         }                                                                                                                      \
       } else {                                                                                                                 \
         const unsigned ezo = (unsigned)z * YX4;                                                                                \
-        lds_barrier(); /* the previous plane's epilogue is done with sA / s_part: the ring is free */                         \
-        PEA_ZM_DMA(xB, 0, ezo)                                                                                                 \
-        PEA_ZM_DMA(xB, PS, ezo + ecs)                                                                                          \
-        PEA_ZM_DMA(xB, 2 * PS, ezo + 2u * ecs)                                                                                 \
-        PEA_ZM_DMA(xB, 3 * PS, ezo + 3u * ecs)                                                                                 \
-        PEA_ZM_WAIT(4);                                                                                                        \
-        PEA_ZM_DMA(xB, 4 * PS, ezo + 4u * ecs)                                                                                 \
-        PEA_ZM_DMA(xB, 5 * PS, ezo + 5u * ecs)                                                                                 \
+        const bool first = z == zb, nxt = z + 1 < ze;                                                                          \
+        const unsigned ezn = (unsigned)(nxt ? z + 1 : z) * YX4;                                                                \
+        const unsigned vn0 = nxt ? vo0 : kOOB, vn1 = nxt ? vo1 : kOOB;                                                         \
+        if (first) { /* the pipeline's head: the plane's eight chunks, and the E a previous plane would have issued */         \
+          _Pragma("unroll") for (int c = 0; c < NP; ++c) PEA_ZMF_CHUNK(c, ezo + (unsigned)(2 * c) * ecs, vo0, vo1)             \
+          bs32(iB, 0.f, kOOB, 0u);                                                                                             \
+          _Pragma("unroll") for (int it = 0; it < ITEMS; ++it) { bs128<true>(aB, zero4, kOOB, 0u); bs128<false>(gB, zero4, kOOB, 0u); } \
+        }                                                                                                                      \
+        /* T: target / weight / mask of the plane's items: they land while the chunks are gathered */                        \
+        f4 t4[ITEMS], w4[ITEMS];                                                                                               \
+        unsigned m4[ITEMS];                                                                                                    \
+        _Pragma("unroll") for (int it = 0; it < ITEMS; ++it) {                                                                 \
+          const unsigned so = ezo + (unsigned)isl[it] * ecs;                                                                   \
+          const unsigned vt = TRAIN ? ivo[it] : kOOB;                                                                          \
+          t4[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(tB, vt, so, kAuxNT));                          \
+          w4[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wB, vt, so, kAuxNT));                          \
+          const unsigned mm = __builtin_amdgcn_raw_buffer_load_b32(mB, (!has_m || vt == kOOB) ? kOOB : vt >> 2,                \
+                                                                   (ezo >> 2) + (unsigned)isl[it] * (unsigned)P.S, kAuxNT);    \
+          m4[it] = has_m ? mm : 0x01010101u;                                                                                   \
+        }                                                                                                                      \
+        if (first) PEA_ZM_WAIT(28 + NST + NLD); /* chunk 0 has landed (chunks 1 - 7, the dummy E and T may fly) */            \
         f2 dot[kXP], ssq[kXP], dz[kZS], oss = {0.f, 0.f};                                                                      \
         _Pragma("unroll") for (int k = 0; k < kXP; ++k) { dot[k] = (f2){0.f, 0.f}; ssq[k] = (f2){0.f, 0.f}; }                  \
         _Pragma("unroll") for (int k = 0; k < kZS; ++k) dz[k] = (f2){0.f, 0.f};                                                \
         _Pragma("unroll") for (int ps = 0; ps < NP; ++ps) {                                                                    \
-          const int bo = (ps % 3) * 2 * PS;                                                                                    \
+          const int bo = (ps % 4) * 2 * PS;                                                                                    \
+          int hi = ps >= 4 ? 8 * PS : 0; /* the upper four buffers: beyond the immediate's reach */                           \
+          if (ps >= 4) asm volatile("" : "+v"(hi));                                                                            \
           f2 o;                                                                                                                \
-          o.x = *(const float*)(lds + bo + vown);                                                                              \
-          o.y = *(const float*)(lds + bo + PS + vown);                                                                         \
+          o.x = *(const float*)(lds + bo + (vown + hi));                                                                       \
+          o.y = *(const float*)(lds + bo + PS + (vown + hi));                                                                  \
           oss = __builtin_elementwise_fma(o, o, oss);                                                                          \
           _Pragma("unroll") for (int k = 0; k < kXP; ++k) {                                                                    \
             f2 v;                                                                                                              \
-            v.x = *(const float*)(lds + bo + an[k]);                                                                           \
-            v.y = *(const float*)(lds + bo + PS + an[k]);                                                                      \
+            v.x = *(const float*)(lds + bo + (an[k] + hi));                                                                    \
+            v.y = *(const float*)(lds + bo + PS + (an[k] + hi));                                                               \
             dot[k] = __builtin_elementwise_fma(o, v, dot[k]);                                                                  \
             ssq[k] = __builtin_elementwise_fma(v, v, ssq[k]);                                                                  \
-            if (k % 5 == 4) asm volatile("" ::: "memory");                                                                     \
+            if (PEA_ZMV_FFENCE && k % (PEA_ZMV_FFENCE ? PEA_ZMV_FFENCE : 1) == (PEA_ZMV_FFENCE ? PEA_ZMV_FFENCE : 1) - 1)      \
+              asm volatile("" ::: "memory");                                                                                   \
           }                                                                                                                    \
           _Pragma("unroll") for (int j = 0; j < kZS; ++j) dz[j] = __builtin_elementwise_fma(o, W[ps][j], dz[j]);               \
           W[ps][JO] = o;                                                                                                       \
           _Pragma("unroll") for (int k = 0; k < kXP; ++k) asm volatile("" : "+v"(dot[k]), "+v"(ssq[k]));                       \
           _Pragma("unroll") for (int j = 0; j < kZS; ++j) asm volatile("" : "+v"(dz[j]));                                      \
           asm volatile("" : "+v"(oss), "+v"(W[ps][JO]));                                                                       \
-          if (ps + 1 < NP) {                                                                                                   \
-            if (ps + 2 < NP) PEA_ZM_WAIT(4);                                                                                   \
-            else PEA_ZM_WAIT(0);                                                                                               \
-            if (ps + 3 < NP) {                                                                                                 \
-              PEA_ZM_DMA(xB, bo, ezo + (unsigned)(2 * ps + 6) * ecs)                                                           \
-              PEA_ZM_DMA(xB, bo + PS, ezo + (unsigned)(2 * ps + 7) * ecs)                                                      \
-            }                                                                                                                  \
-          }                                                                                                                    \
-        }                                                                                                                      \
-        /* target / weight / mask of the plane's items, requested now: they land while the dot products are parked */        \
-        f4 t4[ITEMS], w4[ITEMS];                                                                                               \
-        unsigned m4[ITEMS];                                                                                                    \
-        if (TRAIN) {                                                                                                           \
-          _Pragma("unroll") for (int it = 0; it < ITEMS; ++it) {                                                               \
-            const unsigned so = ezo + (unsigned)isl[it] * ecs;                                                                 \
-            t4[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(tB, ivo[it], so, kAuxNT));                   \
-            w4[it] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wB, ivo[it], so, kAuxNT));                   \
-            m4[it] = has_m ? __builtin_amdgcn_raw_buffer_load_b32(mB, ivo[it] == kOOB ? kOOB : ivo[it] >> 2,                   \
-                                                                 (ezo >> 2) + (unsigned)isl[it] * (unsigned)P.S, kAuxNT)       \
-                           : 0x01010101u;                                                                                      \
-          }                                                                                                                    \
+          /* the next chunk has landed (W_c); everyone is done with this buffer; refill it with the next plane's chunk */   \
+          if (ps < 7) PEA_ZM_WAIT(24 + NST + NLD);                                                                             \
+          else PEA_ZM_WAIT(24);                                                                                                \
+          PEA_ZMF_CHUNK(ps, ezn + (unsigned)(2 * ps) * ecs, vn0, vn1)                                                          \
+          if (TRAIN && ps == 0 && !first && lane_k) { /* the PREVIOUS plane's loss partials: behind this barrier they are all */ \
+            _Pragma("unroll") for (int s = 0; s < NSL; ++s) lacc += s_part[threadIdx.x * NSL + s]; /* written (no barrier of */ \
+          }                                                                                        /* their own)            */ \
         }                                                                                                                      \
         const float osum = oss.x + oss.y;                                                                                      \
         const float inv_own = rnorm(osum, inv_eps);                                                                            \
-        if (has_i) bs32(iB, osum < P.eps * P.eps ? -inv_own : inv_own, pe, ezo);                                               \
-        lds_barrier(); /* every lane is done with the ring: sA goes over it */                                                 \
+        bs32(iB, osum < P.eps * P.eps ? -inv_own : inv_own, has_i ? pe : kOOB, ezo); /* E, 1 of NST */                         \
         _Pragma("unroll") for (int k = 0; k < kXP; ++k) {                                                                      \
           if (k < C.nf) {                                                                                                      \
             float a = (dot[k].x + dot[k].y) * inv_own * rnorm(ssq[k].x + ssq[k].y, inv_eps);                                   \
@@ -534,47 +567,36 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
           const int ch = M.zch[s - 1];                                                                                         \
           if (ch >= 0) {                                                                                                       \
             const int jj = ((JO - s) % kZS + kZS) % kZS;                                                                       \
-            const float a = z - s >= 0 ? (dz[jj].x + dz[jj].y) * inv_own * iw[jj] : 0.f;                                      \
+            const float a = z - s >= 0 ? (dz[jj].x + dz[jj].y) * inv_own * iw[jj] : 0.f;                                       \
             sA[ch * TP + (int)threadIdx.x] = a;                                                                                \
           }                                                                                                                    \
         }                                                                                                                      \
         iw[JO] = inv_own;                                                                                                      \
         lds_barrier();                                                                                                         \
-        _Pragma("unroll") for (int it = 0; it < ITEMS; ++it) {                                                                 \
-          if (!ion[it]) continue;                                                                                              \
+        _Pragma("unroll") for (int it = 0; it < ITEMS; ++it) { /* E: two stores per item, issued whether or not it is live */ \
           const int sl = isl[it];                                                                                              \
           const f4 a4 = *(const f4*)(sA + sl * TP + iqd[it] * 4);                                                              \
           const unsigned so = ezo + (unsigned)sl * ecs;                                                                        \
-          if (has_a) {                                                                                                         \
-            f4 o4 = a4;                                                                                                        \
-            if (af) { o4.x = act_affs(o4.x, af); o4.y = act_affs(o4.y, af); o4.z = act_affs(o4.z, af); o4.w = act_affs(o4.w, af); } \
-            bs128<true>(aB, o4, ivo[it], so);                                                                                  \
+          f4 o4 = a4;                                                                                                          \
+          if (af) { o4.x = act_affs(o4.x, af); o4.y = act_affs(o4.y, af); o4.z = act_affs(o4.z, af); o4.w = act_affs(o4.w, af); } \
+          bs128<true>(aB, o4, (has_a && ion[it]) ? ivo[it] : kOOB, so);                                                        \
+          float acc = 0.f;                                                                                                     \
+          f4 g4;                                                                                                               \
+          const float gs = C.gs[sl];                                                                                           \
+          const int ax_ = C.oax[sl], od_ = C.od[sl];                                                                           \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
+            const float m = (float)((m4[it] >> (8 * j)) & 0xffu);                                                              \
+            const float r = a4[j] * m - t4[it][j] * m;                                                                         \
+            float wr = w4[it][j] * r;                                                                                          \
+            const int q = (ax_ == 1 ? igx[it] + j : ax_ == 0 ? igy[it] : z) + od_;                                             \
+            wr = (unsigned)q < (unsigned)(ax_ == 1 ? P.X : ax_ == 0 ? P.Y : P.Z) ? wr : 0.f;                                   \
+            g4[j] = gs * wr * m;                                                                                               \
+            acc = fmaf(wr, r, acc);                                                                                            \
           }                                                                                                                    \
-          if (TRAIN) {                                                                                                         \
-            float acc = 0.f;                                                                                                   \
-            f4 g4;                                                                                                             \
-            const float gs = C.gs[sl];                                                                                         \
-            const int ax_ = C.oax[sl], od_ = C.od[sl];                                                                         \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
-              const float m = (float)((m4[it] >> (8 * j)) & 0xffu);                                                            \
-              const float r = a4[j] * m - t4[it][j] * m;                                                                       \
-              float wr = w4[it][j] * r;                                                                                        \
-              const int q = (ax_ == 1 ? igx[it] + j : ax_ == 0 ? igy[it] : z) + od_;                                           \
-              wr = (unsigned)q < (unsigned)(ax_ == 1 ? P.X : ax_ == 0 ? P.Y : P.Z) ? wr : 0.f;                                 \
-              g4[j] = gs * wr * m;                                                                                             \
-              acc = fmaf(wr, r, acc);                                                                                          \
-            }                                                                                                                  \
-            if (has_g) bs128<false>(gB, g4, ivo[it], so);                                                                      \
+          bs128<false>(gB, g4, (TRAIN && has_g && ion[it]) ? ivo[it] : kOOB, so);                                              \
+          if (TRAIN && ion[it]) {                                                                                              \
             const float red = wave_sum63(acc);                                                                                 \
             if ((threadIdx.x & 63) == 63) s_part[sl * NSL + (iqd[it] >> 6)] = red;                                             \
-          }                                                                                                                    \
-        }                                                                                                                      \
-        if (TRAIN) {                                                                                                           \
-          lds_barrier();                                                                                                       \
-          if (wave == 0 && (int)threadIdx.x < P.K) {                                                                           \
-            float v = 0.f;                                                                                                     \
-            _Pragma("unroll") for (int s = 0; s < NSL; ++s) v += s_part[threadIdx.x * NSL + s];                                \
-            loss_accumulate(st, tile + z, threadIdx.x, v);                                                                     \
           }                                                                                                                    \
         }                                                                                                                      \
       }                                                                                                                        \
@@ -587,6 +609,16 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
     PEA_ZMF_STEP(3, zq + 3)
   }
 #undef PEA_ZMF_STEP
+#undef PEA_ZMF_CHUNK
+  if (TRAIN) {
+    lds_barrier();  // the last plane's partials
+    if (lane_k) {
+#pragma unroll
+      for (int s = 0; s < NSL; ++s) lacc += s_part[threadIdx.x * NSL + s];
+      loss_accumulate(st, tile, threadIdx.x, lacc);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last plane's look-ahead DMA (out-of-range: zeros) has drained
 }
 
 #undef PEA_ZM_DMA

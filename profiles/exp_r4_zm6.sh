@@ -1,0 +1,6 @@
+#!/bin/bash
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd $ROOT && mkdir -p gpurun_out
+timeout -k 10 600 python -m pytest tests/test_gpu_zmarch.py -x -q -m gpu 2>&1 | tail -5
+python profiles/exp_zm.py 2>&1 | grep -v amdgpu.ids
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu 2>&1 | tail -8
