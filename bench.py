@@ -360,6 +360,9 @@ def pmc_traffic(key, dom):
         return None
     tj = json.load(open(tpath))
     rec = tj.get(key, {}).get(dom)
+    # (recorded with the default switches: under a PEA_* override another kernel may run)
+    if any(k.startswith("PEA_") for k in os.environ):
+        return None
     return rec.get("bytes_per_launch") if rec and tj.get("src_sha16") == source_sha16() else None
 
 
@@ -678,7 +681,7 @@ def main():
         launch_bytes = ab[dom] * B * H * W
         achieved = launch_bytes / (kt[dom] * 1e-3) / 1e9
         step_gbs = ab["step"] * B * H * W / ((kt["fwd"] + kt["bwd"]) * 1e-3) / 1e9
-        traffic = pmc_traffic("c2", dom) if B == B_PER_GPU else None
+        traffic = pmc_traffic("c2" if B == B_PER_GPU else "c2b%d" % B, dom)  # (a key per batch size: profiles/r4_final_pmc.sh)
         out = {
             "metric": "affinity-map Mpixels/sec (fwd+bwd)", "value": round(value, 2), "unit": "Mpx/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),

@@ -33,8 +33,10 @@ struct Env {
   int box;            // PEA_BOX=0: unit-box stencils (the 26-neighbourhood) on the tiled kernels instead of pea_box.h
   int zmarch;         // PEA_ZMARCH=0: 3D volumes with z offsets on the tile-per-plane cross kernels (pea_xdma.h) instead of the z-march
                       //   kernels (pea_zmarch.h); 2: the march also on volumes with fewer tile columns than CUs
+  int boxm;           // PEA_BOXM=0: the unit-box backward per (z, tile) (pea_box.h) instead of marching (pea_boxm.h)
   int zm_nb;          // PEA_ZM_NB=4: the z-march backward with a ring of four buffers instead of three (measured: 2 % slower)
   int zseg;           // PEA_ZSEG=n: planes per segment of a tile column (0: whole columns where there are enough of them)
+  int xcd_stagger;    // PEA_XCD_STAGGER=1: the eight XCDs start at different points of their tile ranges (cross kernels)
   int walk2d;         // PEA_WALK2D=n: 2D images walk strips of n tiles in x down y (0: row-major)
   int lds_pad;        // PEA_LDS_PAD=bytes: extra dynamic LDS on the cross kernels' launches (occupancy experiments)
   int zblk_y, zblk_x; // PEA_ZBLK_Y / PEA_ZBLK_X: tiles per block of the z-fastest walk of 3D volumes (0: the default 4 x 2; Y < 0: plane-major)

@@ -1,7 +1,9 @@
 // pea_k_box.hip -- launchers of the unit-box kernels (pea_box.h): the 26-neighbourhood of BASELINE.json configs[3] and its subsets.
 // One translation unit of libpea_hip.so (pea_host.h).
+#include <algorithm>
+
 #include "pea_host.h"
-#include "pea_box.h"
+#include "pea_boxm.h"
 
 namespace pea {
 
@@ -58,11 +60,40 @@ bool box_fwd(const KParams& P, const FwdArgs& A, hipStream_t s) {
   return true;
 }
 
+// the marching backward (pea_boxm.h): CROP_ZERO volumes with enough tile columns for the CUs (PEA_ZMARCH=2: any); false = not taken
+static bool box_bwd_march(const KParams& P, const BParams& C0, const float* x, const float* inv, const float* g, const float* dl,
+                          float* dx, hipStream_t s) {
+  if (!env().zmarch || P.border != PEA_BORDER_CROP_ZERO || P.Z < 3) return false;
+  if ((long long)P.D * P.S * 4 >= (1LL << 31)) return false;  // channel distance + plane offset in one 32-bit offset
+  const long long cols = (long long)P.B * C0.tiles_per_plane;
+  int nseg = 1;
+  if (env().zseg > 0) nseg = (P.Z + env().zseg - 1) / env().zseg;
+  else if (cols < 2 * device_cus()) nseg = (int)std::min<long long>((2 * device_cus() + cols - 1) / cols, std::max(1, P.Z / 6));
+  if (env().zmarch < 2 && cols * nseg < device_cus()) return false;
+  BMParams M;
+  M.zseg = (P.Z + nseg - 1) / nseg;
+  M.nseg = (P.Z + M.zseg - 1) / M.zseg;
+  BParams C = C0;
+  C.zrun = M.nseg;  // xdma_tile's "z" is the segment; blocks of tile columns per XCD as in pea_k_zmarch.hip
+  C.zgy = env().zblk_y > 0 ? env().zblk_y : 16;
+  C.zgx = env().zblk_x > 0 ? env().zblk_x : 2;
+  const long long nt = cols * M.nseg;
+  if (nt > 0x7fffff00LL) return false;
+  C.ntiles = (int)nt;
+  C.tiles_per_xcd = (C.ntiles + kXcd - 1) / kXcd;
+  const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kBoxTH * kBoxTW);
+  constexpr auto kern = k_bwd_boxm;
+  if (allow_lds<kern>(kBmLds)) return false;
+  hipLaunchKernelGGL(kern, grid, blk, kBmLds, s, P, C, M, x, inv, g, dl, dx);
+  return true;
+}
+
 bool box_bwd(const KParams& P, const float* x, const float* inv, const float* g, const float* dl, float* dx, hipStream_t s) {
   if (P.D != 16 || !inv || !env().box || env().force_direct) return false;
   if (misaligned(x, 16) || misaligned(inv, 16) || misaligned(g, 4) || misaligned(dx, 4)) return false;
   BParams C;
   if (!plan(P, &C)) return false;
+  if (env().boxm && box_bwd_march(P, C, x, inv, g, dl, dx, s)) return true;
   const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kBoxTH * kBoxTW);
   if (P.border != PEA_BORDER_CIRCULAR) {
     constexpr auto kern = k_bwd_box<16, true>;

@@ -27,6 +27,7 @@ bool plan(const KParams& P, int psu, int mode, XPlan* out) {
     if (env().zblk_x > 0) p->C.zgx = env().zblk_x;
     if (env().zblk_y < 0) p->C.zrun = 0;  // plane-major walk
     if (P.Z == 1 && env().walk2d > 0) { p->C.zrun = 1; p->C.zgy = p->C.tiles_y; p->C.zgx = env().walk2d; }
+    p->C.stagger = env().xcd_stagger;
     p->lds += (size_t)env().lds_pad;
     return true;
   });

@@ -81,6 +81,7 @@ struct XParams {
   int npz;                 // backward: (offset, role) pairs along z
   int zd[kXZ];             // plane displacement of the neighbour
   int zgi[kXZ], zgo[kXZ];  // g channel; plane displacement of the g sample (role A: 0, role B: -oz)
+  int stagger;             // the XCDs start at different points of their tile ranges (xdma_tile)
   int zrun;                // > 1: tiles walk z fastest (= Z), so the planes a z offset reaches were staged just before
   int zgy, zgx;            // ... inside blocks of zgy x zgx tiles
   // forward (role A only): in-plane offsets in their own order (nf <= kXP), z offsets (nfz <= kXZ / 2)
@@ -119,7 +120,11 @@ __global__ __launch_bounds__(256) void k_inv_norm(const KParams P, const T* __re
 template <int TH, int TW, typename CP = XParams>
 __device__ __forceinline__ bool xdma_tile(const CP& C, const KParams& P, int& tile, int& b, int& z, int& y0, int& x0) {
   const int bid = blockIdx.x;
-  const int lin = (bid % kXcd) * C.tiles_per_xcd + bid / kXcd;
+  int slot = bid / kXcd;
+  // stagger (PEA_XCD_STAGGER): XCD g starts g / 8 of the way into its tile range and wraps -- with one image per XCD the eight XCDs
+  // otherwise request the same position of eight images at the same time, a fixed distance apart
+  if (C.stagger) { slot += (bid % kXcd) * (C.tiles_per_xcd / kXcd); slot -= slot >= C.tiles_per_xcd ? C.tiles_per_xcd : 0; }
+  const int lin = (bid % kXcd) * C.tiles_per_xcd + slot;
   if (lin >= C.ntiles) return false;
   int plane, rem;
   if (C.zrun >= 1) {

@@ -1,11 +1,12 @@
 #!/bin/bash
 # bash profiles/pmc_cfg.sh <tag> <config> [passes...]: PMC passes over `bench.py --config <config>` (few steps), per-kernel averages
+# (PEA_BENCH_EXTRA: more bench.py arguments, e.g. "--batch 32")
 TAG=$1; CFG=$2; shift; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 run() {
   OUT=$ROOT/gpurun_out/pmcc_${TAG}_$1; rm -rf $OUT; mkdir -p $OUT
-  timeout -k 5 200 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT -o r -- python3 $ROOT/bench.py --config $CFG --steps 4 --warmup 2 --no-cpu-baseline --no-train --no-section > $OUT/log.txt 2>&1 || echo "FAILED/timeout: $2"
+  timeout -k 5 200 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT -o r -- python3 $ROOT/bench.py --config $CFG --steps 4 --warmup 2 --no-cpu-baseline --no-train --no-section $PEA_BENCH_EXTRA > $OUT/log.txt 2>&1 || echo "FAILED/timeout: $2"
   python3 - $OUT $TAG <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict

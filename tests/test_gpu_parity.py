@@ -151,6 +151,28 @@ def test_full_size_cvppp_against_reference_summary(pkg, dev, synth):
     assert abs((gr.astype(np.float64) ** 2).sum() / float(g["grad_sq"]) - 1) < 1e-4
 
 
+@pytest.mark.parametrize("K", [8, 10])
+def test_baseline_config0_single_image(pkg, dev, orc, synth, K):
+    """BASELINE configs[0] taken literally: ONE 544 x 544 image (530 x 500 padded), 16-dim embedding, the first 8 affinity offsets
+    (`offsets[:8]`) and the shipped 10, forward + backward -- the whole image against the C oracle (one image is
+    a quarter of a second of CPU), and inference against the same map"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)[:K]
+    B, D, H, W = 1, 16, 544, 544
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 77)
+    et = cu(e, dev).requires_grad_(True)
+    loss, affs, all_loss = pkg.embedding_loss(et, cu(t, dev), cu(w, dev), cu(m, dev), pkg.WeightedMSE(), offsets)
+    loss.backward()
+    inf = pkg.embedding2affs(et.detach(), offsets)
+    d = orc.desc_2d(e, offsets)
+    o_affs, o_loss = orc.c_fwd(d, e, None, t, w, m)
+    o_grad, _ = orc.c_bwd(d, e, None, t, w, m)
+    assert np.abs(affs.cpu().numpy() - o_affs.reshape(affs.shape)).max() < AFFS_ATOL
+    assert np.abs(inf.cpu().numpy() - o_affs.reshape(affs.shape)).max() < AFFS_ATOL
+    assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+    np.testing.assert_allclose(np.array(list(all_loss)), o_loss[1:], rtol=LOSS_RTOL)
+    assert relmax(et.grad.cpu().numpy(), o_grad.reshape(e.shape)) < GRAD_RTOL
+
+
 def test_baseline_config_b8_properties(pkg, dev, synth):
     """BASELINE configs[1]: B=8, D=16, 544x544, K=10 -- size-independent properties instead of a CPU re-run:
     run-to-run bit reproducibility, linearity of the gradient in dloss, batch additivity of the loss
