@@ -74,9 +74,12 @@ static bool box_bwd_march(const KParams& P, const BParams& C0, const float* x, c
   M.zseg = (P.Z + nseg - 1) / nseg;
   M.nseg = (P.Z + M.zseg - 1) / M.zseg;
   BParams C = C0;
-  C.zrun = M.nseg;  // xdma_tile's "z" is the segment; blocks of tile columns per XCD as in pea_k_zmarch.hip
-  C.zgy = env().zblk_y > 0 ? env().zblk_y : 16;
-  C.zgx = env().zblk_x > 0 ? env().zblk_x : 2;
+  // xdma_tile's "z" is the segment; an XCD's 32 workgroups march through one block of 4 x 8 tile columns (measured on the
+  // 24 x 1024^2 sub-volume: 4 x 8 and 4 x 4 1.82 ms, 8 x 4 and 16 x 4 1.88, 16 x 2 -- the norm5 march's best -- 1.91, 32 x 1 2.25;
+  // the region here has a halo of 1 - 4 pixels, not 27: what matters is that the blocks of the eight XCDs are spread out)
+  C.zrun = M.nseg;
+  C.zgy = env().zblk_y > 0 ? env().zblk_y : 4;
+  C.zgx = env().zblk_x > 0 ? env().zblk_x : 8;
   const long long nt = cols * M.nseg;
   if (nt > 0x7fffff00LL) return false;
   C.ntiles = (int)nt;

@@ -14,6 +14,8 @@ st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 offs = aff.axis_offsets_3d(aff.NORM5_SHIFTS)
 if os.environ.get("STENCIL") == "norm1":
     offs = [[-1, 0, 0], [0, -1, 0], [0, 0, -1]]
+if os.environ.get("STENCIL") == "n26":
+    offs = [[dz, dy, dx] for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dz, dy, dx) != (0, 0, 0)]
 Z, Y, X = (int(v) for v in os.environ.get("DIMS", "24,1024,1024").split(","))
 B, K = int(os.environ.get("B", "1")), len(offs)
 iters = int(os.environ.get("ITERS", "6"))
@@ -58,6 +60,14 @@ for tag in [t for t in os.environ.get("VARIANTS", "").split(",") if t]:  # diagn
         run(kn, "(variant %s)" % tag)
     lm.SO_PATH, lm._lib = keep
     L = keep[1]
+if os.environ.get("STENCIL") == "n26":
+    pkg._lib.set_switch("PEA_BOXM", "0"); run("bwd", "(PEA_BOXM=0: the per-(z, tile) box backward)")
+    pkg._lib.set_switch("PEA_BOXM", None); run("bwd", "(marching again)")
+    for gy, gx in [(8, 4), (4, 8), (16, 4), (32, 1), (4, 4)]:
+        pkg._lib.set_switch("PEA_ZBLK_Y", gy); pkg._lib.set_switch("PEA_ZBLK_X", gx)
+        run("bwd", "(block %d x %d)" % (gy, gx))
+    pkg._lib.set_switch("PEA_ZBLK_Y", None); pkg._lib.set_switch("PEA_ZBLK_X", None)
+    sys.exit(0)
 if os.environ.get("AB", "1") == "1":  # the same box, the same buffers: the alternatives
     pkg._lib.set_switch("PEA_ZM_NB", "4"); run("bwd", "(PEA_ZM_NB=4: ring of four buffers)")
     pkg._lib.set_switch("PEA_ZM_NB", None); run("bwd", "(ring of three again)")

@@ -143,3 +143,44 @@ def test_zmarch_reruns_are_bit_identical_and_dloss_is_linear(pkg, dev, orc, synt
     o_affs, _ = orc.c_fwd(d, e_np, None, t_np, w_np, None)
     # affs at a voxel depend on voxels at lower coordinates only: the window's map is the volume's map there
     assert np.abs(a1[:1, :, zs, ys, xs].cpu().numpy() - o_affs).max() < AFFS_ATOL
+
+
+N26 = [[dz, dy, dx] for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dz, dy, dx) != (0, 0, 0)]
+
+
+@pytest.mark.parametrize("shape,zseg,stencil", [((1, 7, 40, 72), 0, "n26"), ((2, 5, 33, 64), 2, "n26"), ((1, 9, 48, 36), 3, "n26"),
+                                                ((1, 6, 40, 40), 0, "half13"), ((2, 4, 17, 36), 1, "n26"), ((1, 8, 50, 68), 5, "diag4")])
+def test_box_march_backward_vs_oracle(pkg, dev, orc, synth, monkeypatch, shape, zseg, stencil):
+    """the unit-box backward marching along z with all 16 channels of three planes resident in LDS (csrc/pea_boxm.h): the
+    26-neighbourhood of BASELINE configs[3], the 13 offsets of its lower half, four diagonals across planes; whole columns and
+    segments of 1 - 5 planes; ragged tiles; the smallest volume the box kernels take (17 x 36) -- against the C oracle and against
+    the per-(z, tile) kernel it replaces on large volumes (PEA_BOXM=0)"""
+    B, Z, Y, X = shape
+    offs = {"n26": N26, "half13": N26[:13], "diag4": [[-1, -1, -1], [-1, 1, 1], [1, -1, 1], [0, 1, -1]]}[stencil]
+    K = len(offs)
+    monkeypatch.setenv("PEA_ZMARCH", "2")
+    if zseg:
+        monkeypatch.setenv("PEA_ZSEG", str(zseg))
+    e, t, w = synth.synth_inputs_3d(B, 16, Z, Y, X, offs, 41 + Z)
+    e[0, :, Z // 2, 3, 5] = 0.0          # zero-norm pixels: the clamp branch
+    e[-1, :, 0, Y - 1, X - 1] = 1e-14
+    op = pkg.affinity_op
+    spec = op.AffinitySpec(3, offs, None, pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
+
+    def run():
+        et = cu(e, dev).requires_grad_(True)
+        loss, affs, parts = op.FusedAffinityMSE.apply(et, None, cu(t, dev), cu(w, dev), None, spec)
+        (loss * 0.5).backward()
+        return loss.item(), affs.cpu().numpy(), et.grad.cpu().numpy()
+
+    l1, a1, g1 = run()
+    d = orc.make_desc(B, 16, [Z, Y, X], offs, None, orc.BORDER_CROP_ZERO, orc.NORM_CROPPED)
+    o_affs, o_loss = orc.c_fwd(d, e, None, t, w, None)
+    o_grad, _ = orc.c_bwd(d, e, None, t, w, None, dloss=0.5)
+    assert np.abs(a1 - o_affs.reshape(a1.shape)).max() < AFFS_ATOL
+    assert abs(l1 - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+    assert relmax(g1, o_grad.reshape(g1.shape)) < GRAD_RTOL
+    monkeypatch.setenv("PEA_BOXM", "0")
+    l2, a2, g2 = run()
+    assert l1 == l2 and np.array_equal(a1, a2)      # the same forward kernel
+    assert relmax(g1, g2) < 2e-6                    # the same sums in another order
