@@ -14,7 +14,8 @@
 //   * the 26 coefficient sums g_{o = d}(p) + g_{o = -d}(p + d) of the NEXT plane are requested into registers when a plane starts
 //     (52 loads per lane; there is no window here, so the registers exist) and land while the eight pairs are gathered.
 //   * hand-offs: before B1 a wave waits until only the 52 g loads may fly (vmcnt(52): the planes requested at the previous B2 are
-//     older); before B2 until only the 16 stores of this plane may (vmcnt(16): the planes requested at B1 are older).
+//     older); before B2 for everything (vmcnt(0): the planes requested at B1 are the youngest loads -- the 16 gradient stores of
+//     the plane are issued BEHIND B2, because a store may retire before an older load and must not be counted on).
 // A unit (one pair's plane: 360 quads) is moved by one exec-masked dwordx4 LDS-DMA instruction per wave, 45 lanes each (every wave
 // issues the same count); the 1 / norm plane (180 quads) by 23 lanes per wave.
 // Gather form, no state across planes: a column may be cut into segments without warm-up or drain.  CROP_ZERO border only (a plane
@@ -131,17 +132,19 @@ __host__ __device__ constexpr int boxm_lds(int s) {
       if (invo < 0.f) proj = 0.f; /* clamp branch of F.normalize */                                                           \
       const float sc = dl * inv_own;                                                                                           \
       const unsigned pe = live ? (unsigned)((z * P.Y + py) * P.X + px) * 4u : kOOB;                                            \
+      /* B2: pairs 4 - 7 are done with plane z - 1; what was requested at B1 has landed: no load is younger than it (the      */ \
+      /* gradient stores follow the barrier: a store may retire before an older load, so none may sit between a request and the */ \
+      /* wait that counts on it -- pea_zmarch.h zm_bwd_wait)                                                                    */ \
+      PEA_BM_WAIT(0);                                                                                                          \
+      PEA_BM_UNIT(4, z + 2, (J + 2) % 3)                                                                                       \
+      PEA_BM_UNIT(5, z + 2, (J + 2) % 3)                                                                                       \
+      PEA_BM_UNIT(6, z + 2, (J + 2) % 3)                                                                                       \
+      PEA_BM_UNIT(7, z + 2, (J + 2) % 3)                                                                                       \
       _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                          \
         const float vx = (G[c].x - eh[c].x * proj) * sc, vy = (G[c].y - eh[c].y * proj) * sc;                                  \
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), dB, pe, (unsigned)(2 * c) * ecs, kAuxNT);      \
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), dB, pe, (unsigned)(2 * c + 1) * ecs, kAuxNT);  \
       }                                                                                                                        \
-      /* B2: pairs 4 - 7 are done with plane z - 1; what was requested at B1 has landed (this plane's 16 stores may fly) */   \
-      PEA_BM_WAIT(16);                                                                                                         \
-      PEA_BM_UNIT(4, z + 2, (J + 2) % 3)                                                                                       \
-      PEA_BM_UNIT(5, z + 2, (J + 2) % 3)                                                                                       \
-      PEA_BM_UNIT(6, z + 2, (J + 2) % 3)                                                                                       \
-      PEA_BM_UNIT(7, z + 2, (J + 2) % 3)                                                                                       \
     }                                                                                                                          \
   }
 

@@ -34,7 +34,7 @@ struct Env {
   int zmarch;         // PEA_ZMARCH=0: 3D volumes with z offsets on the tile-per-plane cross kernels (pea_xdma.h) instead of the z-march
                       //   kernels (pea_zmarch.h); 2: the march also on volumes with fewer tile columns than CUs
   int boxm;           // PEA_BOXM=0: the unit-box backward per (z, tile) (pea_box.h) instead of marching (pea_boxm.h)
-  int zm_nb;          // PEA_ZM_NB=4: the z-march backward with a ring of four buffers instead of three (measured: 2 % slower)
+  int zm_nb;          // PEA_ZM_NB=3: the z-march backward with a ring of three buffers instead of four (5 % slower once the waits count loads only)
   int zseg;           // PEA_ZSEG=n: planes per segment of a tile column (0: whole columns where there are enough of them)
   int xcd_stagger;    // PEA_XCD_STAGGER=1: the eight XCDs start at different points of their tile ranges (cross kernels)
   int walk2d;         // PEA_WALK2D=n: 2D images walk strips of n tiles in x down y (0: row-major)

@@ -37,7 +37,7 @@ void env_load() {
   g_env.h16_hw = env_int("PEA_H16_HW", 1);
   g_env.zmarch = env_int("PEA_ZMARCH", 1);
   g_env.zseg = env_int("PEA_ZSEG", 0);
-  g_env.zm_nb = env_int("PEA_ZM_NB", 3);
+  g_env.zm_nb = env_int("PEA_ZM_NB", 4);
   g_env.boxm = env_int("PEA_BOXM", 1);
   g_env.xcd_stagger = env_int("PEA_XCD_STAGGER", 0);
   g_env.walk2d = env_int("PEA_WALK2D", 0);

@@ -26,8 +26,8 @@ bool plan(const KParams& P, int mode, ZPlan* out) {
     if (mode == 1 && P.K > kXP + 2) return false;
     // forward: a ring of eight buffers (16 planes) + the parked dot products [kXP + 2][tile] + the loss partials
     if (mode == 1) p->lds = (size_t)16 * kPSUF * 256 + (size_t)(kXP + 2) * kTH * kTW * 4 + 256;
-    // backward: the ring of three (PEA_ZM_NB=4: four) two-plane buffers + the waves' blocks of prefetched g / a values
-    else p->lds = (size_t)2 * (env().zm_nb == 4 ? 4 : 3) * kPSUB * 256 + (size_t)(kTH * kTW / 64) * kZmG * 256;
+    // backward: the ring of four (PEA_ZM_NB=3: three) two-plane buffers + the waves' blocks of prefetched g / a values
+    else p->lds = (size_t)2 * (env().zm_nb == 3 ? 3 : 4) * kPSUB * 256 + (size_t)(kTH * kTW / 64) * kZmG * 256;
     const long long cols = (long long)P.B * C.tiles_per_plane;
     // one workgroup per CU: whole columns when there are enough of them for two rounds, else segments of >= 8 planes
     int nseg = 1;
@@ -98,11 +98,11 @@ bool zmarch_bwd(const KParams& P, const float* x, const float* inv, const float*
   ZPlan Z;
   if (!plan(P, 0, &Z)) return false;
   const dim3 grid((unsigned)(Z.C.tiles_per_xcd * kXcd)), blk(kTH * kTW);
-  if (env().zm_nb == 4) {
-    constexpr auto kern = k_bwd_zm<kTH, kTW, kPSUB, 4>;
+  if (env().zm_nb == 3) {
+    constexpr auto kern = k_bwd_zm<kTH, kTW, kPSUB, 3>;
     PEA_LAUNCH(kern, grid, blk, Z.lds, s, P, Z.C, Z.M, x, inv, g, affs, dl, dx)
   } else {
-    constexpr auto kern = k_bwd_zm<kTH, kTW, kPSUB, 3>;
+    constexpr auto kern = k_bwd_zm<kTH, kTW, kPSUB, 4>;
     PEA_LAUNCH(kern, grid, blk, Z.lds, s, P, Z.C, Z.M, x, inv, g, affs, dl, dx)
   }
   return true;

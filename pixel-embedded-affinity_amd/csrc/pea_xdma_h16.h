@@ -283,14 +283,13 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
       eh[ps] = o;
       asm volatile("" : "+v"(eh[ps]));
     }
-    if (PF) {  // this chunk's two channels are final
-#ifdef PEA_ABL_H_NOSTORE
-      if (acc.x == 12345.f)
-#endif
-      {
-        bs_emb<__half, true>(dB, (acc.x - o.x * proj) * inv_own * dl, ph, hzo + (unsigned)(2 * ps) * hcs);
-        bs_emb<__half, true>(dB, (acc.y - o.y * proj) * inv_own * dl, ph, hzo + (unsigned)(2 * ps + 1) * hcs);
-      }
+    float sx = 0.f, sy = 0.f;
+    if (PF) {  // this chunk's two channels are final; stored BEHIND the hand-off below: a store issued just before a counted wait is
+               // still in flight when the wait is reached, and stores cannot be counted on (pea_xdma_pf.h) -- behind it, it has a
+               // whole chunk's time to retire before the next one
+      sx = (acc.x - o.x * proj) * inv_own * dl;
+      sy = (acc.y - o.y * proj) * inv_own * dl;
+      asm volatile("" : "+v"(sx), "+v"(sy));
     } else {
       if (!KEEP) {
         proj = fmaf(o.x, acc.x, fmaf(o.y, acc.y, proj));
@@ -301,17 +300,20 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
     }
     if (ps + 1 < NP) {
       // everyone is done with the working buffer and with ring buffer ps % 3; chunk ps + 1 has landed (chunk ps + 2 and, PF, the
-      // stores of the last two chunks may still fly: vmcnt retires in order, pea_xdma_pf.h)
-      const int nd = ps + 2 < NP ? 1 : 0, ns = PF ? 2 * (ps + 1 < 2 ? ps + 1 : 2) : 0;
-#ifdef PEA_ABL_H_NOSTORE
+      // stores of the last chunks are not counted on, pea_xdma_pf.h)
+      // (loads only: a store may retire before an older load, pea_xdma_pf.h)
+      const int nd = ps + 2 < NP ? 1 : 0;
       pf_wait(nd * npc);
-#else
-      pf_wait(nd * npc + ns);
-#endif
 #ifndef PEA_ABL_H_NODMA
       if (ps + 3 < NP) PEA_HDMA16(ps % 3, 2 * ps + 6)
 #endif
     }
+#ifndef PEA_ABL_H_NOSTORE
+    if (PF) {
+      bs_emb<__half, true>(dB, sx, ph, hzo + (unsigned)(2 * ps) * hcs);
+      bs_emb<__half, true>(dB, sy, ph, hzo + (unsigned)(2 * ps + 1) * hcs);
+    }
+#endif
   }
 #undef PEA_HDMA16
 

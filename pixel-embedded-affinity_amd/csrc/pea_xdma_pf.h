@@ -24,8 +24,9 @@
 namespace pea {
 
 // s_waitcnt vmcnt(n) lgkmcnt(0); s_barrier for an n that is a constant only after the chunk loop is unrolled (the immediate of
-// s_waitcnt has to be a literal: a switch the optimiser folds).  vmcnt retires IN ORDER: younger than the chunk that has to have
-// landed are the DMA of the chunks after it and the gradient stores issued since (2 per chunk, by every lane: a static count).
+// s_waitcnt has to be a literal: a switch the optimiser folds).  LOADS retire in order: n = the DMA instructions of the chunks
+// after the one that has to have landed.  (Rounds 3 counted the gradient stores issued since as well; a store may retire before
+// an older load, so that count was unsound -- round 4, pea_zmarch.h zm_bwd_wait.)
 __device__ __forceinline__ void pf_wait(int n) {
 #define PEA_PFW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
   switch (n) {
@@ -178,20 +179,22 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_pf(const KParams P, co
     }
     // this chunk's two channels are final: (G - ehat <ehat, G>) dl / n
     const float pq = proj * inv_own;
-    const float vx = (acc.x - o.x * pq) * sc, vy = (acc.y - o.y * pq) * sc;
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), dB, pe, ezo + (unsigned)(2 * ps) * ecs, kAuxNT);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs, kAuxNT);
+    float vx = (acc.x - o.x * pq) * sc, vy = (acc.y - o.y * pq) * sc;
+    asm volatile("" : "+v"(vx), "+v"(vy));  // (stored behind the hand-off: there the stores have a chunk's time to retire)
     if (ps + 1 < NP) {
       // chunk ps + 1 has landed; younger than it: the DMA of chunks ps + 2 .. ps + RB - 1 (those that exist) and the stores of the
       // last min(ps + 1, RB - 1) chunks; everyone is done with buffer ps % RB
+      // (the stores in between are NOT counted: they sit on the same counter but may retire before an older load -- counted in,
+      //  they let the wait pass with part of the awaited chunk in flight; pea_zmarch.h zm_bwd_wait has the case that showed it)
       const int nd = (ps + RB - 1 < NP ? ps + RB - 1 : NP - 1) - (ps + 1);
-      const int ns = 2 * (ps + 1 < RB - 1 ? ps + 1 : RB - 1);
-      pf_wait(nd * npc + ns);
+      pf_wait(nd * npc);
       if (ps + RB < NP) {
         PEA_PFDMA(xB, bo, ezo + (unsigned)(2 * (ps + RB)) * ecs)
         PEA_PFDMA(xB, bo + PS, ezo + (unsigned)(2 * (ps + RB) + 1) * ecs)
       }
     }
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), dB, pe, ezo + (unsigned)(2 * ps) * ecs, kAuxNT);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs, kAuxNT);
   }
 #undef PEA_PFDMA
 }

@@ -38,6 +38,9 @@ constexpr int kZS = 4;  // longest step along z the window covers
 #ifndef PEA_ZMV_FFENCE
 #define PEA_ZMV_FFENCE 0
 #endif
+#ifndef PEA_ZMV_STORE_AUX
+#define PEA_ZMV_STORE_AUX kAuxNT  // cache policy of the march backward's gradient stores (0: plain, 1: sc0, 2: nt, 16: sc1)
+#endif
 
 struct ZMParams {
   int zch[kZS];    // channel of the offset (-s, 0, 0), s = 1 .. kZS; -1: not in the table
@@ -67,27 +70,31 @@ struct ZmSlot { static constexpr int v = ((JO - D_) % kZS + kZS) % kZS; };
 // prefetched the same way: one-dword LDS-DMA into a private [value][lane] block per wave (no registers: the window leaves none),
 // requested together with the next plane's I.  Buffers beyond the 64 KB a ds_read immediate reaches get their addresses formed
 // per chunk.
-// Every staged plane issues the SAME sequence of vector-memory instructions per wave (planes beyond the volume, and the plane
-// after the last, are requested at out-of-range offsets; a gradient that is not due is stored at one), so the hand-offs are
-// literal s_waitcnt vmcnt(N), N = what may still fly behind the item waited for (zm_bwd_wait):
-//     item i: [2 stores of plane z - 4, i >= 1]; W_i: item i + 1 has landed; barrier; request item i + NB (of the next plane from
-//     i + NB >= 9 on; item 0 = I, 2 instructions, + G, 24)
-// NB = 4: W_I, W_0, W_1: 12; W_2 .. W_4, W_7: 14; W_5, W_6: 36.   NB = 3: 6, 6, 8 .. 8, W_6: 30, W_7: 8.
-// The first step requests its items 0 .. NB - 1 itself, with the stores a previous plane would have had in between.
+// Every staged plane issues the SAME sequence of LOAD instructions per wave (planes beyond the volume, and the plane after the
+// last, are requested at out-of-range offsets), so the hand-offs are literal s_waitcnt vmcnt(N), N = the loads that may still fly
+// behind the item waited for (zm_bwd_wait; the two gradient stores per chunk are NOT counted, see there):
+//     item i: W_i: item i + 1 has landed; barrier; request item i + NB (of the next plane from i + NB >= 9 on; item 0 = I,
+//     2 instructions, + G, 24); [2 stores of plane z - 4, i >= 1]
+// NB = 3: vmcnt(4) everywhere, vmcnt(26) behind the request of I + G.   NB = 4: 8 and 30.
+// The first step requests its items 0 .. NB - 1 itself.
 constexpr int kZmG = 24;  // prefetched values per lane: 8 + 8 in-plane pairs, 4 g and 4 a of the z offsets
 
-constexpr int zm_bwd_st(int j) { return ((j % 9) + 9) % 9 != 0 ? 2 : 0; }          // stores while item j is worked on
-constexpr int zm_bwd_sz(int m) { return ((m % 9) + 9) % 9 == 0 ? 2 + kZmG : 4; }   // instructions of the request of item m
-// vmcnt of W_i: everything issued after the request of item i + 1 (made after item i + 1 - NB) and before W_i
+constexpr int zm_bwd_sz(int m) { return ((m % 9) + 9) % 9 == 0 ? 2 + kZmG : 4; }   // LOAD instructions of the request of item m
+// vmcnt of W_i: the LOADS issued after the request of item i + 1 (made after item i + 1 - NB) and before W_i.  Stores are NOT
+// counted although they sit on the same counter: loads retire in order among themselves, but a store may retire before an older
+// load (LLVM's waitcnt pass treats a gfx9 vmcnt with loads and stores pending as out of order for the same reason).  Counting the
+// stores in -- "only these may still fly" -- let a wait pass with part of the awaited chunk in flight whenever stores had retired
+// early: with a ring of three the gradient differed between identical launches at 17 k of 403 M values (runs of eight pixels;
+// profiles/r4_zm_race.txt), with a ring of four it never showed -- and was just as unsound.  With loads only, outstanding stores
+// make a wait a little longer, never shorter.
 constexpr int zm_bwd_wait(int NB, int i) {
   int n = 0;
-  for (int j = i + 2 - NB; j <= i; ++j) n += zm_bwd_st(j);
   for (int j = i + 2 - NB; j <= i - 1; ++j) n += zm_bwd_sz(j + NB);
   return n;
 }
-static_assert(zm_bwd_wait(4, 0) == 12 && zm_bwd_wait(4, 3) == 14 && zm_bwd_wait(4, 6) == 36 && zm_bwd_wait(4, 7) == 36 &&
-              zm_bwd_wait(4, 8) == 14 && zm_bwd_wait(3, 0) == 6 && zm_bwd_wait(3, 1) == 6 && zm_bwd_wait(3, 2) == 8 &&
-              zm_bwd_wait(3, 7) == 30 && zm_bwd_wait(3, 8) == 8, "the hand-off counts derived by hand");
+static_assert(zm_bwd_wait(4, 0) == 8 && zm_bwd_wait(4, 3) == 8 && zm_bwd_wait(4, 6) == 30 && zm_bwd_wait(4, 7) == 30 &&
+              zm_bwd_wait(4, 8) == 8 && zm_bwd_wait(3, 0) == 4 && zm_bwd_wait(3, 1) == 4 && zm_bwd_wait(3, 2) == 4 &&
+              zm_bwd_wait(3, 7) == 26 && zm_bwd_wait(3, 8) == 4, "the hand-off counts derived by hand");
 
 template <int JO, int TH, int TW, int PSU, int NB>
 __device__ __forceinline__ void zm_bwd_full(const KParams& P, const XParams& C, const ZMParams& M, char* lds, const rsrc_t xB,
@@ -149,8 +156,6 @@ __device__ __forceinline__ void zm_bwd_full(const KParams& P, const XParams& C, 
       __builtin_amdgcn_raw_ptr_buffer_load_lds(aB, (lds_ptr_t)(lds + GB + gwave + (2 * XP + kZS + s) * 256), 4, vz, sz, 0, 0);   \
     }                                                                                                                            \
   }
-#define PEA_ZMB_ST2() \
-  { bs32<true>(dB, 0.f, kOOB, 0u); bs32<true>(dB, 0.f, kOOB, 0u); }
 // request item `it_` (0: I + G, else chunk it_ - 1) of the plane with step jo_ at plane offset so_
 #define PEA_ZMB_ITEM(jo_, it_, so_, v0_, v1_, en_)                                                                   \
   {                                                                                                                  \
@@ -160,10 +165,7 @@ __device__ __forceinline__ void zm_bwd_full(const KParams& P, const XParams& C, 
   const unsigned vh0 = here ? vo0 : kOOB, vh1 = here ? vo1 : kOOB;
   if (first) {  // the pipeline's head: items 0 .. NB - 1
 #pragma unroll
-    for (int m = 0; m < NB - 1; ++m) {
-      PEA_ZMB_ITEM(JO, m, ezo, vh0, vh1, here)
-      PEA_ZMB_ST2()
-    }
+    for (int m = 0; m < NB - 1; ++m) PEA_ZMB_ITEM(JO, m, ezo, vh0, vh1, here)
     PEA_ZM_WAIT(zm_bwd_wait(NB, 8));
     PEA_ZMB_ITEM(JO, NB - 1, ezo, vh0, vh1, here)
   }
@@ -244,22 +246,23 @@ __device__ __forceinline__ void zm_bwd_full(const KParams& P, const XParams& C, 
     Pd[ps][ZmSlot<JO, 3>::v] = pk_fma_c<false>(gz23, o, Pd[ps][ZmSlot<JO, 3>::v]);
     const f2 Gf = pk_fma_c<true>(gz23, o, Pd[ps][JO]);
     // plane z - 4 is complete: (G - ehat <ehat, G>) / n
-    const float vx = (Gf.x - Eh[ps][JO].x * projF) * scF, vy = (Gf.y - Eh[ps][JO].y * projF) * scF;
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), dB, pf, fzo + (unsigned)(2 * ps) * ecs, kAuxNT);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), dB, pf, fzo + (unsigned)(2 * ps + 1) * ecs, kAuxNT);
+    float vx = (Gf.x - Eh[ps][JO].x * projF) * scF, vy = (Gf.y - Eh[ps][JO].y * projF) * scF;
     Pd[ps][JO] = acc;
     Eh[ps][JO] = o;
-    asm volatile("" : "+v"(Pd[ps][JO]), "+v"(Eh[ps][JO]), "+v"(pcur));  // the chunk's sums exist before its barrier
+    asm volatile("" : "+v"(Pd[ps][JO]), "+v"(Eh[ps][JO]), "+v"(pcur), "+v"(vx), "+v"(vy));  // the chunk's sums exist before its barrier
     // the next item has landed; everyone is done with this buffer; refill it with the item NB behind
     PEA_ZM_WAIT(zm_bwd_wait(NB, ps + 1));
     if (ps + 1 + NB < 9) PEA_ZMB_ITEM(JO, ps + 1 + NB, ezo, vh0, vh1, here)
     else PEA_ZMB_ITEM(JN, ps + 1 + NB - 9, ezn, vn0, vn1, there)
+    // the finished plane's two channels, stored BEHIND the hand-off: issued just before a counted wait they would still be in
+    // flight when it is reached -- and stores cannot be counted on (zm_bwd_wait); here they have a chunk's time to retire
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), dB, pf, fzo + (unsigned)(2 * ps) * ecs, PEA_ZMV_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), dB, pf, fzo + (unsigned)(2 * ps + 1) * ecs, PEA_ZMV_STORE_AUX);
   }
   prj[JO] = pcur;
   ivs[JO] = invo;
 #undef PEA_ZMB_CHUNK
 #undef PEA_ZMB_IG
-#undef PEA_ZMB_ST2
 #undef PEA_ZMB_ITEM
 #undef PEA_ZMB_BUF
 }
@@ -364,14 +367,15 @@ __global__ __launch_bounds__(TH* TW, 2) void k_bwd_zm(const KParams P, const XPa
 // output byte; PMC: waves parked 49 % of their cycles, TA 55 % busy.)  The K dot products are parked in their own [K][tile pixel]
 // array behind the ring.  The upper four buffers lie beyond the 64 KB a ds_read immediate reaches: their addresses are formed per
 // chunk (one add per read; hoisted out of the march they would cost eleven registers beside the window).
-// Every staged plane issues the SAME sequence of vector-memory instructions per wave (absent operands and the plane after the last
-// are requested at an out-of-range offset), so every hand-off is a literal s_waitcnt vmcnt(N):
+// Every staged plane issues the SAME sequence of LOAD instructions per wave (absent operands and the plane after the last are
+// requested at an out-of-range offset), so every hand-off is a literal s_waitcnt vmcnt(N), N = the loads that may still fly behind
+// the chunk waited for (stores sit on the same counter but may retire before older loads: they are NOT counted, zm_bwd_wait):
 //     T  : 3 * ITEMS loads (target, weight, mask quads of the plane's items)
 //     c  : gather chunk c; wait W_c for chunk c + 1; barrier; 4 DMA instructions: chunk c of the NEXT plane into the same buffer
 //     E  : 1 + 2 * ITEMS stores (the 1 / norm plane, affs and g quads)
-// W_c, c <= 6, waits for DMA issued in the previous plane: behind it are the chunks c + 2 .. 7 of this plane, E (7), T (9) and the
-// chunks 0 .. c - 1 of the next: six chunks (24) + 16 -> vmcnt(40); W_7 (chunk 0 of the next plane): six chunks -> vmcnt(24).
-// The first plane of a segment issues its eight chunks and a dummy E itself.
+// W_c, c <= 6, waits for DMA issued in the previous plane: behind it are the chunks c + 2 .. 7 of this plane, T (9) and the chunks
+// 0 .. c - 1 of the next: six chunks (24) + 9 -> vmcnt(33); W_7 (chunk 0 of the next plane): six chunks -> vmcnt(24).
+// The first plane of a segment issues its eight chunks itself.
 template <int TH, int TW, int PSU, bool TRAIN>
 __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XParams C, const ZMParams M, const float* __restrict__ e,
                                                        const float* __restrict__ target, const float* __restrict__ weight,
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
                                                        float* __restrict__ inv_out) {
   constexpr int D_T = 16, NT = TH * TW, PS = PSU * 256, NP = D_T / 2, TP = NT, QP = TP / 4, NSL = QP / 64;
   constexpr int KMAX = kXP + 2, ITEMS = (KMAX * QP + NT - 1) / NT, RING = 16 * PS;
-  constexpr int NLD = 3 * ITEMS, NST = 1 + 2 * ITEMS;  // T, E
+  constexpr int NLD = 3 * ITEMS;  // T
   static_assert(TW == 32 && QP % 64 == 0, "lane mapping");
   static_assert(KMAX <= kXK && 8 * PS == 65536, "the lower four buffers end where the ds_read immediate does");
   extern __shared__ f4 lds4[];
@@ -466,7 +470,6 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) W[ps][j] = (f2){0.f, 0.f};
   }
-  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
   // the loss: lane k < K of wave 0 sums the workgroup's partials of offset k over the planes it marches through (a fixed order:
   // bit-reproducible) and adds the sum to the integer accumulators ONCE at the end -- per plane, the 128-bit conversion and the
   // atomics made wave 0 late for the next plane's first barrier, and reading the partials cost a barrier of its own
@@ -501,10 +504,8 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
         const bool first = z == zb, nxt = z + 1 < ze;                                                                          \
         const unsigned ezn = (unsigned)(nxt ? z + 1 : z) * YX4;                                                                \
         const unsigned vn0 = nxt ? vo0 : kOOB, vn1 = nxt ? vo1 : kOOB;                                                         \
-        if (first) { /* the pipeline's head: the plane's eight chunks, and the E a previous plane would have issued */         \
+        if (first) { /* the pipeline's head: the plane's eight chunks */                                                       \
           _Pragma("unroll") for (int c = 0; c < NP; ++c) PEA_ZMF_CHUNK(c, ezo + (unsigned)(2 * c) * ecs, vo0, vo1)             \
-          bs32(iB, 0.f, kOOB, 0u);                                                                                             \
-          _Pragma("unroll") for (int it = 0; it < ITEMS; ++it) { bs128<true>(aB, zero4, kOOB, 0u); bs128<false>(gB, zero4, kOOB, 0u); } \
         }                                                                                                                      \
         /* T: target / weight / mask of the plane's items: they land while the chunks are gathered */                        \
         f4 t4[ITEMS], w4[ITEMS];                                                                                               \
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
                                                                    (ezo >> 2) + (unsigned)isl[it] * (unsigned)P.S, kAuxNT);    \
           m4[it] = has_m ? mm : 0x01010101u;                                                                                   \
         }                                                                                                                      \
-        if (first) PEA_ZM_WAIT(28 + NST + NLD); /* chunk 0 has landed (chunks 1 - 7, the dummy E and T may fly) */            \
+        if (first) PEA_ZM_WAIT(28 + NLD); /* chunk 0 has landed (chunks 1 - 7 and T may fly) */                                \
         f2 dot[kXP], ssq[kXP], dz[kZS], oss = {0.f, 0.f};                                                                      \
         _Pragma("unroll") for (int k = 0; k < kXP; ++k) { dot[k] = (f2){0.f, 0.f}; ssq[k] = (f2){0.f, 0.f}; }                  \
         _Pragma("unroll") for (int k = 0; k < kZS; ++k) dz[k] = (f2){0.f, 0.f};                                                \
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
           _Pragma("unroll") for (int j = 0; j < kZS; ++j) asm volatile("" : "+v"(dz[j]));                                      \
           asm volatile("" : "+v"(oss), "+v"(W[ps][JO]));                                                                       \
           /* the next chunk has landed (W_c); everyone is done with this buffer; refill it with the next plane's chunk */   \
-          if (ps < 7) PEA_ZM_WAIT(24 + NST + NLD);                                                                             \
+          if (ps < 7) PEA_ZM_WAIT(24 + NLD);                                                                                   \
           else PEA_ZM_WAIT(24);                                                                                                \
           PEA_ZMF_CHUNK(ps, ezn + (unsigned)(2 * ps) * ecs, vn0, vn1)                                                          \
           if (TRAIN && ps == 0 && !first && lane_k) { /* the PREVIOUS plane's loss partials: behind this barrier they are all */ \
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
         }                                                                                                                      \
         const float osum = oss.x + oss.y;                                                                                      \
         const float inv_own = rnorm(osum, inv_eps);                                                                            \
-        bs32(iB, osum < P.eps * P.eps ? -inv_own : inv_own, has_i ? pe : kOOB, ezo); /* E, 1 of NST */                         \
+        bs32(iB, osum < P.eps * P.eps ? -inv_own : inv_own, has_i ? pe : kOOB, ezo); /* E: the 1 / norm plane */                \
         _Pragma("unroll") for (int k = 0; k < kXP; ++k) {                                                                      \
           if (k < C.nf) {                                                                                                      \
             float a = (dot[k].x + dot[k].y) * inv_own * rnorm(ssq[k].x + ssq[k].y, inv_eps);                                   \

@@ -403,6 +403,31 @@ def case_full_summary(name, seed, B, D, H, W):
          affs_idx=idx, affs_val=affs.reshape(-1)[idx], grad_idx=gidx, grad_val=grad.reshape(-1)[gidx])
 
 
+def case_3d_summary(name, seed, B, D, Z, Y, X, which, affs0_weight=1):
+    """A 3D case sized for the LDS-DMA kernels that march along z (csrc/pea_zmarch.h needs Y >= 43, X >= 96, X % 4 == 0: 4-6 MB of
+    tensors): inputs are a closed-form function of the index (utils/synth.py, no RNG), only summary statistics and 4096 sampled
+    values of the reference's outputs are kept."""
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    import importlib
+    import __graft_entry__ as ge
+    ge.load_package()
+    synth = importlib.import_module(ge.PKG_NAME + ".utils.synth")
+    shifts = [1, 1, 1] if which == "norm1" else [1, 1, 1, 2, 3, 3, 3, 9, 9, 4, 27, 27]
+    offs = [[-s if i % 3 == a else 0 for a in range(3)] for i, s in enumerate(shifts)]
+    e, t, w = synth.synth_inputs_3d(B, D, Z, Y, X, offs, seed)
+    et = T(e).requires_grad_(True)
+    fn = ref3d.embedding_loss_norm1 if which == "norm1" else ref3d.embedding_loss_norm5
+    loss, affs = fn(et, T(t), T(w), criterion, affs0_weight=affs0_weight)
+    loss.backward()
+    affs, grad = affs.detach().numpy(), et.grad.numpy()
+    idx = np.random.default_rng(0).integers(0, affs.size, 4096)
+    gidx = np.random.default_rng(1).integers(0, grad.size, 4096)
+    save(name, kind="3d_" + which + "_summary", seed=np.int64(seed), shape=np.array([B, D, Z, Y, X]), affs0_weight=np.float32(affs0_weight),
+         loss=np.float32(loss.item()), affs_sum=np.float64(affs.astype(np.float64).sum()),
+         affs_sq=np.float64((affs.astype(np.float64) ** 2).sum()), grad_sq=np.float64((grad.astype(np.float64) ** 2).sum()),
+         affs_idx=idx, affs_val=affs.reshape(-1)[idx], grad_idx=gidx, grad_val=grad.reshape(-1)[gidx])
+
+
 def synth_full(B, D, H, W, K, seed):
     """Deterministic, RNG-free synthetic inputs (pixel-embedded-affinity_amd/utils/synth.py)."""
     sys.path.insert(0, os.path.join(OUT, "..", ".."))
@@ -441,6 +466,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "model":  # only the backbone layout fixtures
         case_model("gmodel_resunet2d", 81, (2, 3, 48, 64), [4, 8, 12, 16, 20], 16)
         case_model("gmodel_resunet2d_odd", 82, (1, 3, 40, 40), [4, 6, 8, 10, 12], 16)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "march":  # only the fixtures sized for the z-march kernels (pea_zmarch.h)
+        torch.manual_seed(0)
+        case_3d_summary("g3d_norm5_march", 101, B=1, D=16, Z=9, Y=48, X=96, which="norm5", affs0_weight=2)
+        case_3d_summary("g3d_norm5_march_b2", 102, B=2, D=16, Z=6, Y=43, X=100, which="norm5", affs0_weight=1)
+        case_3d_summary("g3d_norm1_march", 103, B=2, D=16, Z=7, Y=40, X=72, which="norm1", affs0_weight=0.5)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cross":  # only the fixtures sized for the LDS-DMA cross kernels (pea_xdma.h)
         torch.manual_seed(0)
@@ -494,3 +525,6 @@ if __name__ == "__main__":
     case_flip("gflip_rules", 94)
     case_section_3d("gsection_ac3ac4_norm5", 95, B=1, D=16, Z=5, Y=32, X=48, mode=5)
     case_section_3d("gsection_ac3ac4_norm1", 96, B=2, D=16, Z=4, Y=32, X=48, mode=1)
+    case_3d_summary("g3d_norm5_march", 101, B=1, D=16, Z=9, Y=48, X=96, which="norm5", affs0_weight=2)
+    case_3d_summary("g3d_norm5_march_b2", 102, B=2, D=16, Z=6, Y=43, X=100, which="norm5", affs0_weight=1)
+    case_3d_summary("g3d_norm1_march", 103, B=2, D=16, Z=7, Y=40, X=72, which="norm1", affs0_weight=0.5)

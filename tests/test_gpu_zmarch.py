@@ -184,3 +184,33 @@ def test_box_march_backward_vs_oracle(pkg, dev, orc, synth, monkeypatch, shape, 
     l2, a2, g2 = run()
     assert l1 == l2 and np.array_equal(a1, a2)      # the same forward kernel
     assert relmax(g1, g2) < 2e-6                    # the same sums in another order
+
+
+@pytest.mark.parametrize("name", ["g3d_norm5_march", "g3d_norm5_march_b2", "g3d_norm1_march"])
+def test_zmarch_matches_reference_summary(pkg, dev, monkeypatch, name):
+    """the march kernels against the REFERENCE's own embedding_loss_norm5 / norm1 (tests/golden/make_golden.py `march`: the reference
+    run on closed-form inputs at sizes the LDS-DMA kernels take; loss, sums and 4096 sampled values of its map and autograd gradient)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import load_golden
+    from test_oracle import march_inputs
+    g = load_golden(name)
+    e, t, w, shifts = march_inputs(g)
+    monkeypatch.setenv("PEA_ZMARCH", "2")
+    monkeypatch.setenv("PEA_BOX", "0")  # (norm1: keep the unit-box backward out of the way)
+    et = cu(e, dev).requires_grad_(True)
+    a0 = float(g["affs0_weight"])
+    if len(shifts) == 3:
+        loss, affs = pkg.embedding_loss_norm1(et, cu(t, dev), cu(w, dev), pkg.WeightedMSE(), affs0_weight=a0)
+    else:
+        loss, affs = pkg.embedding_loss_norm5(et, cu(t, dev), cu(w, dev), pkg.WeightedMSE(), affs0_weight=a0)
+    spec_offs = [[-s if i % 3 == a else 0 for a in range(3)] for i, s in enumerate(shifts)]
+    assert _march_on(pkg, pkg.AffinitySpec(3, spec_offs, None, pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED), et)
+    loss.backward()
+    a, gr = affs.cpu().numpy(), et.grad.cpu().numpy()
+    assert abs(loss.item() - float(g["loss"])) <= LOSS_RTOL * max(1.0, abs(float(g["loss"])))
+    assert np.abs(a.reshape(-1)[g["affs_idx"]] - g["affs_val"]).max() < AFFS_ATOL
+    assert abs((a.astype(np.float64) ** 2).sum() / float(g["affs_sq"]) - 1) < 1e-5
+    assert np.abs(gr.reshape(-1)[g["grad_idx"]] - g["grad_val"]).max() <= GRAD_RTOL * np.abs(g["grad_val"]).max()
+    assert abs((gr.astype(np.float64) ** 2).sum() / float(g["grad_sq"]) - 1) < 1e-4

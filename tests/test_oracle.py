@@ -8,7 +8,7 @@ import torch
 from conftest import golden_names, lam_for, load_golden, shifts_for
 
 G2D = [n for n in golden_names("g2d_") if "summary" not in n]
-G3D = golden_names("g3d_")
+G3D = [n for n in golden_names("g3d_") if "march" not in n]  # (the *_march fixtures are summaries: test_gpu_zmarch.py, test_oracle.py below)
 
 
 def _desc(orc, g):
@@ -193,3 +193,37 @@ def test_oracle_target_generation_matches_reference_seg_to_aff(orc):
     fg = (seg[0] > 0).astype(np.float32)
     t3[0, 0], t3[1, :, 0], t3[2, :, :, 0] = fg[0], fg[:, 0], fg[:, :, 0]
     assert np.array_equal(t3, g["aff3_replicate"])
+
+
+MARCH = golden_names("g3d_norm5_march") + golden_names("g3d_norm1_march")
+
+
+def march_inputs(g):
+    """the inputs of a *_march summary fixture: a closed-form function of the index (utils/synth.py), regenerated, not stored"""
+    import importlib
+
+    import __graft_entry__ as ge
+    ge.load_package()
+    synth = importlib.import_module(ge.PKG_NAME + ".utils.synth")
+    B, D, Z, Y, X = [int(v) for v in g["shape"]]
+    shifts = [1, 1, 1] if "norm1" in str(g["kind"]) else [1, 1, 1, 2, 3, 3, 3, 9, 9, 4, 27, 27]
+    offs = [[-s if i % 3 == a else 0 for a in range(3)] for i, s in enumerate(shifts)]
+    e, t, w = synth.synth_inputs_3d(B, D, Z, Y, X, offs, int(g["seed"]))
+    return e, t, w, shifts
+
+
+@pytest.mark.parametrize("name", MARCH)
+def test_c_oracle_matches_reference_summary_at_march_size(orc, name):
+    """the fixtures sized for the z-march kernels (too big to store whole: loss, sums and 4096 sampled values of the reference's
+    affinity map and autograd gradient): the C oracle, which checks those kernels on the GPU, against the reference itself"""
+    g = load_golden(name)
+    e, t, w, shifts = march_inputs(g)
+    first = 1 if len(shifts) == 3 else 3
+    d = orc.desc_3d(e, shifts, orc.affs0_lambda_3d(len(shifts), float(g["affs0_weight"]), first))
+    affs, loss = orc.c_fwd(d, e, None, t, w, None)
+    grad, _ = orc.c_bwd(d, e, None, t, w, None)
+    assert abs(loss[0] - float(g["loss"])) <= 3e-6 * max(1.0, abs(float(g["loss"])))
+    assert np.abs(affs.reshape(-1)[g["affs_idx"]] - g["affs_val"]).max() < 2e-6
+    assert abs((affs.astype(np.float64) ** 2).sum() / float(g["affs_sq"]) - 1) < 1e-5
+    assert np.abs(grad.reshape(-1)[g["grad_idx"]] - g["grad_val"]).max() <= 2e-5 * np.abs(g["grad_val"]).max()
+    assert abs((grad.astype(np.float64) ** 2).sum() / float(g["grad_sq"]) - 1) < 1e-4
