@@ -38,6 +38,9 @@ constexpr int kZS = 4;  // longest step along z the window covers
 #ifndef PEA_ZMV_FFENCE
 #define PEA_ZMV_FFENCE 0
 #endif
+#ifndef PEA_ZMV_STORE_LATE
+#define PEA_ZMV_STORE_LATE 0  // 1: the march backward's gradient stores behind the hand-off instead of ahead of it
+#endif
 #ifndef PEA_ZMV_STORE_AUX
 #define PEA_ZMV_STORE_AUX kAuxNT  // cache policy of the march backward's gradient stores (0: plain, 1: sc0, 2: nt, 16: sc1)
 #endif
@@ -250,14 +253,19 @@ __device__ __forceinline__ void zm_bwd_full(const KParams& P, const XParams& C, 
     Pd[ps][JO] = acc;
     Eh[ps][JO] = o;
     asm volatile("" : "+v"(Pd[ps][JO]), "+v"(Eh[ps][JO]), "+v"(pcur), "+v"(vx), "+v"(vy));  // the chunk's sums exist before its barrier
+#if !PEA_ZMV_STORE_LATE
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), dB, pf, fzo + (unsigned)(2 * ps) * ecs, PEA_ZMV_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), dB, pf, fzo + (unsigned)(2 * ps + 1) * ecs, PEA_ZMV_STORE_AUX);
+#endif
     // the next item has landed; everyone is done with this buffer; refill it with the item NB behind
     PEA_ZM_WAIT(zm_bwd_wait(NB, ps + 1));
     if (ps + 1 + NB < 9) PEA_ZMB_ITEM(JO, ps + 1 + NB, ezo, vh0, vh1, here)
     else PEA_ZMB_ITEM(JN, ps + 1 + NB - 9, ezn, vn0, vn1, there)
-    // the finished plane's two channels, stored BEHIND the hand-off: issued just before a counted wait they would still be in
-    // flight when it is reached -- and stores cannot be counted on (zm_bwd_wait); here they have a chunk's time to retire
+#if PEA_ZMV_STORE_LATE
+    // (variant: the finished plane's two channels stored BEHIND the hand-off)
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), dB, pf, fzo + (unsigned)(2 * ps) * ecs, PEA_ZMV_STORE_AUX);
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), dB, pf, fzo + (unsigned)(2 * ps + 1) * ecs, PEA_ZMV_STORE_AUX);
+#endif
   }
   prj[JO] = pcur;
   ivs[JO] = invo;
