@@ -302,8 +302,10 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
       // everyone is done with the working buffer and with ring buffer ps % 3; chunk ps + 1 has landed (chunk ps + 2 and, PF, the
       // stores of the last chunks are not counted on, pea_xdma_pf.h)
       // (loads only: a store may retire before an older load, pea_xdma_pf.h)
+      // (and a wave that issues no DMA -- npc == 0 -- waits for nothing: vmcnt(0) would make it drain its stores at every chunk)
       const int nd = ps + 2 < NP ? 1 : 0;
-      pf_wait(nd * npc);
+      if (PF && npc == 0) lds_barrier();
+      else pf_wait(nd * npc);
 #ifndef PEA_ABL_H_NODMA
       if (ps + 3 < NP) PEA_HDMA16(ps % 3, 2 * ps + 6)
 #endif

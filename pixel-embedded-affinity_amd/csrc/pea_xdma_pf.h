@@ -186,8 +186,11 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_pf(const KParams P, co
       // last min(ps + 1, RB - 1) chunks; everyone is done with buffer ps % RB
       // (the stores in between are NOT counted: they sit on the same counter but may retire before an older load -- counted in,
       //  they let the wait pass with part of the awaited chunk in flight; pea_zmarch.h zm_bwd_wait has the case that showed it)
+      // A wave that issues no DMA (npc == 0: the region has fewer blocks than the workgroup has waves) has nothing to wait for --
+      // vmcnt(0) would make it drain its own stores at every chunk and hold everybody's barrier.
       const int nd = (ps + RB - 1 < NP ? ps + RB - 1 : NP - 1) - (ps + 1);
-      pf_wait(nd * npc);
+      if (npc == 0) lds_barrier();
+      else pf_wait(nd * npc);
       if (ps + RB < NP) {
         PEA_PFDMA(xB, bo, ezo + (unsigned)(2 * (ps + RB)) * ecs)
         PEA_PFDMA(xB, bo + PS, ezo + (unsigned)(2 * (ps + RB) + 1) * ecs)
