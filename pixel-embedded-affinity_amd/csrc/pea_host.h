@@ -2,7 +2,8 @@
 //
 // The library is built from several .hip files compiled in parallel (one per kernel family; a single file took 1 m 47 s):
 //   pea_abi.hip        the extern "C" entry points of include/pea.h: validation, descriptor -> KParams, dispatch
-//   pea_k_xdma.hip     LDS-DMA cross kernels (pea_xdma.h): the training forward / backward of axis-aligned stencils
+//   pea_k_xdma.hip     LDS-DMA cross kernels (pea_xdma.h): the training forward / backward of axis-aligned stencils, f32 storage
+//   pea_k_xdma_h.hip   the same for f16 storage (pea_xdma_h16.h) and the projection-first backward (pea_xdma_pf.h)
 //   pea_k_zmarch.hip   z-march kernels (pea_zmarch.h): 3D volumes with axis-aligned stencils that step along z (norm5 / norm1)
 //   pea_k_box.hip      unit-box stencils (pea_box.h): the 26-neighbourhood of a 3D volume through an LDS-DMA ring of 3-plane boxes
 //   pea_k_tiled.hip    LDS-tiled box kernels (pea_tiled.h, pea_chunked.h): what the cross / box / march kernels do not take -- diagonal
@@ -141,7 +142,10 @@ bool box_bwd(const KParams& P, const float* x, const float* inv, const float* g,
 bool xdma_bwd_self(const KParams& P, const float* x, const float* inv, const float* g, const float* affs, const float* dl, float* dx,
                    hipStream_t s);  // affs: the raw cosine map or null
 bool xdma_bwd_self_h(const KParams& P, const void* x, const float* inv, const float* g, const float* affs, const float* dl, void* dx,
-                     hipStream_t s);  // f16 storage
+                     hipStream_t s);  // f16 storage (pea_k_xdma_h.hip)
+bool xdma_h_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s);  // f16 storage forward / inference (pea_k_xdma_h.hip)
+bool xdma_pf_bwd_self(const KParams& P, const float* x, const float* inv, const float* g, const float* affs, const float* dl, float* dx,
+                      hipStream_t s);  // the projection-first backward, f32 storage (pea_k_xdma_h.hip)
 bool xdma_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* dl,
                     float* de, bool accumulate, hipStream_t s);
 bool xdma_bwd_dual(const KParams& P, const float* e, const float* ema, const float* inv, const float* inv_other, const float* g,

@@ -1,0 +1,138 @@
+// pea_k_xdma_h.hip -- launchers of the LDS-DMA cross kernels for f16 storage (pea_xdma_h16.h) and of the projection-first backward
+// (pea_xdma_pf.h).  One translation unit of libpea_hip.so (pea_host.h); split from pea_k_xdma.hip for compile time.
+#include "pea_k_xdma_plan.h"
+#include "pea_xdma_h16.h"
+#include "pea_xdma_pf.h"
+
+namespace pea {
+
+namespace {
+
+// ---- f16 storage (pea_xdma_h16.h): 2D self loss / inference, X % 8 == 0 ---------------------------------------------------
+template <int D_T, bool TRAIN>
+bool fwd_self_h(const KParams& P, const FwdArgs& A, hipStream_t s) {
+  const __half* e = (const __half*)A.e;
+  if (P.X % 8 || P.Z != 1 || misaligned(e, 16) || misaligned(A.t, 16) || misaligned(A.w, 16) || misaligned(A.affs, 16) ||
+      misaligned(A.gout, 16) || misaligned(A.m, 4) || misaligned(A.inv_out, 4))
+    return false;
+  if (TRAIN && ((P.tbs | P.wbs | P.mbs) & 3)) return false;
+  XPlan X;
+  if (!plan(P, kXdmaPSUF, 1, &X) || X.C.nfz > 0 || P.K > kXP) return false;
+  const size_t lds = (size_t)5 * kXdmaPSUF * 256;  // two f32 working planes + six half-size ring planes
+  const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  if (env().h16_hw) {  // half-precision working buffer, v_dot2 gather: 48 VGPRs and 30 KB -- four workgroups per CU (five: 173 against 168 us)
+    const size_t ldsh = (size_t)4 * kXdmaPSUF * 256;
+    if (P.border != PEA_BORDER_CIRCULAR) {
+      constexpr auto kern = k_fwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, true, TRAIN, 8, true>;
+      PEA_LAUNCH(kern, grid, blk, ldsh, s, P, X.C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out)
+    } else {
+      constexpr auto kern = k_fwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, false, TRAIN, 8, true>;
+      PEA_LAUNCH(kern, grid, blk, ldsh, s, P, X.C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out)
+    }
+    return true;
+  }
+  if (P.border != PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_fwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, true, TRAIN, 6>;
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out)
+  } else {
+    constexpr auto kern = k_fwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, false, TRAIN, 6>;
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out)
+  }
+  return true;
+}
+
+template <int D_T>
+bool bwd_self_h(const KParams& P, const __half* x, const float* inv, const float* g, const float* affs, const float* dl, __half* dx,
+                hipStream_t s) {
+  if (P.X % 8 || P.Z != 1 || misaligned(x, 16) || misaligned(inv, 16) || misaligned(g, 4) || misaligned(dx, 2) || misaligned(affs, 4))
+    return false;
+  XPlan X;
+  const dim3 blk(kXdmaTH * kXdmaTW);
+  const bool crop = P.border != PEA_BORDER_CIRCULAR;
+  if (affs && env().bwd_pf && !(P.flags & kActMask) && (D_T > 16 || env().bwd_pf == 2)) {  // the projection first (pea_xdma_pf.h)
+    const bool small = plan(P, kXdmaPSUHS, 0, &X);
+    if ((small || plan(P, kXdmaPSUH, 0, &X)) && X.C.npz == 0 && X.C.npx <= kXP && X.C.npy <= kXP) {
+      const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd));
+#define PEA_HPF(CROP_, PSU_, WPE_)                                                                   \
+  {                                                                                                  \
+    if (env().h16_hw) {                                                                              \
+      constexpr auto kern = k_bwd_xdma_h<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, kXP, true, WPE_, true>;  \
+      PEA_LAUNCH(kern, grid, blk, (size_t)5 * PSU_ * 256, s, P, X.C, x, inv, g, affs, dl, dx)          \
+    } else {                                                                                         \
+      constexpr auto kern = k_bwd_xdma_h<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, kXP, true, WPE_>;        \
+      PEA_LAUNCH(kern, grid, blk, (size_t)5 * PSU_ * 256, s, P, X.C, x, inv, g, affs, dl, dx)          \
+    }                                                                                                \
+  }
+      // (87 VGPRs: the conversion's temporaries keep it above the 80 a third workgroup would need; small planes all the same --
+      //  less LDS per workgroup never hurts the other kernels sharing the CU in a multi-stream section)
+      if (small) { if (crop) PEA_HPF(true, kXdmaPSUHS, 4) else PEA_HPF(false, kXdmaPSUHS, 4) }
+      else { if (crop) PEA_HPF(true, kXdmaPSUH, 4) else PEA_HPF(false, kXdmaPSUH, 4) }
+#undef PEA_HPF
+      return true;
+    }
+  }
+  if (!plan(P, kXdmaPSUH, 0, &X) || X.C.npz > 0) return false;
+  constexpr int XP = D_T > 32 ? 8 : kXP;
+  if (X.C.npx > XP || X.C.npy > XP) return false;
+  const size_t lds = (size_t)5 * kXdmaPSUH * 256;
+  const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd));
+  if (crop) {
+    constexpr auto kern = k_bwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUH, true, XP>;
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, x, inv, g, (const float*)nullptr, dl, dx)
+  } else {
+    constexpr auto kern = k_bwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUH, false, XP>;
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, x, inv, g, (const float*)nullptr, dl, dx)
+  }
+  return true;
+}
+
+// ---- the backward with the projection first (pea_xdma_pf.h): 2D / in-plane stencils, self loss, f32, needs the raw affs map
+template <int D_T>
+bool bwd_self_pf(const KParams& P, const float* x, const float* inv, const float* g, const float* affs, const float* dl, float* dx,
+                 hipStream_t s) {
+  if (misaligned(x, 16) || misaligned(inv, 16) || misaligned(g, 4) || misaligned(affs, 4) || misaligned(dx, 4)) return false;
+  XPlan X;
+  const bool small = plan(P, kXdmaPSUS, 0, &X);
+  if (!small && !plan(P, kXdmaPSU, 0, &X)) return false;
+  if (X.C.npz > 0 || X.C.npx > kXP || X.C.npy > kXP) return false;
+  const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+#define PEA_PF(CROP_, PSU_, WPE_, RB_)                                                         \
+  {                                                                                            \
+    constexpr auto kern = k_bwd_xdma_pf<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, WPE_, RB_>;        \
+    PEA_LAUNCH(kern, grid, blk, (size_t)2 * RB_ * PSU_ * 256, s, P, X.C, x, inv, g, affs, dl, dx) \
+  }
+  const bool crop = P.border != PEA_BORDER_CIRCULAR;
+  if (small) { if (crop) PEA_PF(true, kXdmaPSUS, 6, 3) else PEA_PF(false, kXdmaPSUS, 6, 3) }
+  else { if (crop) PEA_PF(true, kXdmaPSU, 4, 3) else PEA_PF(false, kXdmaPSU, 4, 3) }
+#undef PEA_PF
+  return true;
+}
+
+}  // namespace
+
+// entry points used by pea_k_xdma.hip's dispatchers
+bool xdma_h_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s) {
+  if (P.D == 16) return A.train ? fwd_self_h<16, true>(P, A, s) : fwd_self_h<16, false>(P, A, s);
+  if (P.D == 32) return A.train ? fwd_self_h<32, true>(P, A, s) : fwd_self_h<32, false>(P, A, s);
+  if (P.D == 64) return A.train ? fwd_self_h<64, true>(P, A, s) : fwd_self_h<64, false>(P, A, s);
+  return false;
+}
+
+bool xdma_pf_bwd_self(const KParams& P, const float* x, const float* inv, const float* g, const float* affs, const float* dl, float* dx,
+                      hipStream_t s) {
+  if (P.D == 16) return bwd_self_pf<16>(P, x, inv, g, affs, dl, dx, s);
+  if (P.D == 32) return bwd_self_pf<32>(P, x, inv, g, affs, dl, dx, s);
+  if (P.D == 64) return bwd_self_pf<64>(P, x, inv, g, affs, dl, dx, s);
+  return false;
+}
+
+bool xdma_bwd_self_h(const KParams& P, const void* x, const float* inv, const float* g, const float* affs, const float* dl, void* dx,
+                     hipStream_t s) {
+  if (!inv || !env().bwd_xdma || env().force_direct) return false;
+  if (P.D == 16) return bwd_self_h<16>(P, (const __half*)x, inv, g, affs, dl, (__half*)dx, s);
+  if (P.D == 32) return bwd_self_h<32>(P, (const __half*)x, inv, g, affs, dl, (__half*)dx, s);
+  if (P.D == 64) return bwd_self_h<64>(P, (const __half*)x, inv, g, affs, dl, (__half*)dx, s);
+  return false;
+}
+
+}  // namespace pea
