@@ -60,6 +60,13 @@ for tag in [t for t in os.environ.get("VARIANTS", "").split(",") if t]:  # diagn
         run(kn, "(variant %s)" % tag)
     lm.SO_PATH, lm._lib = keep
     L = keep[1]
+if os.environ.get("ILV"):  # (needs the PEA_XCD_INTERLEAVE switch of the experiment's build: not in the product)
+    for gy, gx in [tuple(int(v) for v in b.split('x')) for b in os.environ.get('BLOCKS', '16x2,8x4,4x8,4x4').split(',')]:
+        for ilv in ("0", "1"):
+            pkg._lib.set_switch("PEA_ZBLK_Y", gy); pkg._lib.set_switch("PEA_ZBLK_X", gx); pkg._lib.set_switch("PEA_XCD_INTERLEAVE", ilv)
+            for kn in os.environ.get("CASES", "fwd,bwd").split(","):
+                run(kn, "(block %d x %d, interleave %s)" % (gy, gx, ilv))
+    sys.exit(0)
 if os.environ.get("STENCIL") == "n26":
     pkg._lib.set_switch("PEA_BOXM", "0"); run("bwd", "(PEA_BOXM=0: the per-(z, tile) box backward)")
     pkg._lib.set_switch("PEA_BOXM", None); run("bwd", "(marching again)")
