@@ -22,13 +22,16 @@ bool fwd_self_h(const KParams& P, const FwdArgs& A, hipStream_t s) {
   const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
   if (env().h16_hw) {  // half-precision working buffer, v_dot2 gather: 48 VGPRs and 30 KB -- four workgroups per CU (five: 173 against 168 us)
     const size_t ldsh = (size_t)4 * kXdmaPSUF * 256;
-    if (P.border != PEA_BORDER_CIRCULAR) {
-      constexpr auto kern = k_fwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, true, TRAIN, 8, true>;
-      PEA_LAUNCH(kern, grid, blk, ldsh, s, P, X.C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out)
-    } else {
-      constexpr auto kern = k_fwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, false, TRAIN, 8, true>;
-      PEA_LAUNCH(kern, grid, blk, ldsh, s, P, X.C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out)
-    }
+    // (D = 64 with at most eight offsets -- BASELINE configs[4] -- walks eight slots instead of ten)
+#define PEA_HF(CROP_, NXP_)                                                                                          \
+  {                                                                                                                  \
+    constexpr auto kern = k_fwd_xdma_h<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, CROP_, TRAIN, 8, true, NXP_>;               \
+    PEA_LAUNCH(kern, grid, blk, ldsh, s, P, X.C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out)                  \
+  }
+    const bool crop = P.border != PEA_BORDER_CIRCULAR;
+    if (D_T == 64 && X.C.nf <= 8) { if (crop) PEA_HF(true, (D_T == 64 ? 8 : kXP)) else PEA_HF(false, (D_T == 64 ? 8 : kXP)) }
+    else { if (crop) PEA_HF(true, kXP) else PEA_HF(false, kXP) }
+#undef PEA_HF
     return true;
   }
   if (P.border != PEA_BORDER_CIRCULAR) {
@@ -53,9 +56,16 @@ bool bwd_self_h(const KParams& P, const __half* x, const float* inv, const float
     const bool small = plan(P, kXdmaPSUHS, 0, &X);
     if ((small || plan(P, kXdmaPSUH, 0, &X)) && X.C.npz == 0 && X.C.npx <= kXP && X.C.npy <= kXP) {
       const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd));
+      // (D = 64 with at most eight pairs per axis -- BASELINE configs[4]: offsets[:8] = four shifts per axis, two roles each -- walks
+      //  eight pairs per axis instead of ten: an unused pair costs its LDS read and its two FMAs all the same)
+      constexpr int XPS = D_T == 64 ? 8 : kXP;
+      const bool few = D_T == 64 && X.C.npx <= 8 && X.C.npy <= 8;
 #define PEA_HPF(CROP_, PSU_, WPE_)                                                                   \
   {                                                                                                  \
-    if (env().h16_hw) {                                                                              \
+    if (env().h16_hw && few) {                                                                       \
+      constexpr auto kern = k_bwd_xdma_h<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, XPS, true, WPE_, true>;  \
+      PEA_LAUNCH(kern, grid, blk, (size_t)5 * PSU_ * 256, s, P, X.C, x, inv, g, affs, dl, dx)          \
+    } else if (env().h16_hw) {                                                                       \
       constexpr auto kern = k_bwd_xdma_h<D_T, kXdmaTH, kXdmaTW, PSU_, CROP_, kXP, true, WPE_, true>;  \
       PEA_LAUNCH(kern, grid, blk, (size_t)5 * PSU_ * 256, s, P, X.C, x, inv, g, affs, dl, dx)          \
     } else {                                                                                         \

@@ -72,14 +72,16 @@ bool zmarch_fwd(const KParams& P, const FwdArgs& A, hipStream_t s) {
   ZPlan Z;
   if (!plan(P, 1, &Z)) return false;
   const dim3 grid((unsigned)(Z.C.tiles_per_xcd * kXcd)), blk(kTH * kTW);
-  if (A.train) {
-    constexpr auto kern = k_fwd_zm<kTH, kTW, kPSUF, true>;
-    PEA_LAUNCH(kern, grid, blk, Z.lds, s, P, Z.C, Z.M, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out)
-  } else {
-    constexpr auto kern = k_fwd_zm<kTH, kTW, kPSUF, false>;
-    PEA_LAUNCH(kern, grid, blk, Z.lds, s, P, Z.C, Z.M, e, (const float*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr, A.affs,
-               (float*)nullptr, (LossState*)nullptr, (float*)nullptr)
+#define PEA_ZF(TRAIN_, NXP_)                                                                                                      \
+  {                                                                                                                               \
+    constexpr auto kern = k_fwd_zm<kTH, kTW, kPSUF, TRAIN_, NXP_>;                                                                \
+    PEA_LAUNCH(kern, grid, blk, Z.lds, s, P, Z.C, Z.M, e, A.train ? A.t : nullptr, A.train ? A.w : nullptr,                       \
+               A.train ? A.m : nullptr, A.affs, A.train ? A.gout : nullptr, A.train ? A.st : nullptr, A.train ? A.inv_out : nullptr) \
   }
+  const bool few = Z.C.nf <= 8;  // the reference's 3D tables have at most eight in-plane offsets
+  if (A.train) { if (few) PEA_ZF(true, 8) else PEA_ZF(true, kXP) }
+  else { if (few) PEA_ZF(false, 8) else PEA_ZF(false, kXP) }
+#undef PEA_ZF
   return true;
 }
 

@@ -344,7 +344,9 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
 // forward (self loss with TRAIN, or inference), f16 e; writes the f32 1 / norm plane for the backward.  Epilogue as k_fwd_xdma.
 // ------------------------------------------------------------------------------------------------------------------
 // HW: the working buffer stays in f16 (interleave_chunk) and the gather runs on v_dot2_f32_f16
-template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN, int WPE, bool HW = false>
+// NXP: offsets the gather walks (kXP = 10; 8 for tables with no more, e.g. BASELINE configs[4]'s offsets[:8] -- an unused slot costs
+// its LDS read and its two dot products all the same)
+template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN, int WPE, bool HW = false, int NXP = kXP>
 __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, const XParams C, const __half* __restrict__ e,
                                                              const float* __restrict__ target, const float* __restrict__ weight,
                                                              const uint8_t* __restrict__ mask, float* __restrict__ affs,
@@ -392,11 +394,11 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
   PEA_HDMA16(0, 0)
   if (NP > 1) PEA_HDMA16(1, 2)
 
-  int an[kXP];
+  int an[NXP];
   const int vown = ((C.hy0 + ly) * TW + lx) * 4;
   const int hrow = (C.QV * 4 + ly * C.SW) * 4;
 #pragma unroll
-  for (int k = 0; k < kXP; ++k) {
+  for (int k = 0; k < NXP; ++k) {
     const int d = C.fd[k], c = lx + d;
     const int a_x = (unsigned)c < (unsigned)TW ? vown + d * 4 : hrow + (c & C.fm[k]) * 4;
     an[k] = C.fax[k] ? a_x : vown + d * TW * 4;
@@ -407,10 +409,10 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
 
   // HW: scalar accumulators (the two channels of a chunk are summed by v_dot2); else packed over the two channels
   typedef typename std::conditional<HW, float, f2>::type acc_t;
-  acc_t dot[kXP], ssq[kXP], oss;
+  acc_t dot[NXP], ssq[NXP], oss;
   if constexpr (HW) oss = 0.f; else oss = (f2){0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < kXP; ++k) {
+  for (int k = 0; k < NXP; ++k) {
     if constexpr (HW) { dot[k] = 0.f; ssq[k] = 0.f; } else { dot[k] = (f2){0.f, 0.f}; ssq[k] = (f2){0.f, 0.f}; }
   }
 #pragma unroll
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
       const h2_t o = *(const h2_t*)(W + vown);
       oss = __builtin_amdgcn_fdot2(o, o, oss, false);
 #pragma unroll
-      for (int k = 0; k < kXP; ++k) {
+      for (int k = 0; k < NXP; ++k) {
         const h2_t v = *(const h2_t*)(W + an[k]);
         dot[k] = __builtin_amdgcn_fdot2(o, v, dot[k], false);
         ssq[k] = __builtin_amdgcn_fdot2(v, v, ssq[k], false);
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
     const f2 o = *(const f2*)(W + 2 * vown);
     oss = __builtin_elementwise_fma(o, o, oss);
 #pragma unroll
-    for (int k = 0; k < kXP; ++k) {
+    for (int k = 0; k < NXP; ++k) {
       const f2 v = *(const f2*)(W + 2 * an[k]);
       dot[k] = __builtin_elementwise_fma(o, v, dot[k]);
       ssq[k] = __builtin_elementwise_fma(v, v, ssq[k]);
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
     }
     }
 #pragma unroll
-    for (int k = 0; k < kXP; ++k) asm volatile("" : "+v"(dot[k]), "+v"(ssq[k]));
+    for (int k = 0; k < NXP; ++k) asm volatile("" : "+v"(dot[k]), "+v"(ssq[k]));
     asm volatile("" : "+v"(oss));
     if (ps + 1 < NP) {
       if (ps + 2 < NP) PEA_HWAIT1(npc)
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
   if (inv_out) bs32(iB, osum < P.eps * P.eps ? -inv_own : inv_own, pe, ezo);
   lds_barrier();  // every lane is done with the working planes: sA goes over them
 #pragma unroll
-  for (int k = 0; k < kXP; ++k) {
+  for (int k = 0; k < NXP; ++k) {
     if (k < C.nf) {
       float dk, sk;
       if constexpr (HW) { dk = dot[k]; sk = ssq[k]; } else { dk = dot[k].x + dot[k].y; sk = ssq[k].x + ssq[k].y; }

@@ -384,7 +384,9 @@ __global__ __launch_bounds__(TH* TW, 2) void k_bwd_zm(const KParams P, const XPa
 // W_c, c <= 6, waits for DMA issued in the previous plane: behind it are the chunks c + 2 .. 7 of this plane, T (9) and the chunks
 // 0 .. c - 1 of the next: six chunks (24) + 9 -> vmcnt(33); W_7 (chunk 0 of the next plane): six chunks -> vmcnt(24).
 // The first plane of a segment issues its eight chunks itself.
-template <int TH, int TW, int PSU, bool TRAIN>
+// NXP: in-plane offsets the gather walks (8: the norm5 / norm1 tables; 10: every table the cross kernels take) -- an unused slot
+// still costs its LDS reads
+template <int TH, int TW, int PSU, bool TRAIN, int NXP>
 __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XParams C, const ZMParams M, const float* __restrict__ e,
                                                        const float* __restrict__ target, const float* __restrict__ weight,
                                                        const uint8_t* __restrict__ mask, float* __restrict__ affs,
@@ -460,11 +462,11 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
   const bool two = __builtin_amdgcn_readfirstlane(((NT / 64) + wave) * 64 < C.QA);
   const unsigned vo0 = vo[0], vo1 = two ? vo[1] : vo[0];
   const int w1 = two ? wbase + (NT / 64) * 1024 : wbase;
-  int an[kXP];
+  int an[NXP];
   const int vown = ((C.hy0 + ly) * TW + lx) * 4;
   const int hrow = (C.QV * 4 + ly * C.SW) * 4;
 #pragma unroll
-  for (int k = 0; k < kXP; ++k) {
+  for (int k = 0; k < NXP; ++k) {
     const int d = C.fd[k], c = lx + d;
     const int a_x = (unsigned)c < (unsigned)TW ? vown + d * 4 : hrow + (c & C.fm[k]) * 4;
     an[k] = C.fax[k] ? a_x : vown + d * TW * 4;  // unused offsets: d = 0, the own slot
@@ -528,8 +530,8 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
           m4[it] = has_m ? mm : 0x01010101u;                                                                                   \
         }                                                                                                                      \
         if (first) PEA_ZM_WAIT(28 + NLD); /* chunk 0 has landed (chunks 1 - 7 and T may fly) */                                \
-        f2 dot[kXP], ssq[kXP], dz[kZS], oss = {0.f, 0.f};                                                                      \
-        _Pragma("unroll") for (int k = 0; k < kXP; ++k) { dot[k] = (f2){0.f, 0.f}; ssq[k] = (f2){0.f, 0.f}; }                  \
+        f2 dot[NXP], ssq[NXP], dz[kZS], oss = {0.f, 0.f};                                                                      \
+        _Pragma("unroll") for (int k = 0; k < NXP; ++k) { dot[k] = (f2){0.f, 0.f}; ssq[k] = (f2){0.f, 0.f}; }                  \
         _Pragma("unroll") for (int k = 0; k < kZS; ++k) dz[k] = (f2){0.f, 0.f};                                                \
         _Pragma("unroll") for (int ps = 0; ps < NP; ++ps) {                                                                    \
           const int bo = (ps % 4) * 2 * PS;                                                                                    \
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
           o.x = *(const float*)(lds + bo + (vown + hi));                                                                       \
           o.y = *(const float*)(lds + bo + PS + (vown + hi));                                                                  \
           oss = __builtin_elementwise_fma(o, o, oss);                                                                          \
-          _Pragma("unroll") for (int k = 0; k < kXP; ++k) {                                                                    \
+          _Pragma("unroll") for (int k = 0; k < NXP; ++k) {                                                                    \
             f2 v;                                                                                                              \
             v.x = *(const float*)(lds + bo + (an[k] + hi));                                                                    \
             v.y = *(const float*)(lds + bo + PS + (an[k] + hi));                                                               \
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
           }                                                                                                                    \
           _Pragma("unroll") for (int j = 0; j < kZS; ++j) dz[j] = __builtin_elementwise_fma(o, W[ps][j], dz[j]);               \
           W[ps][JO] = o;                                                                                                       \
-          _Pragma("unroll") for (int k = 0; k < kXP; ++k) asm volatile("" : "+v"(dot[k]), "+v"(ssq[k]));                       \
+          _Pragma("unroll") for (int k = 0; k < NXP; ++k) asm volatile("" : "+v"(dot[k]), "+v"(ssq[k]));                       \
           _Pragma("unroll") for (int j = 0; j < kZS; ++j) asm volatile("" : "+v"(dz[j]));                                      \
           asm volatile("" : "+v"(oss), "+v"(W[ps][JO]));                                                                       \
           /* the next chunk has landed (W_c); everyone is done with this buffer; refill it with the next plane's chunk */   \
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
         const float osum = oss.x + oss.y;                                                                                      \
         const float inv_own = rnorm(osum, inv_eps);                                                                            \
         bs32(iB, osum < P.eps * P.eps ? -inv_own : inv_own, has_i ? pe : kOOB, ezo); /* E: the 1 / norm plane */                \
-        _Pragma("unroll") for (int k = 0; k < kXP; ++k) {                                                                      \
+        _Pragma("unroll") for (int k = 0; k < NXP; ++k) {                                                                      \
           if (k < C.nf) {                                                                                                      \
             float a = (dot[k].x + dot[k].y) * inv_own * rnorm(ssq[k].x + ssq[k].y, inv_eps);                                   \
             const int q = (C.fax[k] ? px : py) + C.fd[k];                                                                      \
