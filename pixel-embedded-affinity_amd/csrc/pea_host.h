@@ -30,13 +30,16 @@ struct Env {
   int infer_xdma;     // PEA_INFER_XDMA=0: inference (affs only) on k_fwd_tiled / the chunked kernels instead of the LDS-DMA forward
   int bwd_pf;         // PEA_BWD_PF=0: never the projection-first backward (pea_xdma_pf.h); 2: also at D = 16 (where it loses)
   int fwd_wg3;        // PEA_FWD_WG3=0: the 2-workgroups-per-CU forward
-  int h16_hw;         // PEA_H16_HW=0: the f16 kernels with the f32 working buffer (packed-f32 gather) instead of the f16 one (v_dot2 / v_fma_mix)
+  int h16_hw;         // PEA_H16_HW: the f16 kernels' working buffer.  0: f32 (packed-f32 gather); 1: f16 [pixel][2 halves] behind an LDS-DMA
+                      // ring; 2 (default): as 1, and the backward of small crosses at D = 32 / 64 on producer / consumer waves (pea_xdma_hq.h)
   int box;            // PEA_BOX=0: unit-box stencils (the 26-neighbourhood) on the tiled kernels instead of pea_box.h
   int zmarch;         // PEA_ZMARCH=0: 3D volumes with z offsets on the tile-per-plane cross kernels (pea_xdma.h) instead of the z-march
                       //   kernels (pea_zmarch.h); 2: the march also on volumes with fewer tile columns than CUs
   int boxm;           // PEA_BOXM=0: the unit-box backward per (z, tile) (pea_box.h) instead of marching (pea_boxm.h)
   int zm_nb;          // PEA_ZM_NB=3: the z-march backward with a ring of three buffers instead of four (5 % slower once the waits count loads only)
   int zseg;           // PEA_ZSEG=n: planes per segment of a tile column (0: whole columns where there are enough of them)
+  int skew, skew_slots, skew_mode;  // PEA_SKEW (units of 2048 cycles; -1 = auto: the D = 16 cross backward only, 0 = off) / PEA_SKEW_SLOTS /
+                                    // PEA_SKEW_MODE: the first workgroups of a CU start apart (pea_xdma.h xdma_tile)
   int xcd_stagger;    // PEA_XCD_STAGGER=1: the eight XCDs start at different points of their tile ranges (cross kernels)
   int walk2d;         // PEA_WALK2D=n: 2D images walk strips of n tiles in x down y (0: row-major)
   int lds_pad;        // PEA_LDS_PAD=bytes: extra dynamic LDS on the cross kernels' launches (occupancy experiments)
@@ -144,6 +147,9 @@ bool xdma_bwd_self(const KParams& P, const float* x, const float* inv, const flo
 bool xdma_bwd_self_h(const KParams& P, const void* x, const float* inv, const float* g, const float* affs, const float* dl, void* dx,
                      hipStream_t s);  // f16 storage (pea_k_xdma_h.hip)
 bool xdma_h_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s);  // f16 storage forward / inference (pea_k_xdma_h.hip)
+// f16 storage backward with producer / consumer waves (pea_k_xdma_hq.hip; D = 32 / 64, small crosses, PEA_H16_HW=2)
+bool xdma_hq_bwd_self(const KParams& P, const void* x, const float* inv, const float* g, const float* affs, const float* dl, void* dx,
+                      hipStream_t s);
 bool xdma_pf_bwd_self(const KParams& P, const float* x, const float* inv, const float* g, const float* affs, const float* dl, float* dx,
                       hipStream_t s);  // the projection-first backward, f32 storage (pea_k_xdma_h.hip)
 bool xdma_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* dl,

@@ -34,12 +34,15 @@ void env_load() {
   g_env.infer_xdma = env_int("PEA_INFER_XDMA", 1);
   g_env.bwd_pf = env_int("PEA_BWD_PF", 1);
   g_env.box = env_int("PEA_BOX", 1);
-  g_env.h16_hw = env_int("PEA_H16_HW", 1);
+  g_env.h16_hw = env_int("PEA_H16_HW", 2);
   g_env.zmarch = env_int("PEA_ZMARCH", 1);
   g_env.zseg = env_int("PEA_ZSEG", 0);
   g_env.zm_nb = env_int("PEA_ZM_NB", 4);
   g_env.boxm = env_int("PEA_BOXM", 1);
   g_env.xcd_stagger = env_int("PEA_XCD_STAGGER", 0);
+  g_env.skew = env_int("PEA_SKEW", -1);
+  g_env.skew_slots = env_int("PEA_SKEW_SLOTS", 4);
+  g_env.skew_mode = env_int("PEA_SKEW_MODE", 0);
   g_env.walk2d = env_int("PEA_WALK2D", 0);
   g_env.lds_pad = env_int("PEA_LDS_PAD", 0);
   g_env.zblk_y = env_int("PEA_ZBLK_Y", 0);

@@ -139,6 +139,7 @@ bool xdma_pf_bwd_self(const KParams& P, const float* x, const float* inv, const 
 bool xdma_bwd_self_h(const KParams& P, const void* x, const float* inv, const float* g, const float* affs, const float* dl, void* dx,
                      hipStream_t s) {
   if (!inv || !env().bwd_xdma || env().force_direct) return false;
+  if (env().h16_hw == 2 && env().bwd_pf && xdma_hq_bwd_self(P, x, inv, g, affs, dl, dx, s)) return true;  // pea_k_xdma_hq.hip
   if (P.D == 16) return bwd_self_h<16>(P, (const __half*)x, inv, g, affs, dl, (__half*)dx, s);
   if (P.D == 32) return bwd_self_h<32>(P, (const __half*)x, inv, g, affs, dl, (__half*)dx, s);
   if (P.D == 64) return bwd_self_h<64>(P, (const __half*)x, inv, g, affs, dl, (__half*)dx, s);

@@ -24,15 +24,17 @@ constexpr int kXdmaPSUS = 27;  // small crosses (reach <= 11 or so): 6912-byte p
 struct XPlan { XParams C; size_t lds; };
 
 // memoised plan_xdma (per thread; keyed by KParams, the plane size and the mode)
-bool plan(const KParams& P, int psu, int mode, XPlan* out) {
+// (th x tw: the tile shape; 8 x 64 for the f16 kernels of pea_xdma_hq.h, whose rows are then whole 128-byte lines)
+bool plan(const KParams& P, int psu, int mode, XPlan* out, int th = kXdmaTH, int tw = kXdmaTW) {
   static thread_local PlanCache<XPlan, 12> cache;
-  return cache.get(P, psu * 4 + mode, out, [&](XPlan* p) {
-    if (!plan_xdma(P, kXdmaTH, kXdmaTW, psu, &p->C, &p->lds, mode)) return false;
+  return cache.get(P, psu * 4 + mode + (tw == kXdmaTW ? 0 : 4096), out, [&](XPlan* p) {
+    if (!plan_xdma(P, th, tw, psu, &p->C, &p->lds, mode)) return false;
     if (env().zblk_y > 0) p->C.zgy = env().zblk_y;
     if (env().zblk_x > 0) p->C.zgx = env().zblk_x;
     if (env().zblk_y < 0) p->C.zrun = 0;  // plane-major walk
     if (P.Z == 1 && env().walk2d > 0) { p->C.zrun = 1; p->C.zgy = p->C.tiles_y; p->C.zgx = env().walk2d; }
     p->C.stagger = env().xcd_stagger;
+    p->C.skew = env().skew > 0 ? env().skew : 0; p->C.skew_slots = env().skew_slots > 0 ? env().skew_slots : 1; p->C.skew_mode = env().skew_mode;
     p->lds += (size_t)env().lds_pad;
     return true;
   });

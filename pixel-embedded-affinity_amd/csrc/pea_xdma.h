@@ -72,7 +72,7 @@ struct XParams {
   int tiles_y, tiles_x, tiles_per_plane, ntiles, tiles_per_xcd;
   int npx, npy;
   int xd[kXP], yd[kXP];    // pixel displacement of the neighbour along x / y  (0 for unused pairs)
-  int xm[kXP];             // strip coordinate mask of the x pair: d < 0 ? SW - 1 : 31
+  int xm[kXP];             // strip coordinate mask of the x pair: d < 0 ? SW - 1 : TW - 1
   int xgi[kXP], ygi[kXP];  // g channel
   int xgo[kXP], ygo[kXP];  // role A: 0 (g at p); role B: -o (g at p - o)
   // z offsets (3D volumes): not staged (a third LDS arm would cost 8 region pixels per pixel and does not fit beside the
@@ -82,6 +82,7 @@ struct XParams {
   int zd[kXZ];             // plane displacement of the neighbour
   int zgi[kXZ], zgo[kXZ];  // g channel; plane displacement of the g sample (role A: 0, role B: -oz)
   int stagger;             // the XCDs start at different points of their tile ranges (xdma_tile)
+  int skew, skew_slots, skew_mode;  // PEA_SKEW (experiment): the first workgroups of a CU start a fraction of a tile time apart
   int zrun;                // > 1: tiles walk z fastest (= Z), so the planes a z offset reaches were staged just before
   int zgy, zgx;            // ... inside blocks of zgy x zgx tiles
   // forward (role A only): in-plane offsets in their own order (nf <= kXP), z offsets (nfz <= kXZ / 2)
@@ -126,6 +127,14 @@ __device__ __forceinline__ bool xdma_tile(const CP& C, const KParams& P, int& ti
   if (C.stagger) { slot += (bid % kXcd) * (C.tiles_per_xcd / kXcd); slot -= slot >= C.tiles_per_xcd ? C.tiles_per_xcd : 0; }
   const int lin = (bid % kXcd) * C.tiles_per_xcd + slot;
   if (lin >= C.ntiles) return false;
+  if (C.skew) {
+    // the workgroups resident on a CU start together and run the same phases: they ask for memory at the same time and compute at the
+    // same time.  Delay the j-th of the first `skew_slots` workgroups of each CU by j * skew * 2048 cycles
+    const int w = bid / kXcd;
+    const int j = C.skew_mode ? w % C.skew_slots : w / 32;
+    if (w < 32 * C.skew_slots)
+      for (int i = 0; i < j * C.skew; ++i) __builtin_amdgcn_s_sleep(32);
+  }
   int plane, rem;
   if (C.zrun >= 1) {
     // walk: blocks of kGY x kGX tiles; inside a block z, then y, then x fastest -- the tiles in flight on an XCD (64) are a few
@@ -1049,8 +1058,8 @@ inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, s
   if (hx > TW) return false;  // a neighbour column is inside the tile or in the strip next to it
   if (left > 0 && right > 0) { C.SW = hx <= 16 ? 32 : 64; C.split = C.SW / 2; }
   else { C.SW = 32; C.split = right > 0 ? 32 : 0; }  // one strip (or none: still one row of 32 per tile row)
-  for (int k = 0; k < kXP; ++k) C.xm[k] = C.xd[k] < 0 ? C.SW - 1 : 31;
-  for (int k = 0; k < kXP; ++k) C.fm[k] = C.fd[k] < 0 ? C.SW - 1 : 31;
+  for (int k = 0; k < kXP; ++k) C.xm[k] = C.xd[k] < 0 ? C.SW - 1 : TW - 1;
+  for (int k = 0; k < kXP; ++k) C.fm[k] = C.fd[k] < 0 ? C.SW - 1 : TW - 1;
   C.QV = (C.hy0 + TH + C.hy1) * TW / 4;
   C.QA = C.QV + TH * C.SW / 4;
   const int nw = TH * TW / 64;

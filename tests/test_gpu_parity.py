@@ -1154,11 +1154,14 @@ def test_chunked_d64_forward_vs_oracle(pkg, dev, orc, synth, monkeypatch, case):
     assert np.abs(got[1] - ref[1]).max() < 2e-6 and abs(got[0] - ref[0]) <= 2e-6 * abs(ref[0])
 
 
-@pytest.mark.parametrize("D,shape,border", [(64, (72, 104), "circular"), (32, (50, 72), "crop"), (16, (37, 64), "circular")])
+@pytest.mark.parametrize("D,shape,border", [(64, (72, 104), "circular"), (32, (50, 72), "crop"), (16, (37, 64), "circular"),
+                                            (64, (50, 136), "crop"), (32, (90, 128), "circular")])
 def test_f16_cross_kernels_both_working_buffers(pkg, dev, orc, synth, monkeypatch, D, shape, border):
     """f16 storage on the LDS-DMA cross kernels (csrc/pea_xdma_h16.h): the half-precision working buffer (forward on v_dot2_f32_f16,
-    backward on v_fma_mix_f32: the default) and the f32 one (PEA_H16_HW=0), each against the C oracle on the rounded inputs, and
-    against each other; training forward, projection-first backward (D >= 32) and inference"""
+    backward on v_fma_mix_f32) with the backward on producer / consumer waves where the image is wide enough for its 8 x 64 tiles
+    (csrc/pea_xdma_hq.h: PEA_H16_HW=2, the default), the same on the LDS-DMA backward (=1) and the f32 working buffer (=0), each against
+    the C oracle on the rounded inputs, and against each other (2 and 1 bit for bit: the same arithmetic in the same order); training
+    forward, projection-first backward (D >= 32) and inference"""
     H, W = shape
     offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)[:8]
     B = 2
@@ -1181,7 +1184,7 @@ def test_f16_cross_kernels_both_working_buffers(pkg, dev, orc, synth, monkeypatc
     o_affs, o_loss = orc.c_fwd(d, e, None, t, w, m)
     o_grad, _ = orc.c_bwd(d, e, None, t, w, m, dloss=0.75)
     res = {}
-    for hw in ("1", "0"):
+    for hw in ("2", "1", "0"):
         monkeypatch.setenv("PEA_H16_HW", hw)
         got = res[hw] = run()
         assert np.abs(got[1].reshape(o_affs.shape) - o_affs).max() < AFFS_ATOL, hw
@@ -1190,6 +1193,7 @@ def test_f16_cross_kernels_both_working_buffers(pkg, dev, orc, synth, monkeypatc
         assert relmax(got[3].reshape(o_grad.shape), o_grad) < 2e-3, hw  # the gradient is stored in half precision
     assert np.abs(res["1"][1] - res["0"][1]).max() < 2e-6
     assert relmax(res["1"][3], res["0"][3]) < 2e-3
+    assert np.array_equal(res["2"][3], res["1"][3]) and np.array_equal(res["2"][1], res["1"][1])
 
 
 @pytest.mark.parametrize("scale", [1e-3, 3e-5, 1e-6])
