@@ -38,7 +38,7 @@ struct Env {
   int boxm;           // PEA_BOXM=0: the unit-box backward per (z, tile) (pea_box.h) instead of marching (pea_boxm.h)
   int zm_nb;          // PEA_ZM_NB=3: the z-march backward with a ring of three buffers instead of four (5 % slower once the waits count loads only)
   int zseg;           // PEA_ZSEG=n: planes per segment of a tile column (0: whole columns where there are enough of them)
-  int skew, skew_slots, skew_mode;  // PEA_SKEW (units of 2048 cycles; -1 = auto: the D = 16 cross backward only, 0 = off) / PEA_SKEW_SLOTS /
+  int skew, skew_slots, skew_mode;  // PEA_SKEW (experiment, off by default: units of 2048 cycles) / PEA_SKEW_SLOTS /
                                     // PEA_SKEW_MODE: the first workgroups of a CU start apart (pea_xdma.h xdma_tile)
   int xcd_stagger;    // PEA_XCD_STAGGER=1: the eight XCDs start at different points of their tile ranges (cross kernels)
   int walk2d;         // PEA_WALK2D=n: 2D images walk strips of n tiles in x down y (0: row-major)

@@ -40,7 +40,7 @@ void env_load() {
   g_env.zm_nb = env_int("PEA_ZM_NB", 4);
   g_env.boxm = env_int("PEA_BOXM", 1);
   g_env.xcd_stagger = env_int("PEA_XCD_STAGGER", 0);
-  g_env.skew = env_int("PEA_SKEW", -1);
+  g_env.skew = env_int("PEA_SKEW", 0);
   g_env.skew_slots = env_int("PEA_SKEW_SLOTS", 4);
   g_env.skew_mode = env_int("PEA_SKEW_MODE", 0);
   g_env.walk2d = env_int("PEA_WALK2D", 0);

@@ -59,13 +59,7 @@ bool bwd_self(const KParams& P, const float* x, const float* inv, const float* g
     if (D_T != 16 || !plan(P, kXdmaPSU3, 0, &X)) return false;
     z3 = true;
   }
-  XParams& C = X.C;
-  // The two workgroups of a CU start together and run the same phases: both ask the vector-memory path for their g values and their
-  // first planes at the same time (a wave instruction costs it 16-18 cycles whatever its width: profiles/microbench/vmem_issue.hip),
-  // then both gather.  Starting the second one half a tile time (about 5 us = 6 x 2048 cycles) later interleaves them for the whole
-  // launch: 2D, D = 16, K = 10 backward 104-110 -> 94-100 us on one box (profiles/r4_skew.txt).  PEA_SKEW=0 switches it off; it needs
-  // a few rounds of tiles per CU to pay for the delay
-  if (D_T == 16 && !z3 && env().skew < 0 && C.tiles_per_xcd >= 32 * 2 * 4) { C.skew = 6; C.skew_slots = 2; C.skew_mode = 0; }
+  const XParams& C = X.C;
   constexpr int XP = D_T > 32 ? 8 : kXP;  // pairs per axis the instantiation keeps in registers
   if (C.npx > (z3 ? 8 : XP) || C.npy > (z3 ? 8 : XP)) return false;
   const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);

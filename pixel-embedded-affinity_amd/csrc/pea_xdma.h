@@ -82,7 +82,7 @@ struct XParams {
   int zd[kXZ];             // plane displacement of the neighbour
   int zgi[kXZ], zgo[kXZ];  // g channel; plane displacement of the g sample (role A: 0, role B: -oz)
   int stagger;             // the XCDs start at different points of their tile ranges (xdma_tile)
-  int skew, skew_slots, skew_mode;  // PEA_SKEW (experiment): the first workgroups of a CU start a fraction of a tile time apart
+  int skew, skew_slots, skew_mode;  // PEA_SKEW (experiment, off by default): the first workgroups of a CU start a fraction of a tile time apart
   int zrun;                // > 1: tiles walk z fastest (= Z), so the planes a z offset reaches were staged just before
   int zgy, zgx;            // ... inside blocks of zgy x zgx tiles
   // forward (role A only): in-plane offsets in their own order (nf <= kXP), z offsets (nfz <= kXZ / 2)
