@@ -12,13 +12,12 @@ for cfg in c1 c1k8 c3 c4 c4n26 c5 c5f32; do
 done
 timeout -k 10 400 python bench.py --batch 32 --steps 100 --no-train --no-section > gpurun_out/r4_b32_bench.json 2> gpurun_out/r4_b32_bench.err || { echo "b32 failed"; tail -5 gpurun_out/r4_b32_bench.err; exit 1; }
 PEA_ZMARCH=0 timeout -k 10 400 python bench.py --config c4 --no-cpu-baseline > gpurun_out/r4_c4_zmarch0_bench.json 2> gpurun_out/r4_c4_zmarch0.err || echo "c4 zmarch0 failed"
-# the same box, the switches of this round's last two changes off: the start skew of the D = 16 backward, the producer / consumer f16 backward
-PEA_SKEW=0 timeout -k 10 400 python bench.py --no-cpu-baseline --no-train --no-section > gpurun_out/r4_c2_skew0_bench.json 2> gpurun_out/r4_c2_skew0.err || echo "c2 skew0 failed"
+# the same box with the producer / consumer f16 backward switched off
 PEA_H16_HW=1 timeout -k 10 400 python bench.py --config c5 --no-cpu-baseline > gpurun_out/r4_c5_hw1_bench.json 2> gpurun_out/r4_c5_hw1.err || echo "c5 hw1 failed"
 bash profiles/run_profile.sh r4 > gpurun_out/r4_profile.txt 2>&1
 python3 - <<'PY'
 import json
-for k in ("bench", "c2_skew0_bench", "c1_bench", "c1k8_bench", "c3_bench", "c4_bench", "c4_zmarch0_bench", "c4n26_bench", "c5_bench", "c5_hw1_bench", "c5f32_bench", "b32_bench"):
+for k in ("bench", "c1_bench", "c1k8_bench", "c3_bench", "c4_bench", "c4_zmarch0_bench", "c4n26_bench", "c5_bench", "c5_hw1_bench", "c5f32_bench", "b32_bench"):
     try:
         j = json.loads(open("gpurun_out/r4_%s.json" % k).read().strip().splitlines()[-1])
     except Exception as ex:
