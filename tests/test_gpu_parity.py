@@ -213,6 +213,30 @@ def test_baseline_config_b8_properties(pkg, dev, synth):
     assert float(a1.abs().max()) <= 1.0 + 1e-5
 
 
+@pytest.mark.parametrize("switch,value", [("PEA_SKEW", "6"), ("PEA_WALK2D", "5"), ("PEA_XCD_STAGGER", "1")])
+def test_walk_and_placement_switches_change_no_bit(pkg, dev, synth, monkeypatch, switch, value):
+    """The tile-walk / start-placement experiments kept as switches (csrc/pea_xdma.h xdma_tile)
+    decide WHEN and WHERE a tile is worked on, never what it computes: loss, map and gradient bit for bit, B=4 x 16 x 272 x 320"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    B, D, H, W = 4, 16, 272, 320
+    e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 77)
+    E, T, Wt, M = cu(e, dev), cu(t, dev), cu(w, dev), cu(m, dev)
+    crit = pkg.WeightedMSE()
+
+    def run():
+        x = E.clone().requires_grad_(True)
+        loss, affs, parts = pkg.embedding_loss(x, T, Wt, M, crit, offsets)
+        loss.backward()
+        return loss.detach(), affs, x.grad
+
+    ref = run()
+    monkeypatch.setenv(switch, value)
+    if switch == "PEA_SKEW":
+        monkeypatch.setenv("PEA_SKEW_SLOTS", "2")
+    got = run()
+    assert all(torch.equal(a, b) for a, b in zip(ref, got))
+
+
 def test_packed_down_tensor_slices_need_no_copy(pkg, dev, orc, synth):
     """scripts_cvppp/main.py:284: target/weight/mask are channel slices of one packed `down` tensor"""
     offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)[:8]
