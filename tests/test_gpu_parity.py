@@ -1179,7 +1179,8 @@ def test_chunked_d64_forward_vs_oracle(pkg, dev, orc, synth, monkeypatch, case):
 
 
 @pytest.mark.parametrize("D,shape,border", [(64, (72, 104), "circular"), (32, (50, 72), "crop"), (16, (37, 64), "circular"),
-                                            (64, (50, 136), "crop"), (32, (90, 128), "circular")])
+                                            (64, (50, 136), "crop"), (32, (90, 128), "circular"), (64, (44, 200), "circular"),
+                                            (32, (41, 168), "crop")])
 def test_f16_cross_kernels_both_working_buffers(pkg, dev, orc, synth, monkeypatch, D, shape, border):
     """f16 storage on the LDS-DMA cross kernels (csrc/pea_xdma_h16.h): the half-precision working buffer (forward on v_dot2_f32_f16,
     backward on v_fma_mix_f32) with the backward on producer / consumer waves where the image is wide enough for its 8 x 64 tiles
