@@ -1,5 +1,6 @@
 #!/bin/bash
 # bash profiles/exp_lab.sh: the labels-in forward (k_fwd_xdma<.., LAB>) timed by rocprofv3 with and without the interior-tile store walk
+# (the walk and its PEA_LAB_SLOW switch existed in that experiment's build only: profiles/r4_lab_interior.txt; kept as the recipe)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for slow in "" 1 "" 1; do
