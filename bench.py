@@ -249,6 +249,50 @@ def settle_gpu(step, budget_s=1.5):
     return settle
 
 
+def gpu_state_under_load(step, seconds=0.8):
+    """clocks / power / temperature of GPU 0 as `rocm-smi` reports them WHILE the step runs (rank 0, diagnostic only: the step's time
+    comes in two states on some boxes -- DESIGN.md section 5 item 2 -- and this says which the run was in).  None if rocm-smi is missing."""
+    import shutil
+    import subprocess
+    import threading
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    res = {}
+
+    def sample():
+        try:
+            o = subprocess.run([smi, "-d", "0", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=10).stdout
+            o = o[o.index("{"):]
+            res.update(next(iter(json.loads(o).values())))
+        except Exception as ex:  # diagnostic only
+            res["error"] = repr(ex)[:120]
+
+    th = threading.Thread(target=sample)
+    t0 = time.perf_counter()
+    th.start()
+    while th.is_alive() or time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+    th.join()
+    num = lambda v: float("".join(ch for ch in str(v) if ch.isdigit() or ch == ".") or "nan")
+    out = {}
+    for k, v in res.items():
+        kl = k.lower()
+        if "clock speed" in kl:
+            out[kl.split()[0] + "_mhz"] = num(v)
+        elif "power" in kl:
+            out["power_w"] = num(v)
+        elif "junction" in kl:
+            out["temp_junction_c"] = num(v)
+        elif "memory" in kl and "temp" in kl:
+            out["temp_memory_c"] = num(v)
+        elif k == "error":
+            out["error"] = v
+    return out or None
+
+
 def wall_time_s(step, fence, steps, warm=5):
     """host wall time of `steps` calls of step() between two fences (this rank)"""
     for _ in range(warm):
@@ -570,6 +614,7 @@ def main():
         loss.backward()
 
     dt_seed = wall_time_s(step_seed, fence, args.steps)
+    gpu_state = gpu_state_under_load(step) if rank == 0 else None  # untimed, after both timed loops
     if dist is not None:
         tmax = torch.tensor([dt_seed], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -693,6 +738,7 @@ def main():
             # pixels are counted on the padded tensor the op processes (544^2 per CVPPP image); the same rate in
             # images and in pixels of the un-padded 530x500 image
             "settle_steps": settle,
+            "gpu_state": gpu_state,
             "ms_per_step_autograd_seed": round(dt_seed / args.steps * 1e3, 5),
             "value_autograd_seed": round(px_per_step * args.steps / dt_seed / 1e6, 2),
             **(train or {}),
