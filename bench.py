@@ -249,48 +249,41 @@ def settle_gpu(step, budget_s=1.5):
     return settle
 
 
-def gpu_state_under_load(step, seconds=0.8):
-    """clocks / power / temperature of GPU 0 as `rocm-smi` reports them WHILE the step runs (rank 0, diagnostic only: the step's time
-    comes in two states on some boxes -- DESIGN.md section 5 item 2 -- and this says which the run was in).  None if rocm-smi is missing."""
-    import shutil
-    import subprocess
-    import threading
-    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
-    if not os.path.exists(smi):
-        return None
-    res = {}
+def gpu_state_under_load(step, dev, seconds=0.8):
+    """clocks / power / temperatures of this rank's GPU WHILE the step runs, read from sysfs (hwmon of the card with the device's PCI
+    address; no child process: nothing may exec behind an initialised GPU, least of all under rocprofv3).  Diagnostic only: the step's
+    time comes in two states on some boxes -- DESIGN.md section 5 item 2 -- and this says what the card reported in the run.  None if
+    the files are not there."""
+    import glob
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        addr = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        hw = None
+        for card in glob.glob("/sys/class/drm/card*/device"):
+            if os.path.basename(os.path.realpath(card)).startswith(addr):
+                hs = glob.glob(os.path.join(card, "hwmon", "hwmon*"))
+                hw = hs[0] if hs else None
+                break
+        if hw is None:
+            return None
 
-    def sample():
-        try:
-            o = subprocess.run([smi, "-d", "0", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=10).stdout
-            o = o[o.index("{"):]
-            res.update(next(iter(json.loads(o).values())))
-        except Exception as ex:  # diagnostic only
-            res["error"] = repr(ex)[:120]
+        def rd(name):
+            try:
+                return float(open(os.path.join(hw, name)).read().strip())
+            except (OSError, ValueError):
+                return None
 
-    th = threading.Thread(target=sample)
-    t0 = time.perf_counter()
-    th.start()
-    while th.is_alive() or time.perf_counter() - t0 < seconds:
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
-    th.join()
-    num = lambda v: float("".join(ch for ch in str(v) if ch.isdigit() or ch == ".") or "nan")
-    out = {}
-    for k, v in res.items():
-        kl = k.lower()
-        if "clock speed" in kl:
-            out[kl.split()[0] + "_mhz"] = num(v)
-        elif "power" in kl:
-            out["power_w"] = num(v)
-        elif "junction" in kl:
-            out["temp_junction_c"] = num(v)
-        elif "memory" in kl and "temp" in kl:
-            out["temp_memory_c"] = num(v)
-        elif k == "error":
-            out["error"] = v
-    return out or None
+        samples, t0 = [], time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(20):
+                step()
+            samples.append((rd("freq1_input"), rd("freq2_input"), rd("power1_input"), rd("temp2_input"), rd("temp3_input")))
+            torch.cuda.synchronize()
+        med = lambda k, sc: (lambda v: round(sorted(v)[len(v) // 2] * sc, 1) if v else None)([x[k] for x in samples if x[k] is not None])
+        return {"sclk_mhz": med(0, 1e-6), "mclk_mhz": med(1, 1e-6), "power_w": med(2, 1e-6), "temp2_c": med(3, 1e-3), "temp3_c": med(4, 1e-3),
+                "samples": len(samples), "source": hw}
+    except Exception as ex:  # diagnostic only
+        return {"error": repr(ex)[:160]}
 
 
 def wall_time_s(step, fence, steps, warm=5):
@@ -614,7 +607,7 @@ def main():
         loss.backward()
 
     dt_seed = wall_time_s(step_seed, fence, args.steps)
-    gpu_state = gpu_state_under_load(step) if rank == 0 else None  # untimed, after both timed loops
+    gpu_state = gpu_state_under_load(step, dev) if rank == 0 else None  # untimed, after both timed loops
     if dist is not None:
         tmax = torch.tensor([dt_seed], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # bash profiles/exp_skew3.sh: the headline step with (PEA_SKEW=6, two slots) and without the start skew of the D = 16 backward,
-# alternating, same flags; prints bench.py's gpu_state (rocm-smi clocks / power / temperature under load) beside each run
+# alternating, same flags; prints bench.py's gpu_state (the card's hwmon clocks / power / temperatures under load) beside each run
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for i in 1 2 3 4; do for sk in 6 0; do
   PEA_SKEW=$sk PEA_SKEW_SLOTS=2 timeout -k 10 120 python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-train --no-section $EXTRA > /tmp/sk.json 2>/tmp/sk.err || { echo "FAILED"; tail -3 /tmp/sk.err; continue; }

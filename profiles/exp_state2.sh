@@ -6,7 +6,7 @@ for i in $(seq 1 ${N:-8}); do
   python3 - <<'PY'
 import json
 j = json.loads(open('/tmp/st.json').read().strip().splitlines()[-1]); k = j['kernel_ms']; g = j.get('gpu_state') or {}
-print('step %.4f  fwd %.1f  bwd %.1f  sclk %s  fclk %s  power %s W  T %s / %s C' % (j['ms_per_step'], k['fwd'] * 1e3, k['bwd'] * 1e3, g.get('sclk_mhz'), g.get('fclk_mhz'),
-      g.get('power_w'), g.get('temp_junction_c'), g.get('temp_memory_c')))
+print('step %.4f  fwd %.1f  bwd %.1f  sclk %s  mclk %s  power %s W  T %s / %s C' % (j['ms_per_step'], k['fwd'] * 1e3, k['bwd'] * 1e3, g.get('sclk_mhz'), g.get('mclk_mhz'),
+      g.get('power_w'), g.get('temp2_c'), g.get('temp3_c')))
 PY
 done
