@@ -18,9 +18,9 @@
 //     instead of three times: SQ_LDS_IDX_ACTIVE 58 M -> 30 M), one ds_read_b64 per pair for four channels (two LDS cycles, like the
 //     ds_read_b32 it replaces: MI355X_MICROARCH.md section LDS);
 //   * 8 x 64 tiles: a tile row is one whole 128-byte line of an f16 plane, loads and stores alike.
-// A quad's two 16-byte pieces swap places in every second 128-byte block (hq_addr): 32-byte-strided writers then spread over the
-// banks, and reads stay conflict-free for any start pixel of a row (u -> u ^ (bit4(u) << 1) is a bijection on the 32 eight-byte units
-// of a read).  Arithmetic, order of operations and results are those of k_bwd_xdma_h<PF, HW>, bit for bit.
+// A quad's two 16-byte pieces swap places in every second 128-byte block (hq_addr): reads stay conflict-free for any start pixel of
+// a row (u -> u ^ (bit4(u) << 1) is a bijection on the 32 eight-byte units of a read) and writers a quad (32 bytes) apart spread over
+// the banks; the producers' octs are 64 bytes apart and take two passes per ds_write_b128 -- off the consumers' path.  Arithmetic, order of operations and results are those of k_bwd_xdma_h<PF, HW>, bit for bit.
 // Measured and NOT kept (same file, removed): the forward in the same two forms -- every wave staging quads (162-169 us against
 // 157-161 for k_fwd_xdma_h), producer / consumer waves with octs (184 us): the forward has no stores in its chunk loop to decouple and
 // three or four workgroups per CU already hide its loads; the backward with every wave loading AND storing (285-307 us); three and
