@@ -50,14 +50,30 @@ CONFIGS = {
                shifts=[1, 3, 5, 9, 27], K=8, f16=True),
     "c5f32": dict(what="the shape of BASELINE configs[4] with f32 storage (comparison line: D=64 on the LDS-DMA cross kernels)", ndim=2, B=8, D=64,
                   dims=(544, 544), shifts=[1, 3, 5, 9, 27], K=8, f16=False),
+    # the BBBC039V1 TRAINING shape: 256 x 256 crops, batch 8 (scripts_bbbc039v1/config/bbbc039v1.yaml:48,63)
+    "c3crop": dict(what="BASELINE configs[2], training crops: BBBC039V1 embedding_loss fwd+bwd on 256x256 crops", ndim=2, B=8, D=32, dims=(256, 256),
+                   shifts=[1, 3, 5, 9, 11], K=10, f16=False),
+    # the EMA cross loss (ema_embedding_loss / ema_embedding_loss_norm5: the second operand detached, scripts_cvppp/main.py:293,
+    # scripts_ac3ac4/main.py:224): every training step of every tree calls it beside the self loss.  Algorithmic bytes: + es * D per pass
+    "c2ema": dict(what="BASELINE configs[1], the EMA cross loss: ema_embedding_loss fwd+bwd (second operand detached)", ndim=2, B=8, D=16,
+                  dims=(544, 544), shifts=[1, 3, 5, 9, 27], K=10, f16=False, ema=True),
+    "c3ema": dict(what="BASELINE configs[2], the EMA cross loss: ema_embedding_loss fwd+bwd (second operand detached)", ndim=2, B=8, D=32,
+                  dims=(704, 704), shifts=[1, 3, 5, 9, 11], K=10, f16=False, ema=True),
+    "c4ema": dict(what="BASELINE configs[3], the EMA cross loss: ema_embedding_loss_norm5 fwd+bwd (second operand detached), one 24x1024x1024 sub-volume",
+                  ndim=3, B=1, D=16, dims=(24, 1024, 1024), stencil="norm5", K=12, f16=False, ema=True),
+    "c5ema": dict(what="BASELINE configs[4], the EMA cross loss: ema_embedding_loss fwd+bwd (second operand detached), f16 storage", ndim=2, B=8, D=64,
+                  dims=(544, 544), shifts=[1, 3, 5, 9, 27], K=8, f16=True, ema=True),
 }
 
 
-def algorithmic_bytes_per_px(D, K, es=4, mask=True):
+def algorithmic_bytes_per_px(D, K, es=4, mask=True, ema=False):
     """fwd es*D + (4+4+[1]+4)K, bwd 2*es*D + (4+4+[1])K; es = bytes per embedding element (4, or 2 for f16
-    storage).  2D f32 with the u8 mask: fwd 4D+13K, bwd 8D+9K, fwd+bwd 12D+22K; 3D (no mask): 12D+20K."""
+    storage).  2D f32 with the u8 mask: fwd 4D+13K, bwd 8D+9K, fwd+bwd 12D+22K; 3D (no mask): 12D+20K.  The EMA cross loss reads
+    the second operand once more per pass: + es*D each (20D+22K)."""
     km = 1 if mask else 0
     fwd, bwd = es * D + (12 + km) * K, 2 * es * D + (8 + km) * K
+    if ema:
+        fwd, bwd = fwd + es * D, bwd + es * D
     return {"fwd": fwd, "bwd": bwd, "step": fwd + bwd}
 
 
@@ -131,6 +147,11 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
     if c["f16"]:
         E = E.half()
     E.requires_grad_(True)
+    ema = bool(c.get("ema"))
+    E2 = None
+    if ema:  # the EMA embedding: the detached second operand (convert_consistency_flip detaches it, data_consistency.py:36)
+        E2 = torch.randn([B, Dm] + dims, generator=g, device=dev)
+        E2 = E2.half() if c["f16"] else E2
     T = (torch.rand([B, K] + dims, generator=g, device=dev) < 0.6).float()
     Wt = torch.rand([B, K] + dims, generator=g, device=dev) + 0.5
     M = (torch.rand([B, K] + dims, generator=g, device=dev) < 0.9).to(torch.uint8) if c["ndim"] == 2 else None
@@ -148,27 +169,19 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
 
     def step():
         E.grad = None
-        loss, affs, _ = op.FusedAffinityMSE.apply(E, None, T, Wt, M, spec)
+        loss, affs, _ = op.FusedAffinityMSE.apply(E, E2, T, Wt, M, spec)
         pkg.backward(loss)  # loss.backward() seeded with a cached ones-scalar (no per-step fill kernel)
 
     settle = settle_gpu(step)
     for _ in range(max(args.warmup, 3)):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    bst = batch_stats(timed_batches(step, fence, args.steps, dist, dev), args.steps)  # median of N_BATCHES batches (see main())
+    dt = bst["median"] * 1e-3 * args.steps
     # the same step started with plain loss.backward() -- what a drop-in caller of INTEGRATION.md section 2 executes (autograd seeds
     # the scalar's backward with a ones_like fill kernel); untimed for `value`, reported beside it
     def step_seed():
         E.grad = None
-        loss, affs, _ = op.FusedAffinityMSE.apply(E, None, T, Wt, M, spec)
+        loss, affs, _ = op.FusedAffinityMSE.apply(E, E2, T, Wt, M, spec)
         loss.backward()
 
     dt_seed = wall_time_s(step_seed, fence, args.steps)
@@ -181,33 +194,38 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
     affs, G = torch.empty([B, K] + dims, device=dev), torch.empty([B, K] + dims, device=dev)
     lossv, dE, one = torch.empty(1 + K, device=dev), torch.empty_like(Ed), torch.ones((), device=dev)
     # the 1 / norm plane only where the cross backward takes it (as affinity_op.FusedAffinityMSE does)
-    INV = torch.empty([B] + dims, device=dev) if L.pea_cross_supported(ctypes.byref(desc), 1) else None
+    if ema:  # two planes (e, e_other) where the role-A cross kernels take the shape
+        INV = torch.empty([2, B] + dims, device=dev) if L.pea_cross_supported(ctypes.byref(desc), 2) else None
+    else:
+        INV = torch.empty([B] + dims, device=dev) if L.pea_cross_supported(ctypes.byref(desc), 1) else None
     wsb = L.pea_workspace_bytes(ctypes.byref(desc))
     work = torch.empty(max(wsb, 4) // 4, device=dev)
     assert L.pea_workspace_init(ctypes.c_void_p(work.data_ptr()), wsb, None) == 0  # the loss-state block: prepared once
     P = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())
     cur = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # (read per call: the graph capture runs on its own stream)
-    fwd = lambda: L.pea_affinity_fwd_ex(ctypes.byref(desc), P(Ed), None, P(T), P(Wt), P(M), P(affs), P(G), P(INV), P(lossv), P(work), wsb, cur())
-    bwd = lambda: L.pea_affinity_bwd_ex2(ctypes.byref(desc), P(Ed), None, P(G), P(INV), P(affs), P(one), P(dE), None, cur())
+    fwd = lambda: L.pea_affinity_fwd_ex(ctypes.byref(desc), P(Ed), P(E2), P(T), P(Wt), P(M), P(affs), P(G), P(INV), P(lossv), P(work), wsb, cur())
+    bwd = lambda: L.pea_affinity_bwd_ex2(ctypes.byref(desc), P(Ed), P(E2), P(G), P(INV), None if ema else P(affs), P(one), P(dE), None, cur())
     in_step_times_ms(fwd, bwd, 3)
-    kf, kb = in_step_times_ms(fwd, bwd, max(10, min(args.steps, 50)))
-    ab = algorithmic_bytes_per_px(Dm, K, 2 if c["f16"] else 4, mask=M is not None)
+    kf, kb, kspread = in_step_batches_ms(fwd, bwd, max(10, min(args.steps, 50)), nb=5)
+    ab = algorithmic_bytes_per_px(Dm, K, 2 if c["f16"] else 4, mask=M is not None, ema=ema)
     dom = "bwd" if kb >= kf else "fwd"
     achieved = ab[dom] * npx / (max(kf, kb) * 1e-3) / 1e9
     step_gbs = ab["step"] * npx / ((kf + kb) * 1e-3) / 1e9
     out = {
         "metric": "affinity-map Mpixels/sec (fwd+bwd)", "value": round(value, 2), "unit": "Mpx/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
+        "ms_min": round(bst["min"], 5), "ms_max": round(bst["max"], 5), "batches_ms": bst["all"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 storage / f32 arithmetic" if c["f16"] else "f32",
         "data": "synthetic",
         "config": {"workload": "%s: B=%d per GPU x D=%d x %s, K=%d offsets" % (c["what"], B, Dm, "x".join(str(v) for v in dims), K),
                    "images_per_gpu": B, "embedding_dim": Dm, "dims": dims, "offsets": K, "sharding": "batch across ranks, no data-path collective"},
         "ms_per_step_autograd_seed": round(dt_seed / args.steps * 1e3, 5), "settle_steps": settle,
-        "kernel_ms": {"fwd": round(kf, 5), "bwd": round(kb, 5)},
+        "kernel_ms": {"fwd": round(kf, 5), "bwd": round(kb, 5)}, "kernel_ms_spread": kspread,
         # the launch floor as a number: the entry points' launches (forward + loss finish + backward) captured in a
         # HIP graph and replayed back to back -- no Python, no ctypes, no autograd between them
         "graph_replay_ms": graph_replay_ms(fwd, bwd, max(20, min(args.steps, 200))),
-        "cross_kernels": {"fwd": int(L.pea_cross_supported(ctypes.byref(desc), 0)), "bwd": int(L.pea_cross_supported(ctypes.byref(desc), 1))},
+        "cross_kernels": ({"fwd+bwd (second operand)": int(L.pea_cross_supported(ctypes.byref(desc), 2))} if ema else
+                          {"fwd": int(L.pea_cross_supported(ctypes.byref(desc), 0)), "bwd": int(L.pea_cross_supported(ctypes.byref(desc), 1))}),
         "roofline": {"bound": "hbm", "kernel": "pea_affinity_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.config, dom) if B == c["B"] else None,
                      "algorithmic_bytes_per_px": ab[dom], "px_per_launch": npx,
@@ -217,7 +235,8 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
         # bounded sample: one image (2D) / one 24 x 256 x 256 block of the sub-volume (3D), same op sequence on the host cores
         if c["ndim"] == 2:
             out["cpu_baseline"] = cpu_baseline(offsets, Ed[:1].float().cpu(), T[:1].cpu(), Wt[:1].cpu(), M[:1].cpu(),
-                                               what="the image" if B == 1 else "1 image of the batch")
+                                               what="the image" if B == 1 else "1 image of the batch",
+                                               ema=None if E2 is None else E2[:1].float().cpu())
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["best_cpu_value"], 1)  # vs the faster CPU line
         elif c["stencil"] == "n26":
             sl = (slice(0, 1), slice(None), slice(None), slice(0, 256), slice(0, 256))
@@ -227,7 +246,8 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
             sl = (slice(0, 1), slice(None), slice(None), slice(0, 256), slice(0, 256))
             out["cpu_baseline"] = cpu_baseline(None, Ed[sl].float().cpu().contiguous(), T[:, :12][sl].cpu().contiguous(), Wt[:, :12][sl].cpu().contiguous(),
                                                None, shifts3d=pkg.utils.affinity_ours.NORM5_SHIFTS,
-                                               what="a 24x256x256 block of the sub-volume with the norm5 stencil (K=12)")
+                                               what="a 24x256x256 block of the sub-volume with the norm5 stencil (K=12)",
+                                               ema=None if E2 is None else E2[sl].float().cpu().contiguous())
     return out
 
 
@@ -286,6 +306,34 @@ def gpu_state_under_load(step, dev, seconds=0.8):
         return {"error": repr(ex)[:160]}
 
 
+N_BATCHES = 7  # timed batches of --steps steps each: `value` is their MEDIAN (one batch of 20 steps is 4.5 ms -- a slow
+               # state of the box / process silently became the round's number; now it shows as ms_min / ms_max beside the median)
+
+
+def timed_batches(step, fence, steps, dist, red_dev, nb=N_BATCHES):
+    """nb batches of EXACTLY `steps` calls of step(), each bracketed by fence() (barrier + synchronize) on both sides; per batch the MAX
+    over ranks.  Returns the list of batch durations in seconds, in the order they ran."""
+    out = []
+    for _ in range(nb):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        out.append(time.perf_counter() - t0)
+    if dist is not None:
+        tmax = torch.tensor(out, dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        out = [float(v) for v in tmax.tolist()]
+    return out
+
+
+def batch_stats(dts, steps):
+    """median / min / max of the batches, as ms per step"""
+    ms = sorted(d / steps * 1e3 for d in dts)
+    return {"median": ms[len(ms) // 2], "min": ms[0], "max": ms[-1], "all": [round(d / steps * 1e3, 5) for d in dts]}
+
+
 def wall_time_s(step, fence, steps, warm=5):
     """host wall time of `steps` calls of step() between two fences (this rank)"""
     for _ in range(warm):
@@ -298,9 +346,9 @@ def wall_time_s(step, fence, steps, warm=5):
     return time.perf_counter() - t0
 
 
-def graph_replay_ms(fwd, bwd, iters):
-    """fwd(); bwd() (C-ABI launches on the current stream) captured once in a HIP graph; average duration of a replay, replays
-    queued back to back (HIP events around the batch).  None if the capture fails."""
+def graph_replay_ms(fwd, bwd, iters, per_graph=1):
+    """`per_graph` x (fwd(); bwd()) (C-ABI launches on the current stream) captured once in a HIP graph; average duration of ONE
+    fwd + bwd step over `iters` replays queued back to back (HIP events around the batch).  None if the capture fails."""
     try:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -310,7 +358,8 @@ def graph_replay_ms(fwd, bwd, iters):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            assert fwd() == 0 and bwd() == 0
+            for _ in range(per_graph):
+                assert fwd() == 0 and bwd() == 0
         for _ in range(5):
             g.replay()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -319,7 +368,7 @@ def graph_replay_ms(fwd, bwd, iters):
             g.replay()
         b.record()
         b.synchronize()
-        return round(a.elapsed_time(b) / iters, 5)
+        return round(a.elapsed_time(b) / iters / per_graph, 5)
     except Exception:  # noqa: BLE001 -- an extra field, never the headline
         return None
 
@@ -389,6 +438,21 @@ def in_step_times_ms(fwd, bwd, iters):
     return (sum(a.elapsed_time(b) for a, b, _ in ev) / iters, sum(b.elapsed_time(c) for _, b, c in ev) / iters)
 
 
+def in_step_batches_ms(fwd, bwd, iters, nb=N_BATCHES):
+    """in_step_times_ms over nb batches: per entry point the median batch with the fastest and the slowest beside it"""
+    rs = [in_step_times_ms(fwd, bwd, iters) for _ in range(nb)]
+    f, b = sorted(r[0] for r in rs), sorted(r[1] for r in rs)
+    return f[nb // 2], b[nb // 2], {"fwd_min": round(f[0], 5), "fwd_max": round(f[-1], 5), "bwd_min": round(b[0], 5), "bwd_max": round(b[-1], 5)}
+
+
+# switches that select kernels (csrc/pea_k_direct.hip env_make) + the library override: with one of them set, another kernel than the
+# profiled one may be running.  (Round-4 advice: the bare PEA_ prefix also caught PEA_BENCH_EXTRA, PEA_STEPS, ... and silently nulled
+# the roofline's traffic field.)
+KERNEL_SWITCHES = ("PEA_FORCE_DIRECT", "PEA_FWD_XDMA", "PEA_BWD_XDMA", "PEA_LABELS_DUAL", "PEA_FWD_WG3", "PEA_INFER_XDMA", "PEA_BWD_PF", "PEA_BOX",
+                   "PEA_H16_HW", "PEA_ZMARCH", "PEA_ZSEG", "PEA_ZM_NB", "PEA_BOXM", "PEA_XCD_STAGGER", "PEA_SKEW", "PEA_SKEW_SLOTS", "PEA_SKEW_MODE",
+                   "PEA_WALK2D", "PEA_LDS_PAD", "PEA_ZBLK_Y", "PEA_ZBLK_X", "PEA_BWD_REV", "PEA_BWD_W3", "PEA_BWD_VEC", "PEA_HIP_LIB")
+
+
 def pmc_traffic(key, dom):
     """PMC-measured HBM bytes per launch of the dominant entry point's kernel, recorded by profiles/make_traffic.py from a
     rocprofv3 --pmc run of THESE sources (null when the kernel sources changed since)"""
@@ -398,7 +462,7 @@ def pmc_traffic(key, dom):
     tj = json.load(open(tpath))
     rec = tj.get(key, {}).get(dom)
     # (recorded with the default switches: under a PEA_* override another kernel may run)
-    if any(k.startswith("PEA_") for k in os.environ):
+    if any(k in os.environ for k in KERNEL_SWITCHES):
         return None
     return rec.get("bytes_per_launch") if rec and tj.get("src_sha16") == source_sha16() else None
 
@@ -428,7 +492,7 @@ def isolated_time_ms(fn, iters):
     return tot / iters
 
 
-def cpu_baseline(offsets, e, t, w, m, budget_s=20.0, shifts3d=None, what=None):
+def cpu_baseline(offsets, e, t, w, m, budget_s=20.0, shifts3d=None, what=None, ema=None):
     """The reference's arithmetic (F.normalize -> K x roll/mul/sum -> WeightedMSE -> autograd backward; 3D: the cropped slices of
     embedding_loss_norm5) as the oracle's torch-CPU restatement, on all host cores, on a bounded sample of the workload (numpy
     arrays or CPU tensors); at most ~budget_s of CPU work.  The only place bench.py touches the oracle."""
@@ -438,13 +502,14 @@ def cpu_baseline(offsets, e, t, w, m, budget_s=20.0, shifts3d=None, what=None):
     torch.set_num_threads(cores)
     et, tt, wt = (torch.as_tensor(x) for x in (e, t, w))
     mt = None if m is None else torch.as_tensor(m)
+    emt = None if ema is None else torch.as_tensor(ema)  # the EMA cross loss: the detached second operand
 
     def one():
         x = et.clone().requires_grad_(True)
         if shifts3d is not None:
-            loss = orc.torch_embedding_loss_3d(x, tt, wt, shifts3d)[0]
+            loss = orc.torch_embedding_loss_3d(x, tt, wt, shifts3d, ema=emt)[0]
         else:
-            loss = orc.torch_embedding_loss(x, tt, wt, mt, offsets)[0]
+            loss = orc.torch_embedding_loss(x, tt, wt, mt, offsets, ema=emt)[0]
         loss.backward()
         return float(loss.detach())
 
@@ -465,14 +530,14 @@ def cpu_baseline(offsets, e, t, w, m, budget_s=20.0, shifts3d=None, what=None):
     # of the torch port and this one
     en, tn, wn = (np.ascontiguousarray(x.numpy()) for x in (et, tt, wt))
     mn = None if mt is None else np.ascontiguousarray(mt.numpy())
+    on = None if emt is None else np.ascontiguousarray(emt.numpy())
     d = orc.desc_3d(en, shifts3d) if shifts3d is not None else orc.desc_2d(en, offsets)
 
     def c_once(sl):
         t0 = time.perf_counter()
-        orc.c_fwd(d if sl is None else d1, en[sl] if sl is not None else en, None, tn[sl] if sl is not None else tn,
-                  wn[sl] if sl is not None else wn, None if mn is None else (mn[sl] if sl is not None else mn))
-        orc.c_bwd(d if sl is None else d1, en[sl] if sl is not None else en, None, tn[sl] if sl is not None else tn,
-                  wn[sl] if sl is not None else wn, None if mn is None else (mn[sl] if sl is not None else mn))
+        cut = (lambda a: None if a is None else a[sl]) if sl is not None else (lambda a: a)
+        orc.c_fwd(d if sl is None else d1, cut(en), cut(on), cut(tn), cut(wn), cut(mn))
+        orc.c_bwd(d if sl is None else d1, cut(en), cut(on), cut(tn), cut(wn), cut(mn))
         return time.perf_counter() - t0
 
     prev = orc.c_set_threads(cores)
@@ -491,7 +556,7 @@ def cpu_baseline(offsets, e, t, w, m, budget_s=20.0, shifts3d=None, what=None):
         et1, tt1, wt1, mt1 = et[:1], tt[:1], wt[:1], (None if mt is None else mt[:1])
         t0 = time.perf_counter()
         x = et1.clone().requires_grad_(True)
-        orc.torch_embedding_loss(x, tt1, wt1, mt1, offsets)[0].backward()
+        orc.torch_embedding_loss(x, tt1, wt1, mt1, offsets, ema=None if emt is None else emt[:1])[0].backward()
         d1t = time.perf_counter() - t0
         torch.set_num_threads(cores)
         out["torch_1thread"] = {"value": round(en[0, 0].size / d1t / 1e6, 4), "unit": "Mpx/s", "cores": 1, "kind": "port",
@@ -587,16 +652,10 @@ def main():
     settle = settle_gpu(step)
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    # N_BATCHES timed batches of exactly --steps steps, each between barrier + synchronize, max over ranks per batch; the MEDIAN batch is
+    # the headline, the fastest and the slowest are printed beside it
+    bst = batch_stats(timed_batches(step, fence, args.steps, dist, "cpu" if shared else dev), args.steps)
+    dt = bst["median"] * 1e-3 * args.steps
     px_per_step = world * B * H * W
     value = px_per_step * args.steps / dt / 1e6
     # the same step started with plain loss.backward(): what a drop-in caller executes -- autograd seeds a
@@ -712,7 +771,7 @@ def main():
         kt_iso = {name: isolated_time_ms(fn, 20) for name, fn in (("fwd", fwd), ("bwd", bwd))}
         # the roofline uses the in-step durations (kt["fwd"] includes the loss reduction launch, as the step does)
         in_step_times_ms(fwd, bwd, 10)
-        kt["fwd"], kt["bwd"] = in_step_times_ms(fwd, bwd, max(20, min(args.steps, 200)))
+        kt["fwd"], kt["bwd"], kspread = in_step_batches_ms(fwd, bwd, max(20, min(args.steps, 200)))
         section = None if args.no_section else section_us()
         ab = algorithmic_bytes_per_px(D, K)
         dom = "bwd" if kt["bwd"] >= kt["fwd"] else "fwd"
@@ -723,6 +782,8 @@ def main():
         out = {
             "metric": "affinity-map Mpixels/sec (fwd+bwd)", "value": round(value, 2), "unit": "Mpx/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
+            "ms_min": round(bst["min"], 5), "ms_max": round(bst["max"], 5), "batches_ms": bst["all"],
+            "timing": "median of %d batches of %d steps (each between barrier + synchronize; max over ranks per batch)" % (N_BATCHES, args.steps),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: CVPPP A1 embedding_loss fwd+bwd, B=%d per GPU x D=%d x %dx%d (530x500 padded), "
                                    "K=%d offsets (shifts 1,3,5,9,27 x neighbor 4), circular border, u8 mask" % (B, D, H, W, K),
@@ -738,7 +799,13 @@ def main():
             "images_per_s_op_only": round(value * 1e6 / (H * W), 1),
             "value_530x500_equiv": round(value * (530 * 500) / (H * W), 2),
             "kernel_ms": {k: round(v, 5) for k, v in kt.items()},
+            "kernel_ms_spread": kspread,  # fwd / bwd above are the medians of the same number of in-step batches
+            # forward + loss finish + backward captured in a HIP graph and replayed back to back.  One step per graph pays the graph
+            # launch's own fixed cost every step (MI355X_MICROARCH.md, graph-replay-floor: 10-16 us per replay, not hidden behind the
+            # previous replay -- why round 4's one-step figure was SLOWER than the eager loop, whose launches queue ahead of the GPU);
+            # eight steps per graph amortise it: that figure is the launch floor
             "graph_replay_ms": graph_replay_ms(fwd, bwd, max(20, min(args.steps, 200))),
+            "graph_replay_x8_ms": graph_replay_ms(fwd, bwd, max(5, min(args.steps, 200) // 8), per_graph=8),
             "kernel_sum_mpx_s": round(B * H * W / ((kt["fwd"] + kt["bwd"]) * 1e-3) / 1e6, 1),
             "infer_mpx_s": round(B * H * W / (kt["infer"] * 1e-3) / 1e6, 1),
             "labels_step_mpx_s": round(B * H * W / (kt["labels_step"] * 1e-3) / 1e6, 1),

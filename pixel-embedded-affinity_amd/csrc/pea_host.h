@@ -44,6 +44,11 @@ struct Env {
   int walk2d;         // PEA_WALK2D=n: 2D images walk strips of n tiles in x down y (0: row-major)
   int lds_pad;        // PEA_LDS_PAD=bytes: extra dynamic LDS on the cross kernels' launches (occupancy experiments)
   int zblk_y, zblk_x; // PEA_ZBLK_Y / PEA_ZBLK_X: tiles per block of the z-fastest walk of 3D volumes (0: the default 4 x 2; Y < 0: plane-major)
+  int bwd_rev;        // PEA_BWD_REV=0: the 2D cross backward walks every XCD's tile range first tile first.  Default 1: LAST tile first -- what
+                      //   the forward touched last (the bottom rows of every image: e read, g and 1 / norm written) is what the backward
+                      //   asks for first, and the next forward starts where the backward ended (-1.7 % / -0.8 %, profiles/r5_switch1.txt)
+  int bwd_w3;         // PEA_BWD_W3=1: the D = 16 self-loss backward on three workgroups per CU (pea_xdma_w3.h)
+  int bwd_vec;        // PEA_BWD_VEC=1: k_bwd_xdma's 16-byte g loads / stores instantiation
 };
 const Env& env();
 void env_reload();          // pea_reload_env(): tests that change a switch call it

@@ -23,41 +23,57 @@ int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
 }
-Env g_env;
-std::once_flag g_env_once;
-void env_load() {
-  g_env.force_direct = env_int("PEA_FORCE_DIRECT", 0);
-  g_env.fwd_xdma = env_int("PEA_FWD_XDMA", 1);
-  g_env.bwd_xdma = env_int("PEA_BWD_XDMA", 1);
-  g_env.labels_dual = env_int("PEA_LABELS_DUAL", 1);
-  g_env.fwd_wg3 = env_int("PEA_FWD_WG3", 1);
-  g_env.infer_xdma = env_int("PEA_INFER_XDMA", 1);
-  g_env.bwd_pf = env_int("PEA_BWD_PF", 1);
-  g_env.box = env_int("PEA_BOX", 1);
-  g_env.h16_hw = env_int("PEA_H16_HW", 2);
-  g_env.zmarch = env_int("PEA_ZMARCH", 1);
-  g_env.zseg = env_int("PEA_ZSEG", 0);
-  g_env.zm_nb = env_int("PEA_ZM_NB", 4);
-  g_env.boxm = env_int("PEA_BOXM", 1);
-  g_env.xcd_stagger = env_int("PEA_XCD_STAGGER", 0);
-  g_env.skew = env_int("PEA_SKEW", 0);
-  g_env.skew_slots = env_int("PEA_SKEW_SLOTS", 4);
-  g_env.skew_mode = env_int("PEA_SKEW_MODE", 0);
-  g_env.walk2d = env_int("PEA_WALK2D", 0);
-  g_env.lds_pad = env_int("PEA_LDS_PAD", 0);
-  g_env.zblk_y = env_int("PEA_ZBLK_Y", 0);
-  g_env.zblk_x = env_int("PEA_ZBLK_X", 0);
+// The switch set is immutable once published: env_reload() builds a NEW set and swaps the pointer (the old one is left in place: a
+// handful of bytes per reload, and reloads happen in tests only), so a launch on another thread sees the old set or the new one, never
+// a half-written mix (round-4 advice: a plan sized for one ring depth launched with another).
+std::atomic<const Env*> g_env_cur{nullptr};
+std::mutex g_env_mu;
+const Env* env_make() {
+  Env* e = new Env();
+  e->force_direct = env_int("PEA_FORCE_DIRECT", 0);
+  e->fwd_xdma = env_int("PEA_FWD_XDMA", 1);
+  e->bwd_xdma = env_int("PEA_BWD_XDMA", 1);
+  e->labels_dual = env_int("PEA_LABELS_DUAL", 1);
+  e->fwd_wg3 = env_int("PEA_FWD_WG3", 1);
+  e->infer_xdma = env_int("PEA_INFER_XDMA", 1);
+  e->bwd_pf = env_int("PEA_BWD_PF", 1);
+  e->box = env_int("PEA_BOX", 1);
+  e->h16_hw = env_int("PEA_H16_HW", 2);
+  e->zmarch = env_int("PEA_ZMARCH", 1);
+  e->zseg = env_int("PEA_ZSEG", 0);
+  e->zm_nb = env_int("PEA_ZM_NB", 4);
+  e->boxm = env_int("PEA_BOXM", 1);
+  e->xcd_stagger = env_int("PEA_XCD_STAGGER", 0);
+  e->skew = env_int("PEA_SKEW", 0);
+  e->skew_slots = env_int("PEA_SKEW_SLOTS", 4);
+  e->skew_mode = env_int("PEA_SKEW_MODE", 0);
+  e->walk2d = env_int("PEA_WALK2D", 0);
+  e->lds_pad = env_int("PEA_LDS_PAD", 0);
+  e->zblk_y = env_int("PEA_ZBLK_Y", 0);
+  e->zblk_x = env_int("PEA_ZBLK_X", 0);
+  e->bwd_rev = env_int("PEA_BWD_REV", 1);
+  e->bwd_w3 = env_int("PEA_BWD_W3", 0);
+  e->bwd_vec = env_int("PEA_BWD_VEC", 0);
+  return e;
 }
+std::atomic<unsigned> g_env_gen{1};
 }  // namespace
 const Env& env() {
-  std::call_once(g_env_once, env_load);
-  return g_env;
+  const Env* e = g_env_cur.load(std::memory_order_acquire);
+  if (!e) {
+    std::lock_guard<std::mutex> lk(g_env_mu);
+    e = g_env_cur.load(std::memory_order_acquire);
+    if (!e) {
+      e = env_make();
+      g_env_cur.store(e, std::memory_order_release);
+    }
+  }
+  return *e;
 }
-namespace { std::atomic<unsigned> g_env_gen{1}; }
 void env_reload() {
-  (void)env();
-  env_load();
-  g_env_gen.fetch_add(1, std::memory_order_relaxed);
+  std::lock_guard<std::mutex> lk(g_env_mu);
+  g_env_cur.store(env_make(), std::memory_order_release);
+  g_env_gen.fetch_add(1, std::memory_order_release);
 }
 unsigned env_generation() { return g_env_gen.load(std::memory_order_relaxed); }
 
