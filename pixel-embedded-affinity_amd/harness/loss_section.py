@@ -102,24 +102,29 @@ class _TensorSection(torch.autograd.Function):
                     m, ms = op._batch_strided(m, "mask", torch.uint8, kshape)
                 d = op.make_desc(spec, e_c, ts, ws, ms)
                 work, wsb = op.workspace(dev, d)
-                affs = torch.empty(kshape, dtype=torch.float32, device=dev) if want_affs else None
                 g = torch.empty(kshape, dtype=torch.float32, device=dev)
                 inv = None
-                if planes and L.pea_cross_supported(ctypes.byref(d), planes):
+                if planes and op.cross_supported(d, planes):
                     inv = torch.empty(((planes,) if planes == 2 else ()) + (e_c.shape[0],) + tuple(e_c.shape[2:]), dtype=torch.float32,
                                       device=dev)
+                # the RAW cosine map is an input of the projection-first backward (D > 16, f16) and of the z-march backward (3D):
+                # written also for a loss whose map nobody asked for, where one of those kernels takes the shape (mode 3) -- round-4
+                # advice: without it the section's 3D backwards ran on the tile-per-plane kernels, not on the march
+                raw_ok = planes == 1 and inv is not None and spec.act == 0 and op.cross_supported(d, 3)
+                affs = torch.empty(kshape, dtype=torch.float32, device=dev) if (want_affs or raw_ok) else None
                 _lib.check(L.pea_affinity_fwd_ex(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(t), op._ptr(w), op._ptr(m),
                                                  op._ptr(affs), op._ptr(g), op._ptr(inv), op._ptr(rows[j]), op._ptr(work), wsb,
                                                  op._stream()), "pea_affinity_fwd_ex")
-                return d, g, affs, inv
+                return d, g, affs, inv, (affs if raw_ok else None)
 
-            def backward_one(j, d, e_c, o_c, g, inv=None, de=None):
+            def backward_one(j, d, e_c, o_c, g, inv=None, de=None, raw=None):
+                """raw: the forward's map, untouched (the backward runs inside this node's forward, before `pred` is handed out)"""
                 de = torch.empty_like(e_c) if de is None else de
-                rc = L.pea_affinity_bwd_ex(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(g), op._ptr(inv), op._ptr(wdev[j:j + 1]),
-                                           op._ptr(de), None, op._stream())
+                rc = L.pea_affinity_bwd_ex2(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(g), op._ptr(inv), op._ptr(raw),
+                                            op._ptr(wdev[j:j + 1]), op._ptr(de), None, op._stream())
                 if rc == _lib.E_UNSUPPORTED:
                     return None
-                _lib.check(rc, "pea_affinity_bwd_ex")
+                _lib.check(rc, "pea_affinity_bwd_ex2")
                 return de
 
             # ---- full resolution: self + cross; their backwards are ONE launch: the cross kernel with a second phase where the
@@ -131,18 +136,20 @@ class _TensorSection(torch.autograd.Function):
             with fork:  # the deep-supervision scales, on their own stream beside the full-resolution pair
                 for j in range(1, jx):
                     e_c = op._embedding_arg(embs[j], "embedding")
-                    d, g, _, inv = forward_one(j, e_c, None, False, 0)
-                    small.append(backward_one(j, d, e_c, None, g, inv))
+                    # (no 1 / norm plane and no raw map for the small scales: their grids are launch-sized, the tiled backward that
+                    #  computes the norms itself is one launch and one allocation less; the march kernels need >= 256 tile columns)
+                    d, g, _, inv, raw = forward_one(j, e_c, None, False, 0)
+                    small.append(backward_one(j, d, e_c, None, g, inv, raw=raw))
             e0 = op._embedding_arg(embs[0], "embedding")
             ema_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e0.dtype)
-            d0, g0, pred, inv0 = forward_one(0, e0, None, True, 1)
-            dxx, gx, _, invx = forward_one(jx, e0, ema_c, False, 2 if inv0 is not None else 0)
+            d0, g0, pred, inv0, raw0 = forward_one(0, e0, None, True, 1)
+            dxx, gx, _, invx, _ = forward_one(jx, e0, ema_c, False, 2 if inv0 is not None else 0)
             de0 = torch.empty_like(e0)
             rc = L.pea_affinity_bwd_dual_ex(ctypes.byref(d0), op._ptr(e0), op._ptr(ema_c), op._ptr(g0), op._ptr(gx), op._ptr(inv0),
                                             op._ptr(None if invx is None else invx[1]), op._ptr(wdev[0:1]), op._ptr(wdev[jx:jx + 1]),
                                             op._ptr(de0), op._stream())
             if rc == _lib.E_UNSUPPORTED:
-                de0 = backward_one(0, d0, e0, None, g0, inv0)
+                de0 = backward_one(0, d0, e0, None, g0, inv0, raw=raw0)
                 de0.add_(backward_one(jx, dxx, e0, ema_c, gx, invx))
             else:
                 _lib.check(rc, "pea_affinity_bwd_dual_ex")

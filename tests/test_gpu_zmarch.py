@@ -214,3 +214,44 @@ def test_zmarch_matches_reference_summary(pkg, dev, monkeypatch, name):
     assert abs((a.astype(np.float64) ** 2).sum() / float(g["affs_sq"]) - 1) < 1e-5
     assert np.abs(gr.reshape(-1)[g["grad_idx"]] - g["grad_val"]).max() <= GRAD_RTOL * np.abs(g["grad_val"]).max()
     assert abs((gr.astype(np.float64) ** 2).sum() / float(g["grad_sq"]) - 1) < 1e-4
+
+
+def test_ac3ac4_section_backward_runs_the_march(pkg, dev, orc, synth, monkeypatch):
+    """round-4 advice: ac3ac4_loss_section's one-node path (_TensorSection) called the backward WITHOUT the raw affinity map, so its
+    full-resolution self backward fell back to the tile-per-plane kernel.  With the map handed over the section's gradient of the
+    full-resolution embedding is, bit for bit, (z-march self gradient) + (cross gradient) as the stand-alone losses compute them; with
+    the march switched off the self part comes from another kernel and the bits differ."""
+    crit = pkg.WeightedMSE()
+    B, D = 1, 16
+    shapes = [(6, 48, 96), (6, 24, 48), (6, 24, 48), (3, 12, 24), (3, 12, 24)]
+    sh5, sh1 = orc.norm_offsets(NORM5), orc.norm_offsets([1, 1, 1])
+    lab_t = [torch.from_numpy(synth.synth_labels(B, s, 240 + i, cell=7)).to(dev) for i, s in enumerate(shapes)]
+    embs = [synth.synth_embedding((B, D) + s, 250 + i) for i, s in enumerate(shapes)]
+    ema = cu(synth.synth_embedding((B, D) + shapes[0], 260), dev)
+    t0, _, w0 = pkg.gen_targets(lab_t[0], sh5, padding=False, both_foreground=True, want_mask=False)
+    heads = [pkg.gen_targets(lab_t[1 + j], sh1, padding=False, both_foreground=True, want_mask=False) for j in range(4)]
+    downs = [torch.cat([heads[3 - k][0], heads[3 - k][2]], dim=1) for k in range(4)]
+
+    def section_grad():
+        x = [cu(e, dev).requires_grad_(True) for e in embs]
+        loss, pred = pkg.ac3ac4_loss_section(x[0], x[1:], ema, t0, w0, downs, crit, embedding_mode=5, affs0_weight=2)
+        loss.backward()
+        return x[0].grad.clone()
+
+    def standalone_grads():
+        a = cu(embs[0], dev).requires_grad_(True)
+        pkg.embedding_loss_norm5(a, t0, w0, crit, affs0_weight=2)[0].backward()
+        b = cu(embs[0], dev).requires_grad_(True)
+        pkg.ema_embedding_loss_norm5(b, ema, t0, w0, crit, affs0_weight=2)[0].backward()
+        return a.grad, b.grad
+
+    monkeypatch.setenv("PEA_ZMARCH", "2")
+    spec = pkg.AffinitySpec(3, sh5, orc.affs0_lambda_3d(12, 2, 3), pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
+    assert _march_on(pkg, spec, cu(embs[0], dev))
+    gs = section_grad()
+    g_self, g_cross = standalone_grads()
+    assert torch.equal(gs, g_self + g_cross), "the section's self backward is not the z-march kernel's"
+    monkeypatch.setenv("PEA_ZMARCH", "0")
+    g_self0, _ = standalone_grads()
+    assert not torch.equal(g_self0, g_self)  # (the check above can tell the two kernels apart)
+    assert relmax(g_self0.cpu().numpy(), g_self.cpu().numpy()) < 2e-5
