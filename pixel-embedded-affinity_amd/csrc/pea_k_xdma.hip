@@ -119,11 +119,13 @@ bool xdma_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s) {
   return false;
 }
 
-// the cross loss with a second operand: 2D, D = 16, f32, circular border, axis-aligned stencil.  e_other staged, own pixel from e,
-// both 1 / norm planes written (inv_out[0 .. B*S) own, inv_out[B*S .. 2*B*S) second operand)
+// the cross loss with a second operand: D = 16, f32, axis-aligned stencil; 2D images (either border) and 3D volumes whose stencil
+// steps along z (ema_embedding_loss_norm5 / norm1, scripts_ac3ac4/loss/loss_embedding_mse.py:30-51, 237-289: CROP_ZERO; the z
+// neighbours are the second operand's, gathered per chunk like the self loss' tile-per-plane kernels do).  e_other staged, own pixel
+// from e, both 1 / norm planes written (inv_out[0 .. B*S) own, inv_out[B*S .. 2*B*S) second operand)
 bool xdma_fwd_other(const KParams& P, const FwdArgs& A, hipStream_t s) {
   if (!env().fwd_xdma || env().force_direct || A.dtype != PEA_F32 || !A.train || !A.inv_out) return false;
-  if (P.D != 16 || P.border != PEA_BORDER_CIRCULAR) return false;
+  if (P.D != 16) return false;
   const float *e = (const float*)A.e, *e_other = (const float*)A.eo;
   if (misaligned(e, 4) || misaligned(e_other, 16) || misaligned(A.t, 16) || misaligned(A.w, 16) || misaligned(A.affs, 16) ||
       misaligned(A.gout, 16) || misaligned(A.m, 4) || misaligned(A.inv_out, 4))
@@ -131,11 +133,26 @@ bool xdma_fwd_other(const KParams& P, const FwdArgs& A, hipStream_t s) {
   if ((P.tbs | P.wbs | P.mbs) & 3) return false;
   XPlan X;
   // (three workgroups per CU do not fit here: the own pixel's 16 registers on top of the accumulators spill at 80 VGPRs)
-  if (!plan(P, kXdmaPSU, 1, &X) || X.C.nfz > 0 || P.K > kXP) return false;
+  bool z3 = false;
+  if (!plan(P, kXdmaPSU, 1, &X) || X.C.nfz > 0) {
+    if (!plan(P, kXdmaPSU3F, 1, &X) || X.C.nfz == 0) return false;
+    z3 = true;
+  }
+  if (P.K > (z3 ? kXP + 2 : kXP)) return false;
   const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
-  constexpr auto kern = k_fwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, true, 0, true>;
-  PEA_LAUNCH(kern, grid, blk, X.lds, s, P, X.C, e_other, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out, e,
-             A.inv_out + (size_t)P.B * P.S, LabArgs{})
+  const bool crop = P.border != PEA_BORDER_CIRCULAR;
+#define PEA_XFO(CROP_, PSU_, ZF_)                                                                                           \
+  {                                                                                                                         \
+    constexpr auto kern = k_fwd_xdma<16, kXdmaTH, kXdmaTW, PSU_, CROP_, true, ZF_, true>;                                   \
+    PEA_LAUNCH(kern, grid, blk, X.lds, s, P, X.C, e_other, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out, e,               \
+               A.inv_out + (size_t)P.B * P.S, LabArgs{})                                                                    \
+  }
+  if (z3) {
+    if (crop) PEA_XFO(true, kXdmaPSU3F, kXZ / 2) else PEA_XFO(false, kXdmaPSU3F, kXZ / 2)
+  } else {
+    if (crop) PEA_XFO(true, kXdmaPSU, 0) else PEA_XFO(false, kXdmaPSU, 0)
+  }
+#undef PEA_XFO
   return true;
 }
 
@@ -196,18 +213,33 @@ bool xdma_bwd_self(const KParams& P, const float* x, const float* inv, const flo
   return false;
 }
 
-// backward, role A only (the second operand is detached): de (+)= dloss * d loss / d e
+// backward, role A only (the second operand is detached): de (+)= dloss * d loss / d e.  2D (either border) and 3D volumes with z steps
 bool xdma_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* dl,
                     float* de, bool accumulate, hipStream_t s) {
-  if (!inv2 || !env().bwd_xdma || env().force_direct || P.D != 16 || P.border != PEA_BORDER_CIRCULAR) return false;
+  if (!inv2 || !env().bwd_xdma || env().force_direct || P.D != 16) return false;
   if (misaligned(e_other, 16) || misaligned(inv2, 16) || ((size_t)P.B * P.S) % 4) return false;
   XPlan X;
-  if (!plan(P, kXdmaPSU, 2, &X) || X.C.npx > kXP || X.C.npy > kXP) return false;
+  bool z3 = false;
+  if (!plan(P, kXdmaPSU, 2, &X) || X.C.npz > 0) {
+    if (!plan(P, kXdmaPSU3, 2, &X) || X.C.npz == 0) return false;
+    z3 = true;
+  }
+  if (X.C.npx > (z3 ? 8 : kXP) || X.C.npy > (z3 ? 8 : kXP)) return false;
   const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
-  constexpr auto kern = k_bwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, kXP, kAuxNT, 0, true>;
   OtherArgs O;
   O.own = e; O.own_inv = inv2; O.accumulate = accumulate ? 1 : 0;
-  PEA_LAUNCH(kern, grid, blk, X.lds, s, P, X.C, e_other, inv2 + (size_t)P.B * P.S, g, dl, de, O, DualArgs{})
+  const bool crop = P.border != PEA_BORDER_CIRCULAR;
+#define PEA_XBO(CROP_, XP_, PSU_, ZP_)                                                                                      \
+  {                                                                                                                         \
+    constexpr auto kern = k_bwd_xdma<16, kXdmaTH, kXdmaTW, PSU_, CROP_, XP_, kAuxNT, ZP_, true>;                            \
+    PEA_LAUNCH(kern, grid, blk, X.lds, s, P, X.C, e_other, inv2 + (size_t)P.B * P.S, g, dl, de, O, DualArgs{})              \
+  }
+  if (z3) {
+    if (crop) PEA_XBO(true, 8, kXdmaPSU3, kXZ / 2) else PEA_XBO(false, 8, kXdmaPSU3, kXZ / 2)
+  } else {
+    if (crop) PEA_XBO(true, kXP, kXdmaPSU, 0) else PEA_XBO(false, kXP, kXdmaPSU, 0)
+  }
+#undef PEA_XBO
   return true;
 }
 
@@ -248,9 +280,12 @@ int xdma_cross_supported(const KParams& P, int dtype, int mode) {
     return (X.C.npx <= xp && X.C.npy <= xp) ? 1 : 0;
   }
   if (mode == 2) {
-    if (P.D != 16 || P.border != PEA_BORDER_CIRCULAR || P.K > kXP || !env().fwd_xdma) return 0;
-    if (!plan(P, kXdmaPSU, 1, &X) || X.C.nfz > 0) return 0;
-    return plan(P, kXdmaPSU, 2, &X) ? 1 : 0;
+    if (P.D != 16 || !env().fwd_xdma) return 0;
+    if (plan(P, kXdmaPSU, 1, &X) && X.C.nfz == 0)
+      return (P.K <= kXP && plan(P, kXdmaPSU, 2, &X) && X.C.npx <= kXP && X.C.npy <= kXP) ? 1 : 0;
+    // 3D volumes whose stencil steps along z (ema_embedding_loss_norm5 / norm1): the tile-per-plane instantiations
+    if (!plan(P, kXdmaPSU3F, 1, &X) || X.C.nfz == 0 || P.K > kXP + 2) return 0;
+    return (plan(P, kXdmaPSU3, 2, &X) && X.C.npz > 0 && X.C.npx <= 8 && X.C.npy <= 8) ? 1 : 0;
   }
   const int pm = mode == 0 ? 1 : 0;
   if (!plan(P, kXdmaPSU3, pm, &X)) return 0;

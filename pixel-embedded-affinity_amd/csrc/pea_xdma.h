@@ -343,7 +343,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
                                                          const float* __restrict__ invp, const float* __restrict__ gin,
                                                          const float* __restrict__ dloss, float* __restrict__ dx,
                                                          const OtherArgs O, const DualArgs Q) {
-  static_assert(!OTHER || (D_T <= 16 && ZP == 0), "role-A instantiation: D <= 16, in-plane");
+  static_assert(!OTHER || D_T <= 16, "role-A instantiation: D <= 16 (z pairs: role A only, ZP = kXZ / 2)");
   static_assert(!DUAL || (D_T == 16 && ZP == 0 && !OTHER), "pair instantiation: D = 16, in-plane");
   static_assert(!VEC || (D_T == 16 && ZP == 0 && !OTHER && !DUAL && TH == 16 && (2 * XP) % 4 == 0 && PSU * 256 >= 8 * 1024),
                 "16-byte g loads / stores: D = 16, in-plane self loss, a wave = two tile rows");
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
                                                            float* __restrict__ inv_out,
                                                            const float* __restrict__ own, float* __restrict__ inv_other_out,
                                                            const LabArgs LA) {
-  static_assert(!OTHER || (D_T <= 16 && ZF == 0), "cross-loss instantiation: D <= 16, in-plane");
+  static_assert(!OTHER || D_T <= 16, "cross-loss instantiation: D <= 16");
   static_assert(!LAB || (TRAIN && ZF == 0 && !OTHER), "labels-in instantiation: 2D self loss");
   constexpr int NT = TH * TW, PS = PSU * 256, NP = D_T / 2, TP = NT, QP = TP / 4, NSL = QP / 64;
   constexpr int KMAX = ZF > 0 ? kXP + 2 : kXP;      // channels the epilogue handles (norm5: 8 in-plane + 4 z offsets)
@@ -1165,8 +1165,11 @@ inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, s
     C.oax[i] = ox != 0 ? 1 : (oy != 0 ? 0 : 2);
     C.od[i] = ox != 0 ? ox : (oy != 0 ? oy : oz);
     if (oz != 0) {
-      if (oz <= -P.Z || oz >= P.Z || role_a) return false;
-      if (fwd) {
+      if (oz <= -P.Z || oz >= P.Z) return false;
+      if (role_a) {  // the detached second operand's backward: role A only (neighbour plane z + oz of the second operand, g at z)
+        if (C.npz + 1 > kXZ / 2) return false;
+        C.zd[C.npz] = oz; C.zgi[C.npz] = i; C.zgo[C.npz] = 0; ++C.npz;
+      } else if (fwd) {
         if (C.nfz >= kXZ / 2) return false;
         C.fzd[C.nfz] = oz; C.fzi[C.nfz] = i; ++C.nfz;
       } else {

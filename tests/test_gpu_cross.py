@@ -177,6 +177,75 @@ def test_cross_3d_norm5_vs_oracle(pkg, dev, orc, synth, shape):
     assert relmax(et.grad.cpu().numpy(), o_grad) < GRAD_RTOL
 
 
+@pytest.mark.parametrize("shape,which", [((2, 6, 48, 96), "norm5"), ((1, 5, 64, 132), "norm5"), ((1, 9, 43, 96), "norm5"), ((2, 7, 48, 64), "norm1"),
+                                         ((1, 4, 40, 72), "norm1_s2")])
+def test_cross_3d_ema_vs_oracle(pkg, dev, orc, synth, monkeypatch, shape, which):
+    """ema_embedding_loss_norm5 / norm1 (scripts_ac3ac4/loss/loss_embedding_mse.py:30-51, 237-289; the EMA operand is the shifted-from one,
+    detached) on the role-A cross kernels' 3D instantiations (round 5: second operand staged, its z neighbours gathered per chunk, own
+    pixel from e; CROP_ZERO): forward, both 1 / norm planes, backward against the oracle; and against the tiled kernels they replace"""
+    B, Z, Y, X = shape
+    sh = [1, 1, 1, 2, 3, 3, 3, 9, 9, 4, 27, 27] if which == "norm5" else ([2, 2, 2] if which == "norm1_s2" else [1, 1, 1])
+    first = 3 if which == "norm5" else 1
+    offs = orc.norm_offsets(sh)
+    e, t, w = synth.synth_inputs_3d(B, 16, Z, Y, X, offs, 55 + Z)
+    eo = synth.synth_embedding((B, 16, Z * Y * X), 66 + Z).reshape(e.shape)
+    e[0, :, Z // 2, 3, 5] = 0.0
+    eo[0, :, 1, 9, 11] = 0.0          # zero-norm pixels in both operands (the clamp branch)
+    lam = orc.affs0_lambda_3d(len(sh), 2, first)
+    spec = pkg.AffinitySpec(3, offs, lam, pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
+    crit = pkg.WeightedMSE()
+    E, EO, T, Wt = cu(e, dev), cu(eo, dev), cu(t, dev), cu(w, dev)
+    L = pkg._lib.lib()
+    d_hip = pkg.affinity_op.make_desc(spec, E)
+    assert L.pea_cross_supported(ctypes.byref(d_hip), 2) == 1
+
+    def run():
+        x = E.clone().requires_grad_(True)
+        if which == "norm5":
+            loss, a = pkg.ema_embedding_loss_norm5(x, EO, T, Wt, crit, affs0_weight=2)
+        else:
+            loss, a = pkg.ema_embedding_loss_norm1(x, EO, T, Wt, crit, affs0_weight=2, shift=sh[0])
+        (loss * 0.25).backward()
+        return loss.item(), a.cpu().numpy(), x.grad.cpu().numpy()
+
+    l1, a1, g1 = run()
+    d = orc.desc_3d(e, sh, lam)
+    o_affs, o_loss = orc.c_fwd(d, e, eo, t, w, None)
+    o_grad, _ = orc.c_bwd(d, e, eo, t, w, None, dloss=0.25)
+    assert np.abs(a1 - o_affs).max() < AFFS_ATOL
+    assert abs(l1 - o_loss[0]) <= LOSS_RTOL * abs(o_loss[0])
+    assert relmax(g1, o_grad) < GRAD_RTOL
+    l1b, a1b, g1b = run()
+    assert l1 == l1b and np.array_equal(a1, a1b) and np.array_equal(g1, g1b)   # bit-reproducible
+    monkeypatch.setenv("PEA_FWD_XDMA", "0")
+    monkeypatch.setenv("PEA_BWD_XDMA", "0")
+    assert L.pea_cross_supported(ctypes.byref(pkg.affinity_op.make_desc(spec, E)), 2) == 0
+    l0, a0, g0 = run()
+    assert abs(l1 - l0) <= 3e-6 * abs(l0) and np.abs(a1 - a0).max() < 2e-6 and relmax(g1, g0) < 2e-5
+
+
+def test_cross_2d_crop_border_ema_vs_oracle(pkg, dev, orc, synth):
+    """the role-A cross kernels with the CROP_ZERO border in 2D (round 5: the border is a template argument of the cross-loss
+    instantiations too): forward + backward against the oracle"""
+    B, D, H, W = 2, 16, 64, 128
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    K = len(offsets)
+    e, t, w, m = _inputs(synth, B, D, [1, H, W], K, 23, zero_px=True)
+    e, t, w, m = e[:, :, 0], t[:, :, 0], w[:, :, 0], m[:, :, 0]
+    eo = synth.synth_embedding((B, D, H * W), 978).reshape(B, D, H, W)
+    spec = pkg.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
+    E = cu(e, dev).requires_grad_(True)
+    assert pkg._lib.lib().pea_cross_supported(ctypes.byref(pkg.affinity_op.make_desc(spec, E.detach())), 2) == 1
+    loss, affs, _ = pkg.affinity_op.FusedAffinityMSE.apply(E, cu(eo, dev), cu(t, dev), cu(w, dev), cu(m, dev), spec)
+    (loss * 0.5).backward()
+    d = orc.make_desc(B, D, [1, H, W], [[0, o[0], o[1]] for o in offsets], None, orc.BORDER_CROP_ZERO, orc.NORM_CROPPED, ndim=2)
+    o_affs, o_loss = orc.c_fwd(d, e, eo, t, w, m)
+    o_grad, _ = orc.c_bwd(d, e, eo, t, w, m, dloss=0.5)
+    assert np.abs(affs.cpu().numpy() - o_affs.reshape(affs.shape)).max() < AFFS_ATOL
+    assert abs(loss.item() - o_loss[0]) <= LOSS_RTOL * abs(o_loss[0])
+    assert relmax(E.grad.cpu().numpy(), o_grad.reshape(e.shape)) < GRAD_RTOL
+
+
 @pytest.mark.parametrize("with_other_loss", [False, True])
 def test_head_and_loss_as_one_autograd_node(pkg, dev, orc, synth, with_other_loss):
     """f1: head(x) -> embedding_loss -> backward as ONE node (harness/head_loss.py: four launches, no autograd bookkeeping between
