@@ -224,6 +224,9 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
         # the launch floor as a number: the entry points' launches (forward + loss finish + backward) captured in a
         # HIP graph and replayed back to back -- no Python, no ctypes, no autograd between them
         "graph_replay_ms": graph_replay_ms(fwd, bwd, max(20, min(args.steps, 200))),
+        # the same step through the PUBLIC API captured with pea.graphed (one graph launch per step: no Python / ctypes / autograd
+        # bookkeeping per launch) -- what a caller of a small, static shape gets; host wall time per replay, replays queued back to back
+        "graphed_api_ms": graphed_api_ms(pkg, op, E, E2, T, Wt, M, spec, max(20, min(args.steps, 200))),
         "cross_kernels": ({"fwd+bwd (second operand)": int(L.pea_cross_supported(ctypes.byref(desc), 2))} if ema else
                           {"fwd": int(L.pea_cross_supported(ctypes.byref(desc), 0)), "bwd": int(L.pea_cross_supported(ctypes.byref(desc), 1))}),
         "roofline": {"bound": "hbm", "kernel": "pea_affinity_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -369,6 +372,28 @@ def graph_replay_ms(fwd, bwd, iters, per_graph=1):
         b.record()
         b.synchronize()
         return round(a.elapsed_time(b) / iters / per_graph, 5)
+    except Exception:  # noqa: BLE001 -- an extra field, never the headline
+        return None
+
+
+def graphed_api_ms(pkg, op, E, E2, T, Wt, M, spec, iters):
+    """ms per step of `FusedAffinityMSE + pea.backward` captured once with pea.graphed (the product-level HIP-graph wrapper) and
+    replayed `iters` times back to back; wall clock around the batch.  None if the capture fails."""
+    try:
+        def fn(E):
+            E.grad = None
+            loss, affs, _ = op.FusedAffinityMSE.apply(E, E2, T, Wt, M, spec)
+            pkg.backward(loss)
+            return loss, affs, E.grad
+        g = pkg.graphed(fn, E)
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            g.replay()
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / iters * 1e3, 5)
     except Exception:  # noqa: BLE001 -- an extra field, never the headline
         return None
 

@@ -216,6 +216,10 @@ int pea_scale_inplace(void *buf, int dtype, size_t n, const float *scale, void *
 /* the same for up to 8 buffers (host arrays of device pointers / element counts) in one launch: the gradients of one loss
  * section share their grad_output */
 int pea_scale_inplace_multi(void *const *bufs, const size_t *counts, int nbuf, int dtype, const float *scale, void *stream);
+/* out[0] = sum_{j < n} w[j] * rows[j * stride] (device pointers; n <= 64; fixed order of additions): the total of a loss section --
+ * `loss = (sum of the deep-supervision losses + loss_embedding) * self_emb + loss_embedding_cross * cross_emb`,
+ * scripts_cvppp/main.py:295-306 -- from the loss_out rows of its calls in ONE small launch instead of a multiply and a reduction. */
+int pea_weighted_sum(const float *rows, int stride, const float *w, int n, float *out, void *stream);
 
 /* Caller epilogue of the 3D path, in place on affs [B,K,Z,Y,X] (scripts_ac3ac4/main.py:233-237, 296-300;
  * scripts_ac3ac4/inference.py:160-164): pred[:,0,:s] = pred[:,0,s:2s] (z), pred[:,1,:,:s] = pred[:,1,:,s:2s] (y),

@@ -11,7 +11,8 @@ Import name: the directory is not a valid Python identifier, so load it through
 """
 from . import _lib
 from ._lib import PeaLibraryError, build
-from .affinity_op import AffinityMap, AffinitySpec, FusedAffinityMSE, LabelsAffinityMSE, affinity_infer, backward, check_label_ranges
+from .affinity_op import (AffinityMap, AffinitySpec, FusedAffinityMSE, Graphed, LabelsAffinityMSE, affinity_infer, backward, check_label_ranges,
+                          graphed)
 from .loss.loss import WeightedMSE
 from .loss.loss_embedding_mse import (ema_embedding_loss, ema_embedding_loss_from_labels, embedding2affs, embedding_loss,
                                       embedding_loss_from_labels)
@@ -35,7 +36,7 @@ from .harness.loss_section import (ac3ac4_loss_section, ac3ac4_loss_section_comp
                                    finish_pred_2d_, finish_pred_3d_)
 
 __all__ = [
-    "PeaLibraryError", "build", "backward", "check_label_ranges", "AffinityMap", "AffinitySpec", "FusedAffinityMSE", "affinity_infer", "WeightedMSE",
+    "PeaLibraryError", "build", "backward", "graphed", "Graphed", "check_label_ranges", "AffinityMap", "AffinitySpec", "FusedAffinityMSE", "affinity_infer", "WeightedMSE",
     "embedding_loss", "ema_embedding_loss", "embedding2affs", "embedding_loss_norm1", "embedding_loss_norm5",
     "ema_embedding_loss_norm1", "ema_embedding_loss_norm5", "inf_embedding_loss_norm1", "inf_embedding_loss_norm5",
     "gen_offsets", "multi_offset", "fill_border_relu_", "relu_", "cvppp_loss_section", "ac3ac4_loss_section",

@@ -103,16 +103,21 @@ def make_desc(spec, e, tstride=0, wstride=0, mstride=0):
 
 
 _CROSS_OK = {}
+_CROSS_LOCK = threading.Lock()
 
 
 def cross_supported(d, mode):
-    """pea_cross_supported(desc, mode), remembered per memoised descriptor (the host-side plan behind it costs a few microseconds)"""
-    key = (id(d), mode)
+    """pea_cross_supported(desc, mode), remembered per memoised descriptor AND current device (the host-side plan behind it costs a few
+    microseconds; the march kernels' answer depends on the device's CU count, and nn.DataParallel replicas call this from one thread
+    per device: round-4 advice)"""
+    key = (id(d), mode, torch.cuda.current_device())
     r = _CROSS_OK.get(key)
     if r is None:
-        if len(_CROSS_OK) > 2048:
-            _CROSS_OK.clear()
-        r = _CROSS_OK[key] = bool(_lib.lib().pea_cross_supported(ctypes.byref(d), mode))
+        r = bool(_lib.lib().pea_cross_supported(ctypes.byref(d), mode))
+        with _CROSS_LOCK:
+            if len(_CROSS_OK) > 2048:
+                _CROSS_OK.clear()
+            _CROSS_OK[key] = r
     return r
 
 
@@ -305,6 +310,56 @@ def backward(loss, **kw):
     if one is None:
         one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
     loss.backward(one, **kw)
+
+
+class Graphed(object):
+    """fn(*static_inputs) captured ONCE in a HIP graph; replay() runs it again on whatever the static input tensors hold now.
+
+    Why: at small shapes the path is host-bound -- one 544 x 544 image through embedding_loss + backward is 0.12 ms of Python, ctypes and
+    autograd bookkeeping around 0.05 ms of kernels (BASELINE configs[0]; the BBBC 256 x 256 training crops likewise).  Everything fn
+    launches (the library's kernels through the C ABI, autograd's own kernels, allocations -- taken from the graph's private pool)
+    becomes one graph launch of ~10 us of host time.  fn may contain the backward (pea.backward(loss)): gradients it leaves on leaf
+    tensors are captured like any other output.
+
+        E, T, W, M = ...                                   # static inputs: refill them with .copy_() between replays
+        def step(E, T, W, M):
+            E.grad = None
+            loss, affs, _ = pea.embedding_loss(E, T, W, M, crit, offsets)
+            pea.backward(loss)
+            return loss, affs, E.grad
+        g = pea.graphed(step, E, T, W, M)
+        loss, affs, grad = g.replay()                      # the same tensors every time (overwritten by the next replay)
+
+    The capture is bit-identical to the eager call (same kernels, same order; tests/test_gpu_parity.py::test_graphed_step_equals_eager).
+    Constraints are those of torch.cuda.graph: static shapes and addresses, no host synchronisation inside fn (the path has none)."""
+
+    def __init__(self, fn, *static_inputs, warmup=2):
+        dev = next((t.device for t in static_inputs if isinstance(t, torch.Tensor) and t.is_cuda), None)
+        if dev is None:
+            raise RuntimeError("graphed() needs at least one static input on a ROCm device (no CPU fallback)")
+        self.static_inputs = static_inputs
+        with torch.cuda.device(dev):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # warm-up on the capture stream: allocator, memoised descriptors, the stream's loss-state block
+                for _ in range(max(1, warmup)):
+                    fn(*static_inputs)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side):
+                self.outputs = fn(*static_inputs)
+
+    def replay(self):
+        self.graph.replay()
+        return self.outputs
+
+    __call__ = replay
+
+
+def graphed(fn, *static_inputs, warmup=2):
+    """Graphed(fn, *static_inputs): see there"""
+    return Graphed(fn, *static_inputs, warmup=warmup)
 
 
 class AffinityMap(torch.autograd.Function):

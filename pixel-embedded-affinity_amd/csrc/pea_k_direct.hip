@@ -369,4 +369,21 @@ int pea_scale_inplace_multi(void* const* bufs, const size_t* counts, int nbuf, i
   return hip_rc();
 }
 
+// out[0] = sum_j w[j] * rows[j * stride]: the total of a loss section's weighted losses (loss row j = loss_out of call j), one wave.
+// Fixed order of additions (j = 0, 1, ..): bit-reproducible.
+namespace { __global__ void k_weighted_sum(const float* __restrict__ rows, int stride, const float* __restrict__ w, int n, float* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int j = 0; j < n; ++j) t += rows[(size_t)j * stride] * w[j];
+    out[0] = t;
+  }
+} }
+int pea_weighted_sum(const float* rows, int stride, const float* w, int n, float* out, void* stream) {
+  if (!rows || !w || !out) return PEA_E_NULL;
+  if (n < 1 || n > 64 || stride < 1) return PEA_E_DESC;
+  if (misaligned(rows, 4) || misaligned(w, 4) || misaligned(out, 4)) return PEA_E_ALIGN;
+  hipLaunchKernelGGL(k_weighted_sum, dim3(1), dim3(64), 0, (hipStream_t)stream, rows, stride, w, n, out);
+  return hip_rc();
+}
+
 }  // extern "C"

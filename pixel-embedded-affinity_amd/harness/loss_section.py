@@ -157,13 +157,21 @@ class _TensorSection(torch.autograd.Function):
             grads.extend(small)
             fork.join()
             losses = rows[:, 0]
-            total = (losses * wdev).sum()
+            total = _section_total(L, rows, wdev, ncall)
         ctx.grads, ctx.n_embs = grads, len(embs)
         _stash_again(ctx, _TensorSection, (specs, weights, ema_embedding, tensors) + tuple(embs))
         ctx.mark_non_differentiable(pred, losses)
         return total, pred, losses
 
     backward = staticmethod(lambda ctx, dtotal, _dp, _dl: _section_backward(ctx, dtotal))
+
+
+def _section_total(L, rows, wdev, ncall):
+    """sum_j weight_j * loss_j (scripts_cvppp/main.py:295-306) from the loss rows of the section's calls: one small launch
+    (pea_weighted_sum) instead of a multiply and a reduction -- they sit at the end of the section's critical path, 5 us each"""
+    total = torch.empty((), dtype=torch.float32, device=rows.device)
+    _lib.check(L.pea_weighted_sum(op._ptr(rows), rows.stride(0), op._ptr(wdev), ncall, op._ptr(total), op._stream()), "pea_weighted_sum")
+    return total
 
 
 def _stash_again(ctx, cls, args):
@@ -237,7 +245,10 @@ def _section_backward(ctx, dtotal):
     L = _lib.lib()
     dev = grads[0].device
     with op._on_device(dev):
-        # one launch rescales every gradient by grad_output (and returns untouched when that is exactly 1)
+        # one launch rescales every gradient by grad_output (and returns untouched when that is exactly 1); pea.backward(loss) seeds
+        # the backward with ITS cached ones-scalar: recognised by identity, the launch is skipped
+        if any(dtotal is one for one in op._ONES.values()):
+            return (None, None, None, None) + tuple(g if ctx.needs_input_grad[4 + k] else None for k, g in enumerate(grads))
         dl = dtotal.to(device=dev, dtype=torch.float32).contiguous()
         bufs = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
         cnts = (ctypes.c_size_t * n)(*[g.numel() for g in grads])
@@ -554,7 +565,7 @@ class _LabelsSection(torch.autograd.Function):
             grads = [de0] + small
             fork.join()
             losses = rows[:, 0]
-            total = (losses * wdev).sum()
+            total = _section_total(L, rows, wdev, ncall)
         ctx.grads, ctx.n_embs = grads, len(embs)
         _stash_again(ctx, _LabelsSection, (specs, weights, ema_embedding, label_cfg) + tuple(embs))
         ctx.mark_non_differentiable(pred, losses)

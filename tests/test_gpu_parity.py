@@ -213,6 +213,40 @@ def test_baseline_config_b8_properties(pkg, dev, synth):
     assert float(a1.abs().max()) <= 1.0 + 1e-5
 
 
+def test_graphed_step_equals_eager(pkg, dev, synth):
+    """pea.graphed: embedding_loss + backward of BASELINE configs[0] (one 544 x 544 image, K = 10) captured in a HIP graph through the
+    PUBLIC API -- every replay equals the eager call bit for bit, also after the static inputs were refilled"""
+    offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
+    crit = pkg.WeightedMSE()
+    e, t, w, m = synth.synth_inputs_2d(1, 16, 544, 544, offsets, seed=71)
+    e2 = synth.synth_embedding((1, 16, 544, 544), 72)
+    E = cu(e, dev).requires_grad_(True)
+    T, W, M = cu(t, dev), cu(w, dev), cu(m, dev)
+
+    def step(E, T, W, M):
+        E.grad = None
+        loss, affs, parts = pkg.embedding_loss(E, T, W, M, crit, offsets)
+        pkg.backward(loss)
+        return loss, affs, E.grad
+
+    def eager(ev):
+        x = cu(ev, dev).requires_grad_(True)
+        loss, affs, _ = pkg.embedding_loss(x, T, W, M, crit, offsets)
+        pkg.backward(loss)
+        return loss.detach().clone(), affs.clone(), x.grad.clone()
+
+    g = pkg.graphed(step, E, T, W, M)
+    for ev in (e, e2, e):
+        with torch.no_grad():
+            E.copy_(cu(ev, dev))
+        loss, affs, grad = g.replay()
+        l0, a0, g0 = eager(ev)
+        assert torch.equal(loss, l0) and torch.equal(affs, a0) and torch.equal(grad, g0)
+    # and the replay is what it claims to be: one graph launch, no autograd graph left behind
+    loss, affs, grad = g()
+    assert grad.shape == E.shape and torch.isfinite(grad).all()
+
+
 @pytest.mark.parametrize("switch,value", [("PEA_SKEW", "6"), ("PEA_WALK2D", "5"), ("PEA_XCD_STAGGER", "1")])
 def test_walk_and_placement_switches_change_no_bit(pkg, dev, synth, monkeypatch, switch, value):
     """The tile-walk / start-placement experiments kept as switches (csrc/pea_xdma.h xdma_tile)
