@@ -204,7 +204,9 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
     P = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())
     cur = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # (read per call: the graph capture runs on its own stream)
     fwd = lambda: L.pea_affinity_fwd_ex(ctypes.byref(desc), P(Ed), P(E2), P(T), P(Wt), P(M), P(affs), P(G), P(INV), P(lossv), P(work), wsb, cur())
-    bwd = lambda: L.pea_affinity_bwd_ex2(ctypes.byref(desc), P(Ed), P(E2), P(G), P(INV), None if ema else P(affs), P(one), P(dE), None, cur())
+    # (the raw map goes along where the backward reads it: self loss always here; second operand: mode 4, D = 32 / 64)
+    raw_in = P(affs) if (not ema or L.pea_cross_supported(ctypes.byref(desc), 4)) else None
+    bwd = lambda: L.pea_affinity_bwd_ex2(ctypes.byref(desc), P(Ed), P(E2), P(G), P(INV), raw_in, P(one), P(dE), None, cur())
     in_step_times_ms(fwd, bwd, 3)
     kf, kb, kspread = in_step_batches_ms(fwd, bwd, max(10, min(args.steps, 50)), nb=5)
     ab = algorithmic_bytes_per_px(Dm, K, 2 if c["f16"] else 4, mask=M is not None, ema=ema)

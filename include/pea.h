@@ -191,7 +191,10 @@ int pea_inv_norm(const PeaDesc *desc, const void *e, float *inv_norm_out, void *
  * loss with a detached second operand (forward and role-A backward, given the two planes); else 0 (the tiled / direct kernels
  * run).  A caller uses it to decide whether to allocate the 1 / norm plane.  backward == 3: 1 when pea_affinity_bwd_ex2 READS the
  * raw affinity map for this descriptor (the projection-first kernels at D > 16, csrc/pea_xdma_pf.h; the z-march backward of 3D
- * volumes, csrc/pea_zmarch.h): a caller that hands `affs` over must then keep the forward's map unmodified until the backward. */
+ * volumes, csrc/pea_zmarch.h): a caller that hands `affs` over must then keep the forward's map unmodified until the backward.
+ * backward == 4: the same question for the cross loss with a detached second operand (e_other != NULL, de_other == NULL): 1 at
+ * D = 32 / 64, f32, 2D -- there the role-A backward is the projection-first kernel k_bwd_xdma_pfo (csrc/pea_xdma_pf.h) and runs only
+ * when `affs` (the cross loss' raw map) comes along; without it the tiled kernels run. */
 int pea_cross_supported(const PeaDesc *desc, int backward);
 
 /* The backward of the full-resolution pair of the training loop in one launch: g is what pea_affinity_fwd wrote for the self

@@ -273,7 +273,11 @@ class FusedAffinityMSE(torch.autograd.Function):
         # version counter catches an in-place edit of the returned map (affs.relu_()) between forward and backward
         # -- and only where the backward reads it (pea_cross_supported mode 3: the projection-first kernels at D > 16, the z-march
         # backward of 3D volumes): elsewhere saving it would turn a harmless affs.relu_() before backward() into a RuntimeError
-        raw = affs if (inv is not None and o_c is None and spec.act == 0 and cross_supported(d, 3)) else None
+        # (mode 4: the same for the cross loss with a detached second operand -- D = 32 / 64)
+        raw = None
+        if inv is not None and spec.act == 0:
+            if (o_c is None and cross_supported(d, 3)) or (o_c is not None and cross_supported(d, 4)):
+                raw = affs
         ctx.save_for_backward(e_c, o_c, g, inv, raw)
         loss, per_offset = loss_vec[0], loss_vec[1:]  # views of a buffer that is not itself returned
         ctx.mark_non_differentiable(affs, per_offset)

@@ -157,8 +157,10 @@ bool xdma_hq_bwd_self(const KParams& P, const void* x, const float* inv, const f
                       hipStream_t s);
 bool xdma_pf_bwd_self(const KParams& P, const float* x, const float* inv, const float* g, const float* affs, const float* dl, float* dx,
                       hipStream_t s);  // the projection-first backward, f32 storage (pea_k_xdma_h.hip)
-bool xdma_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* dl,
-                    float* de, bool accumulate, hipStream_t s);
+bool xdma_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* affs,
+                    const float* dl, float* de, bool accumulate, hipStream_t s);  // affs: the raw cosine map or null (read at D > 16)
+bool xdma_pf_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* affs,
+                       const float* dl, float* de, hipStream_t s);  // D = 32 / 64, projection first (pea_k_xdma_h.hip)
 bool xdma_bwd_dual(const KParams& P, const float* e, const float* ema, const float* inv, const float* inv_other, const float* g,
                    const float* g_cross, const float* dl, const float* dl_cross, float* de, hipStream_t s);
 bool tiled_bwd(const KParams& P, int dtype, int roles, const void* x, const void* nbA, const void* nbB, const float* g,

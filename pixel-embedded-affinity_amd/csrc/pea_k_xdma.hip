@@ -123,14 +123,37 @@ bool xdma_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s) {
 // steps along z (ema_embedding_loss_norm5 / norm1, scripts_ac3ac4/loss/loss_embedding_mse.py:30-51, 237-289: CROP_ZERO; the z
 // neighbours are the second operand's, gathered per chunk like the self loss' tile-per-plane kernels do).  e_other staged, own pixel
 // from e, both 1 / norm planes written (inv_out[0 .. B*S) own, inv_out[B*S .. 2*B*S) second operand)
+// D = 32 / 64 (2D): the own pixel comes from own TILES staged beside each chunk (k_fwd_xdma OWNL); one-sided cross in 7.5 KB planes
+template <int D_T>
+static bool fwd_other_wide(const KParams& P, const FwdArgs& A, hipStream_t s) {
+  const float *e = (const float*)A.e, *e_other = (const float*)A.eo;
+  if (misaligned(e, 16)) return false;
+  XPlan X;
+  if (!plan(P, kXdmaPSUF, 1, &X) || X.C.nfz > 0 || P.K > kXP || P.Z != 1) return false;
+  const size_t lds = X.lds + (size_t)6 * 2048;  // + the own tiles: three buffers x two channels x 2 KB
+  const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  if (P.border != PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_fwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, true, true, 0, true, 4>;
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, e_other, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out, e,
+               A.inv_out + (size_t)P.B * P.S, LabArgs{})
+  } else {
+    constexpr auto kern = k_fwd_xdma<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, false, true, 0, true, 4>;
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, e_other, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out, e,
+               A.inv_out + (size_t)P.B * P.S, LabArgs{})
+  }
+  return true;
+}
+
 bool xdma_fwd_other(const KParams& P, const FwdArgs& A, hipStream_t s) {
   if (!env().fwd_xdma || env().force_direct || A.dtype != PEA_F32 || !A.train || !A.inv_out) return false;
-  if (P.D != 16) return false;
+  if (P.D != 16 && P.D != 32 && P.D != 64) return false;
   const float *e = (const float*)A.e, *e_other = (const float*)A.eo;
   if (misaligned(e, 4) || misaligned(e_other, 16) || misaligned(A.t, 16) || misaligned(A.w, 16) || misaligned(A.affs, 16) ||
       misaligned(A.gout, 16) || misaligned(A.m, 4) || misaligned(A.inv_out, 4))
     return false;
   if ((P.tbs | P.wbs | P.mbs) & 3) return false;
+  if (P.D == 32) return fwd_other_wide<32>(P, A, s);
+  if (P.D == 64) return fwd_other_wide<64>(P, A, s);
   XPlan X;
   // (three workgroups per CU do not fit here: the own pixel's 16 registers on top of the accumulators spill at 80 VGPRs)
   bool z3 = false;
@@ -214,9 +237,14 @@ bool xdma_bwd_self(const KParams& P, const float* x, const float* inv, const flo
 }
 
 // backward, role A only (the second operand is detached): de (+)= dloss * d loss / d e.  2D (either border) and 3D volumes with z steps
-bool xdma_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* dl,
-                    float* de, bool accumulate, hipStream_t s) {
-  if (!inv2 || !env().bwd_xdma || env().force_direct || P.D != 16) return false;
+bool xdma_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* affs,
+                    const float* dl, float* de, bool accumulate, hipStream_t s) {
+  if (!inv2 || !env().bwd_xdma || env().force_direct) return false;
+  if (P.D == 32 || P.D == 64) {  // projection first: needs the forward's raw map; no accumulate form
+    if (!affs || accumulate || (P.flags & kActMask) || !env().bwd_pf || P.Z != 1) return false;
+    return xdma_pf_bwd_other(P, e, e_other, inv2, g, affs, dl, de, s);
+  }
+  if (P.D != 16) return false;
   if (misaligned(e_other, 16) || misaligned(inv2, 16) || ((size_t)P.B * P.S) % 4) return false;
   XPlan X;
   bool z3 = false;
@@ -273,14 +301,20 @@ int xdma_cross_supported(const KParams& P, int dtype, int mode) {
   if (!(mode ? env().bwd_xdma : env().fwd_xdma)) return 0;
   XPlan X;
   if (dtype == PEA_F16) {  // pea_xdma_h16.h: 2D self loss
-    if (mode == 2 || P.X % 8 || P.Z != 1) return 0;
+    if (mode == 2 || mode == 4 || P.X % 8 || P.Z != 1) return 0;
     if (mode == 0) return (plan(P, kXdmaPSUF, 1, &X) && X.C.nfz == 0 && P.K <= kXP) ? 1 : 0;
     if (!plan(P, kXdmaPSUH, 0, &X) || X.C.npz > 0) return 0;
     const int xp = P.D > 32 ? 8 : kXP;
     return (X.C.npx <= xp && X.C.npy <= xp) ? 1 : 0;
   }
-  if (mode == 2) {
-    if (P.D != 16 || !env().fwd_xdma) return 0;
+  if (mode == 2 || mode == 4) {  // 4: does the backward of the cross loss with a detached second operand READ the raw map?
+    if (!env().fwd_xdma) return 0;
+    if (P.D == 32 || P.D == 64) {
+      if (!env().bwd_pf || (P.flags & kActMask) || P.Z != 1 || P.K > kXP) return 0;
+      if (!plan(P, kXdmaPSUF, 1, &X) || X.C.nfz > 0) return 0;
+      return (plan(P, kXdmaPSUF, 2, &X) && X.C.npz == 0 && X.C.npx <= kXP && X.C.npy <= kXP) ? 1 : 0;
+    }
+    if (P.D != 16 || mode == 4) return 0;
     if (plan(P, kXdmaPSU, 1, &X) && X.C.nfz == 0)
       return (P.K <= kXP && plan(P, kXdmaPSU, 2, &X) && X.C.npx <= kXP && X.C.npy <= kXP) ? 1 : 0;
     // 3D volumes whose stencil steps along z (ema_embedding_loss_norm5 / norm1): the tile-per-plane instantiations

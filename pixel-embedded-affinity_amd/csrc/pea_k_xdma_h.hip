@@ -118,7 +118,37 @@ bool bwd_self_pf(const KParams& P, const float* x, const float* inv, const float
   return true;
 }
 
+// ---- the same for the cross loss with a detached second operand at D = 32 / 64 (k_bwd_xdma_pfo): role A, one-sided cross
+template <int D_T>
+bool bwd_other_pf(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* affs,
+                  const float* dl, float* de, hipStream_t s) {
+  if (misaligned(e, 16) || misaligned(e_other, 16) || misaligned(inv2, 16) || ((size_t)P.B * P.S) % 4 || misaligned(g, 4) ||
+      misaligned(affs, 4) || misaligned(de, 4))
+    return false;
+  XPlan X;
+  if (!plan(P, kXdmaPSUF, 2, &X) || X.C.npz > 0 || X.C.npx > kXP || X.C.npy > kXP) return false;
+  const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  constexpr int RB = 3;
+  const size_t lds = (size_t)2 * RB * kXdmaPSUF * 256 + (size_t)2 * RB * 2048;  // the ring + the own tiles
+  const float* inv_other = inv2 + (size_t)P.B * P.S;
+  if (P.border != PEA_BORDER_CIRCULAR) {
+    constexpr auto kern = k_bwd_xdma_pfo<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, true, 4, RB>;
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, e_other, inv_other, e, inv2, g, affs, dl, de)
+  } else {
+    constexpr auto kern = k_bwd_xdma_pfo<D_T, kXdmaTH, kXdmaTW, kXdmaPSUF, false, 4, RB>;
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, e_other, inv_other, e, inv2, g, affs, dl, de)
+  }
+  return true;
+}
+
 }  // namespace
+
+bool xdma_pf_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* affs,
+                       const float* dl, float* de, hipStream_t s) {
+  if (P.D == 32) return bwd_other_pf<32>(P, e, e_other, inv2, g, affs, dl, de, s);
+  if (P.D == 64) return bwd_other_pf<64>(P, e, e_other, inv2, g, affs, dl, de, s);
+  return false;
+}
 
 // entry points used by pea_k_xdma.hip's dispatchers
 bool xdma_h_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s) {

@@ -776,7 +776,10 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
                                                            float* __restrict__ inv_out,
                                                            const float* __restrict__ own, float* __restrict__ inv_other_out,
                                                            const LabArgs LA) {
-  static_assert(!OTHER || D_T <= 16, "cross-loss instantiation: D <= 16");
+  // OWNL: the cross loss at D > 16 -- the own pixel's D registers do not exist, so the OWN tile (16 x 32 pixels, 2 KB per channel, no
+  // halo) is staged beside each chunk by the first two waves (one dwordx4 DMA instruction per channel and wave) and read from LDS
+  constexpr bool OWNL = OTHER && D_T > 16;
+  static_assert(!OWNL || ZF == 0, "cross-loss instantiation at D > 16: in-plane");
   static_assert(!LAB || (TRAIN && ZF == 0 && !OTHER), "labels-in instantiation: 2D self loss");
   constexpr int NT = TH * TW, PS = PSU * 256, NP = D_T / 2, TP = NT, QP = TP / 4, NSL = QP / 64;
   constexpr int KMAX = ZF > 0 ? kXP + 2 : kXP;      // channels the epilogue handles (norm5: 8 in-plane + 4 z offsets)
@@ -877,8 +880,24 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
   const unsigned vo1 = SDMA ? (two ? vo[1] : vo[0]) : vo[1];
   const int w1 = SDMA ? (two ? wbase + (NT / 64) * 1024 : wbase) : wbase + (NT / 64) * 1024;
   const int npc = SDMA ? 4 : 2 * ((__builtin_amdgcn_ballot_w64(act[0]) != 0) + (__builtin_amdgcn_ballot_w64(act[1]) != 0));
-  f2 eo[OTHER ? NP : 1];  // OTHER: the own pixel, requested before the first DMA (vmcnt retires in order)
-  if (OTHER) {
+  f2 eo[(OTHER && !OWNL) ? NP : 1];  // OTHER: the own pixel, requested before the first DMA (vmcnt retires in order)
+  const rsrc_t ownB = mkbuf(OWNL ? own + (size_t)b * D_T * S : nullptr);
+  constexpr int OWNB = 6 * PS;  // OWNL: three buffers x two channels x 2 KB behind the ring
+  unsigned ownvo = kOOB;        // OWNL: the quad of the own tile this lane moves (waves 0 and 1)
+  if (OWNL) {
+    const int q = (int)threadIdx.x;  // quads 0 .. 127 of the tile: row q / 8, columns 4 (q % 8) ..
+    const int qy = y0 + (q >> 3), qx = x0 + 4 * (q & 7);
+    ownvo = (q < NT / 4 && qy < P.Y && qx < P.X) ? (unsigned)(qy * P.X + qx) * 4u : kOOB;
+  }
+  const bool ownw = OWNL && wave < NT / 256;  // uniform: this wave moves own tiles
+#define PEA_XOWN(ch)                                                                                                          \
+  if (ownw) {                                                                                                                 \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ownB, (lds_ptr_t)(lds + OWNB + (((ch) % 3) * 2) * 2048 + wave * 1024), 16, ownvo,   \
+                                             ezo + (unsigned)(2 * (ch)) * ecs, 0, 0);                                          \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ownB, (lds_ptr_t)(lds + OWNB + (((ch) % 3) * 2 + 1) * 2048 + wave * 1024), 16, ownvo, \
+                                             ezo + (unsigned)(2 * (ch) + 1) * ecs, 0, 0);                                      \
+  }
+  if (OTHER && !OWNL) {
     const rsrc_t oB = mkbuf(own + (size_t)b * D_T * S);
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
@@ -896,10 +915,12 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
       if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + (plane_byte) + w1), 16, vo1, so, 0, 0); \
     }                                                                                                               \
   }
+  const int npt = npc + (ownw ? 2 : 0);  // DMA instructions per chunk of this wave, the own tile's included
 #define PEA_XWAIT1()                                                                             \
   {                                                                                              \
-    if (npc == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
-    else if (npc == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
+    if (npt == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
+    else if (npt == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
+    else if (npt == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                \
   }
 #define PEA_XWAITZ() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * ZF + 4) : "memory");
@@ -910,9 +931,11 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
   }
   PEA_XDMA(0, ezo)
   PEA_XDMA(PS, ezo + ecs)
+  PEA_XOWN(0)
   if (NP > 1) {
     PEA_XDMA(2 * PS, ezo + 2u * ecs)
     PEA_XDMA(3 * PS, ezo + 3u * ecs)
+    PEA_XOWN(1)
   }
 
   // ---- LDS slot of every offset's neighbour
@@ -951,6 +974,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
   if (NP > 2) {
     PEA_XDMA(4 * PS, ezo + 4u * ecs)
     PEA_XDMA(5 * PS, ezo + 5u * ecs)
+    PEA_XOWN(2)
   }
 
   f2 dot[kXP], ssq[kXP], oss = {0.f, 0.f}, css = {0.f, 0.f}, dotz[ZF > 0 ? ZF : 1], ssqz[ZF > 0 ? ZF : 1];
@@ -964,9 +988,14 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
     f2 o;
     o.x = *(const float*)(lds + bo + vown);
     o.y = *(const float*)(lds + bo + PS + vown);
-    if (OTHER) {  // the staged centre is the second operand's pixel: its norm goes to the backward; the own pixel is eo
+    if (OTHER) {  // the staged centre is the second operand's pixel: its norm goes to the backward; the own pixel is eo / the own tile
       css = __builtin_elementwise_fma(o, o, css);
-      o = eo[ps];
+      if (OWNL) {
+        o.x = *(const float*)(lds + OWNB + ((ps % 3) * 2) * 2048 + (int)threadIdx.x * 4);
+        o.y = *(const float*)(lds + OWNB + ((ps % 3) * 2 + 1) * 2048 + (int)threadIdx.x * 4);
+      } else {
+        o = eo[ps];
+      }
     }
     oss = __builtin_elementwise_fma(o, o, oss);
 #pragma unroll
@@ -998,10 +1027,12 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma(const KParams P, const
       if (ps + 3 < NP) {
         PEA_XDMA(bo, ezo + (unsigned)(2 * ps + 6) * ecs)
         PEA_XDMA(bo + PS, ezo + (unsigned)(2 * ps + 7) * ecs)
+        PEA_XOWN(ps + 3)
       }
     }
   }
 #undef PEA_XDMA
+#undef PEA_XOWN
 #undef PEA_XWAIT1
 #undef PEA_XWAITZ
 #undef PEA_XZLOAD

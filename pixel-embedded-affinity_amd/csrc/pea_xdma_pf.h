@@ -202,4 +202,167 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_pf(const KParams P, co
 #undef PEA_PFDMA
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The cross loss with a DETACHED second operand (ema_embedding_loss, scripts_cvppp/loss/loss_embedding_mse.py:79-95 behind
+// convert_consistency_flip's detach) at D > 16: role A only,
+//     G(p) = sum_i g_i(p) ehat_other(p + o_i),     <ehat(p), G(p)> = sum_i g_i(p) a_i(p)      (every pair, exactly)
+// so the projection-first form needs nothing but the K values of g and of the raw map at the own pixel.  xt / invp are the SECOND
+// operand and its 1 / norm plane (staged: the one-sided cross of plan_xdma mode 2); the own pixel -- needed raw, two channels per
+// chunk, to finish them -- is staged as the own TILE (no halo: 2 KB per channel, the first two waves move it) beside each chunk;
+// own_inv: the own operand's signed 1 / norm plane.  No accumulate form (the caller adds two buffers).
+// ------------------------------------------------------------------------------------------------------------------
+template <int D_T, int TH, int TW, int PSU, bool CROP, int WPE, int RB = 3>
+__global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_pfo(const KParams P, const XParams C, const float* __restrict__ xt,
+                                                               const float* __restrict__ invp, const float* __restrict__ own,
+                                                               const float* __restrict__ own_inv, const float* __restrict__ gin,
+                                                               const float* __restrict__ affs, const float* __restrict__ dloss,
+                                                               float* __restrict__ dx) {
+  constexpr int NT = TH * TW, PS = PSU * 256, NP = D_T / 2, XP = kXP, IP = 2 * (RB - 1), OWNB = 2 * RB * PS;
+  static_assert(TW == 32 && D_T % 2 == 0 && RB >= 3 && NP >= RB && NT == 512, "lane mapping / channel pairs / ring");
+  extern __shared__ f4 lds4[];
+  char* lds = (char*)lds4;
+  int tile, b, z, y0, x0;
+  if (!xdma_tile<TH, TW>(C, P, tile, b, z, y0, x0)) return;
+  const size_t S = (size_t)P.S;
+  const unsigned YX = (unsigned)(P.Y * P.X);
+  const rsrc_t xB = mkbuf(xt + (size_t)b * D_T * S), dB = mkbuf(dx + (size_t)b * D_T * S), oB = mkbuf(own + (size_t)b * D_T * S);
+  const rsrc_t gB = mkbuf(gin + (size_t)b * P.K * S), iB = mkbuf(invp + (size_t)b * S), aB = mkbuf(affs + (size_t)b * P.K * S);
+  const rsrc_t oiB = mkbuf(own_inv + (size_t)b * S);
+  const unsigned ecs = (unsigned)P.S * 4u, ezo = (unsigned)z * YX * 4u;
+  const float dl = dloss ? dloss[0] : 1.f;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
+  const int py = y0 + ly, px = x0 + lx;
+  const bool live = py < P.Y && px < P.X;
+  const unsigned pe = live ? (unsigned)(py * P.X + px) * 4u : kOOB;
+
+  unsigned vo[2];
+  bool act[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int q = (s * (NT / 64) + wave) * 64 + lane;
+    int gy, gx;
+    if (q < C.QV) {
+      gy = y0 - C.hy0 + (q >> 3);
+      gx = x0 + 4 * (q & 7);
+    } else {
+      const int k = q - C.QV;
+      const int sh = C.SW == 64 ? 4 : 3;
+      const int cc = 4 * (k & ((1 << sh) - 1));
+      gy = y0 + (k >> sh);
+      gx = cc < C.split ? x0 + TW + cc : x0 - C.SW + cc;
+    }
+    act[s] = q < C.QA;
+    bool oky, okx;
+    gy = wrap1<CROP>(gy, P.Y, oky);
+    gx = wrap1<CROP>(gx, P.X, okx);
+    vo[s] = (act[s] && oky && okx) ? (unsigned)(gy * P.X + gx) * 4u : kOOB;
+  }
+  const int wbase = wave * 1024, w1 = wbase + (NT / 64) * 1024;
+  const bool ownw = wave < NT / 256;  // uniform: the waves that move the own tile (quads 0 .. 127)
+  unsigned ownvo = kOOB;
+  {
+    const int q = (int)threadIdx.x, qy = y0 + (q >> 3), qx = x0 + 4 * (q & 7);
+    ownvo = (q < NT / 4 && qy < P.Y && qx < P.X) ? (unsigned)(qy * P.X + qx) * 4u : kOOB;
+  }
+  const int npc = 2 * ((__builtin_amdgcn_ballot_w64(act[0]) != 0) + (__builtin_amdgcn_ballot_w64(act[1]) != 0)) + (ownw ? 2 : 0);
+#define PEA_PFDMA(rsrc, plane_byte, so)                                                                                          \
+  {                                                                                                                              \
+    if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, 0);    \
+    if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + w1), 16, vo[1], so, 0, 0);       \
+  }
+// chunk c: the second operand's cross into ring buffer c % RB, the own tile into its 4 KB slot
+#define PEA_PFCHUNK(c)                                                                                                            \
+  {                                                                                                                              \
+    PEA_PFDMA(xB, (2 * ((c) % RB)) * PS, ezo + (unsigned)(2 * (c)) * ecs)                                                        \
+    PEA_PFDMA(xB, (2 * ((c) % RB) + 1) * PS, ezo + (unsigned)(2 * (c) + 1) * ecs)                                                \
+    if (ownw) {                                                                                                                  \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(oB, (lds_ptr_t)(lds + OWNB + (2 * ((c) % RB)) * 2048 + wave * 1024), 16, ownvo,    \
+                                               ezo + (unsigned)(2 * (c)) * ecs, 0, 0);                                            \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(oB, (lds_ptr_t)(lds + OWNB + (2 * ((c) % RB) + 1) * 2048 + wave * 1024), 16, ownvo, \
+                                               ezo + (unsigned)(2 * (c) + 1) * ecs, 0, 0);                                        \
+    }                                                                                                                            \
+  }
+  // the second operand's 1 / norm plane sits in the LAST buffer's first plane until the coefficients are done; chunk 0 .. RB - 2
+  PEA_PFDMA(iB, IP * PS, ezo)
+  PEA_PFCHUNK(0)
+
+  // ---- g and the raw affinity at the own pixel: the coefficients, and the projection
+  float cx[XP], cy[XP];
+  int ax[XP], ay[XP];
+  float proj = 0.f;
+  const int vown = ((C.hy0 + ly) * TW + lx) * 4;
+  const int hrow = (C.QV * 4 + ly * C.SW) * 4;
+#pragma unroll
+  for (int k = 0; k < XP; ++k) {
+    const unsigned so = ezo + (unsigned)C.xgi[k] * ecs;
+    cx[k] = bl32(gB, k < C.npx ? pe : kOOB, so);
+    proj = fmaf(cx[k], bl32(aB, k < C.npx ? pe : kOOB, so), proj);
+    const int d = C.xd[k], c = lx + d;
+    ax[k] = (unsigned)c < (unsigned)TW ? vown + d * 4 : hrow + (c & C.xm[k]) * 4;
+  }
+#pragma unroll
+  for (int k = 0; k < XP; ++k) {
+    const unsigned so = ezo + (unsigned)C.ygi[k] * ecs;
+    cy[k] = bl32(gB, k < C.npy ? pe : kOOB, so);
+    proj = fmaf(cy[k], bl32(aB, k < C.npy ? pe : kOOB, so), proj);
+    ay[k] = vown + C.yd[k] * TW * 4;
+  }
+  const float invo = bl32(oiB, pe, ezo);
+#pragma unroll
+  for (int c = 1; c <= RB - 2; ++c) PEA_PFCHUNK(c)
+  pf_wait((RB - 2) * npc);  // inv, chunk 0, g, affs and the own 1 / norm have landed (chunks 1 .. RB - 2 may still fly)
+
+  const float inv_own = fabsf(invo);
+#pragma unroll
+  for (int k = 0; k < XP; ++k) {
+    cx[k] *= fabsf(*(const float*)(lds + IP * PS + ax[k]));
+    cy[k] *= fabsf(*(const float*)(lds + IP * PS + ay[k]));
+    asm volatile("" : "+v"(cx[k]), "+v"(cy[k]));
+  }
+  if (invo < 0.f) proj = 0.f;  // clamp branch of F.normalize
+  asm volatile("" : "+v"(proj));
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the inv plane is dead: the last buffer may be filled
+  PEA_PFCHUNK(RB - 1)
+  const float sc = dl * inv_own;
+  const float pq = proj * inv_own;
+
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int bo = (ps % RB) * 2 * PS;
+    f2 o;  // the own pixel, raw
+    o.x = *(const float*)(lds + OWNB + (2 * (ps % RB)) * 2048 + (int)threadIdx.x * 4);
+    o.y = *(const float*)(lds + OWNB + (2 * (ps % RB) + 1) * 2048 + (int)threadIdx.x * 4);
+    f2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < XP; ++k) {
+      f2 v;
+      v.x = *(const float*)(lds + bo + ax[k]);
+      v.y = *(const float*)(lds + bo + PS + ax[k]);
+      acc = __builtin_elementwise_fma((f2){cx[k], cx[k]}, v, acc);
+      if (k % 5 == 4) asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int k = 0; k < XP; ++k) {
+      f2 v;
+      v.x = *(const float*)(lds + bo + ay[k]);
+      v.y = *(const float*)(lds + bo + PS + ay[k]);
+      acc = __builtin_elementwise_fma((f2){cy[k], cy[k]}, v, acc);
+      if (k % 5 == 4) asm volatile("" ::: "memory");
+    }
+    float vx = __builtin_fmaf(-o.x, pq, acc.x) * sc, vy = __builtin_fmaf(-o.y, pq, acc.y) * sc;
+    asm volatile("" : "+v"(vx), "+v"(vy));
+    if (ps + 1 < NP) {
+      const int nd = (ps + RB - 1 < NP ? ps + RB - 1 : NP - 1) - (ps + 1);  // chunks requested behind the one that has to have landed
+      if (npc == 0) lds_barrier();
+      else pf_wait(nd * npc);
+      if (ps + RB < NP) PEA_PFCHUNK(ps + RB)
+    }
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), dB, pe, ezo + (unsigned)(2 * ps) * ecs, kAuxNT);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs, kAuxNT);
+  }
+#undef PEA_PFDMA
+#undef PEA_PFCHUNK
+}
+
 }  // namespace pea

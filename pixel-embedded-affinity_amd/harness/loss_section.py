@@ -89,6 +89,9 @@ class _TensorSection(torch.autograd.Function):
                 """forward launch of loss j -> (desc, g, affs, inv); planes: 1 / norm planes wanted for the cross backward
                 (1: self loss, 2: cross loss with the detached second operand), allocated where those kernels cover the shape"""
                 spec = specs[j]
+                if not want_affs and spec.act:  # a map nobody sees (the cross loss'): without the activation it can serve the backward
+                    spec = copy.copy(spec)
+                    spec.act = 0
                 kshape = op._affs_shape(e_c, spec.K)
                 t, w, m = tensors[0] if j == ncall - 1 else tensors[j]
                 t, ts = op._batch_strided(t, "target", torch.float32, kshape)
@@ -110,7 +113,7 @@ class _TensorSection(torch.autograd.Function):
                 # the RAW cosine map is an input of the projection-first backward (D > 16, f16) and of the z-march backward (3D):
                 # written also for a loss whose map nobody asked for, where one of those kernels takes the shape (mode 3) -- round-4
                 # advice: without it the section's 3D backwards ran on the tile-per-plane kernels, not on the march
-                raw_ok = planes == 1 and inv is not None and spec.act == 0 and op.cross_supported(d, 3)
+                raw_ok = inv is not None and spec.act == 0 and op.cross_supported(d, 3 if planes == 1 else 4)
                 affs = torch.empty(kshape, dtype=torch.float32, device=dev) if (want_affs or raw_ok) else None
                 _lib.check(L.pea_affinity_fwd_ex(ctypes.byref(d), op._ptr(e_c), op._ptr(o_c), op._ptr(t), op._ptr(w), op._ptr(m),
                                                  op._ptr(affs), op._ptr(g), op._ptr(inv), op._ptr(rows[j]), op._ptr(work), wsb,
@@ -143,14 +146,14 @@ class _TensorSection(torch.autograd.Function):
             e0 = op._embedding_arg(embs[0], "embedding")
             ema_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e0.dtype)
             d0, g0, pred, inv0, raw0 = forward_one(0, e0, None, True, 1)
-            dxx, gx, _, invx, _ = forward_one(jx, e0, ema_c, False, 2 if inv0 is not None else 0)
+            dxx, gx, _, invx, rawx = forward_one(jx, e0, ema_c, False, 2 if inv0 is not None else 0)
             de0 = torch.empty_like(e0)
             rc = L.pea_affinity_bwd_dual_ex(ctypes.byref(d0), op._ptr(e0), op._ptr(ema_c), op._ptr(g0), op._ptr(gx), op._ptr(inv0),
                                             op._ptr(None if invx is None else invx[1]), op._ptr(wdev[0:1]), op._ptr(wdev[jx:jx + 1]),
                                             op._ptr(de0), op._stream())
             if rc == _lib.E_UNSUPPORTED:
                 de0 = backward_one(0, d0, e0, None, g0, inv0, raw=raw0)
-                de0.add_(backward_one(jx, dxx, e0, ema_c, gx, invx))
+                de0.add_(backward_one(jx, dxx, e0, ema_c, gx, invx, raw=rawx))
             else:
                 _lib.check(rc, "pea_affinity_bwd_dual_ex")
             grads.append(de0)

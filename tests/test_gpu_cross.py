@@ -224,6 +224,49 @@ def test_cross_3d_ema_vs_oracle(pkg, dev, orc, synth, monkeypatch, shape, which)
     assert abs(l1 - l0) <= 3e-6 * abs(l0) and np.abs(a1 - a0).max() < 2e-6 and relmax(g1, g0) < 2e-5
 
 
+@pytest.mark.parametrize("D,shape,shifts,K,border", [(32, (2, 48, 96), [1, 3, 5, 9, 11], 10, 0), (64, (1, 50, 100), [1, 3, 5, 9, 27], 8, 0),
+                                                     (32, (1, 64, 128), [1, 3, 5, 9, 27], 10, 1), (32, (2, 43, 96), [1, 3, 5, 9, 27], 9, 0)])
+def test_wide_cross_loss_with_detached_second_operand(pkg, dev, orc, synth, monkeypatch, D, shape, shifts, K, border):
+    """ema_embedding_loss at D = 32 / 64 (BASELINE configs[2] and [4] train it every step, scripts_bbbc039v1/main.py:288): round 5 --
+    forward k_fwd_xdma<D, .., OTHER> with the own pixel from own TILES staged beside each chunk, backward k_bwd_xdma_pfo (projection
+    first from the cross loss' raw map): against the oracle, bit-reproducible, and against the tiled kernels they replace"""
+    B, H, W = shape
+    offsets = pkg.multi_offset(shifts, 4)[:K]
+    lam = [2.0, 2.0] + [1.0] * (K - 2)
+    e, t, w, m = _inputs(synth, B, D, [1, H, W], K, 41, zero_px=True)
+    e, t, w, m = e[:, :, 0], t[:, :, 0], w[:, :, 0], m[:, :, 0]
+    eo = synth.synth_embedding((B, D, H * W), 979).reshape(B, D, H, W)
+    eo[0, :, 9, 11] = 0.0
+    bmode = pkg._lib.BORDER_CROP_ZERO if border else pkg._lib.BORDER_CIRCULAR
+    nmode = pkg._lib.NORM_CROPPED if border else pkg._lib.NORM_BX
+    spec = pkg.AffinitySpec(2, offsets, lam, bmode, nmode)
+    E, EO, T, Wt, M = cu(e, dev), cu(eo, dev), cu(t, dev), cu(w, dev), cu(m, dev)
+    L = pkg._lib.lib()
+    desc = pkg.affinity_op.make_desc(spec, E)
+    assert L.pea_cross_supported(ctypes.byref(desc), 2) == 1 and L.pea_cross_supported(ctypes.byref(desc), 4) == 1
+
+    def run():
+        x = E.clone().requires_grad_(True)
+        loss, a, parts = pkg.affinity_op.FusedAffinityMSE.apply(x, EO, T, Wt, M, spec)
+        (loss * 0.75).backward()
+        return loss.item(), a.cpu().numpy(), x.grad.cpu().numpy()
+
+    l1, a1, g1 = run()
+    d = orc.make_desc(B, D, [1, H, W], [[0, o[0], o[1]] for o in offsets], lam, orc.BORDER_CROP_ZERO if border else orc.BORDER_CIRCULAR,
+                      orc.NORM_CROPPED if border else orc.NORM_BX, ndim=2)
+    o_affs, o_loss = orc.c_fwd(d, e, eo, t, w, m)
+    o_de, _ = orc.c_bwd(d, e, eo, t, w, m, dloss=0.75)
+    assert np.abs(a1 - o_affs.reshape(a1.shape)).max() < AFFS_ATOL
+    assert abs(l1 - o_loss[0]) <= LOSS_RTOL * abs(o_loss[0])
+    assert relmax(g1, o_de.reshape(g1.shape)) < GRAD_RTOL
+    l1b, a1b, g1b = run()
+    assert l1 == l1b and np.array_equal(a1, a1b) and np.array_equal(g1, g1b)
+    monkeypatch.setenv("PEA_FWD_XDMA", "0")
+    monkeypatch.setenv("PEA_BWD_XDMA", "0")
+    l0, a0, g0 = run()
+    assert abs(l1 - l0) <= 3e-6 * abs(l0) and np.abs(a1 - a0).max() < 2e-6 and relmax(g1, g0) < 2e-5
+
+
 def test_cross_2d_crop_border_ema_vs_oracle(pkg, dev, orc, synth):
     """the role-A cross kernels with the CROP_ZERO border in 2D (round 5: the border is a template argument of the cross-loss
     instantiations too): forward + backward against the oracle"""
