@@ -208,7 +208,7 @@ int pea_affinity_fwd(const PeaDesc* desc, const void* e, const void* e_other, co
 int pea_cross_supported(const PeaDesc* desc, int backward) {
   if (validate(desc)) return 0;
   const KParams P = make_params(desc);
-  if (backward == 4) return desc->dtype == PEA_F32 ? xdma_cross_supported(P, desc->dtype, 4) : 0;  // ... with a detached second operand?
+  if (backward == 4) return xdma_cross_supported(P, desc->dtype, 4);  // ... with a detached second operand?
   if (backward == 3) {  // does pea_affinity_bwd_ex2 READ the raw affinity map for this descriptor (self loss)?
     if (zmarch_bwd_supported(P, desc->dtype)) return 1;
     return (env().bwd_pf && !(P.flags & kActMask) && (P.D > 16 || env().bwd_pf == 2) && xdma_cross_supported(P, desc->dtype, 1)) ? 1 : 0;
@@ -266,6 +266,9 @@ int pea_affinity_bwd_ex2(const PeaDesc* desc, const void* e, const void* e_other
   if (de && !de_other && dt == PEA_F32 &&
       xdma_bwd_other(P, (const float*)e, (const float*)e_other, inv_norm, g, affs, dloss, (float*)de, accumulate, s))
     return hip_rc();  // detached second operand: the role-A cross kernel (inv_norm = the two planes pea_affinity_fwd_ex wrote)
+  if (de && !de_other && dt == PEA_F16 && inv_norm && !accumulate && env().bwd_xdma && !env().force_direct &&
+      xdma_h_bwd_other(P, e, e_other, inv_norm, g, affs, dloss, de, s))
+    return hip_rc();
   if (accumulate) return PEA_E_UNSUPPORTED;
   if (de) {
     rc = run_bwd(P, dt, 1, e, e_other, nullptr, g, dloss, de, s);

@@ -152,6 +152,11 @@ bool xdma_bwd_self(const KParams& P, const float* x, const float* inv, const flo
 bool xdma_bwd_self_h(const KParams& P, const void* x, const float* inv, const float* g, const float* affs, const float* dl, void* dx,
                      hipStream_t s);  // f16 storage (pea_k_xdma_h.hip)
 bool xdma_h_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s);  // f16 storage forward / inference (pea_k_xdma_h.hip)
+// f16 storage, the cross loss with a detached second operand (pea_k_xdma_h.hip): forward (two 1 / norm planes) and the role-A backward
+// (projection first: needs the cross loss' raw map)
+bool xdma_h_fwd_other(const KParams& P, const FwdArgs& A, hipStream_t s);
+bool xdma_h_bwd_other(const KParams& P, const void* e, const void* e_other, const float* inv2, const float* g, const float* affs,
+                      const float* dl, void* de, hipStream_t s);
 // f16 storage backward with producer / consumer waves (pea_k_xdma_hq.hip; D = 32 / 64, small crosses, PEA_H16_HW=2)
 bool xdma_hq_bwd_self(const KParams& P, const void* x, const float* inv, const float* g, const float* affs, const float* dl, void* dx,
                       hipStream_t s);

@@ -145,7 +145,9 @@ static bool fwd_other_wide(const KParams& P, const FwdArgs& A, hipStream_t s) {
 }
 
 bool xdma_fwd_other(const KParams& P, const FwdArgs& A, hipStream_t s) {
-  if (!env().fwd_xdma || env().force_direct || A.dtype != PEA_F32 || !A.train || !A.inv_out) return false;
+  if (!env().fwd_xdma || env().force_direct || !A.train || !A.inv_out) return false;
+  if (A.dtype == PEA_F16) return xdma_h_fwd_other(P, A, s);  // pea_k_xdma_h.hip
+  if (A.dtype != PEA_F32) return false;
   if (P.D != 16 && P.D != 32 && P.D != 64) return false;
   const float *e = (const float*)A.e, *e_other = (const float*)A.eo;
   if (misaligned(e, 4) || misaligned(e_other, 16) || misaligned(A.t, 16) || misaligned(A.w, 16) || misaligned(A.affs, 16) ||
@@ -301,7 +303,12 @@ int xdma_cross_supported(const KParams& P, int dtype, int mode) {
   if (!(mode ? env().bwd_xdma : env().fwd_xdma)) return 0;
   XPlan X;
   if (dtype == PEA_F16) {  // pea_xdma_h16.h: 2D self loss
-    if (mode == 2 || mode == 4 || P.X % 8 || P.Z != 1) return 0;
+    if (P.X % 8 || P.Z != 1) return 0;
+    if (mode == 2 || mode == 4) {  // the cross loss with a detached second operand: forward + projection-first role-A backward
+      if (!env().h16_hw || !env().bwd_pf || !env().fwd_xdma || (P.flags & kActMask) || P.K > kXP) return 0;
+      if (!plan(P, kXdmaPSUF, 1, &X) || X.C.nfz > 0) return 0;
+      return (plan(P, kXdmaPSUF, 2, &X) && X.C.npz == 0 && X.C.npx <= kXP && X.C.npy <= kXP) ? 1 : 0;
+    }
     if (mode == 0) return (plan(P, kXdmaPSUF, 1, &X) && X.C.nfz == 0 && P.K <= kXP) ? 1 : 0;
     if (!plan(P, kXdmaPSUH, 0, &X) || X.C.npz > 0) return 0;
     const int xp = P.D > 32 ? 8 : kXP;

@@ -47,6 +47,9 @@ __device__ unsigned long long* g_stamps;
 #endif
 constexpr int kStampLast = 95;
 
+#ifndef PEA_BWD_DMA_AUX  // (diagnostic builds of profiles/microbench/bwd_vec.hip: cache policy of the backward's LDS-DMA; 2 = nt)
+#define PEA_BWD_DMA_AUX 0
+#endif
 constexpr int kXP = 10;  // (offset, role) pairs per axis held in registers (CVPPP: 5 shifts x 2 roles)
 constexpr int kXZ = 8;   // (offset, role) pairs along z (AC3/AC4 norm5: shifts 1, 2, 3, 4)
 constexpr int kXK = 16;  // channels (offsets) the forward's epilogue handles
@@ -422,8 +425,8 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, 0); \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + w1), 16, vo1, so, 0, 0);      \
     } else {                                                                                                        \
-      if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, 0);        \
-      if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + w1), 16, vo1, so, 0, 0); \
+      if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, PEA_BWD_DMA_AUX);        \
+      if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + w1), 16, vo1, so, 0, PEA_BWD_DMA_AUX); \
     }                                                                                                               \
   }
   PEA_STAMP(0)

@@ -78,7 +78,8 @@ __device__ __forceinline__ void x_items(const KParams& P, const XParams& C, int 
 // wait until only the youngest chunk's DMA (npc wave instructions of this wave: 2 or 0) may be in flight, then the barrier
 #define PEA_HWAIT1(npc)                                                                          \
   {                                                                                              \
-    if ((npc) == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");     \
+    if ((npc) == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");     \
+    else if ((npc) == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                \
   }
 #define PEA_HWAIT0() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -138,13 +139,19 @@ __device__ __forceinline__ float pf_finish(float acc, float o, float proj, float
 // (stored at once, in f16), there is no G array and no second read of the own pixel; WPE = 6 with the small planes.
 // HW: the working buffer stays in f16 (interleave_chunk: no conversion, half the LDS bytes written, a ds_read_b32 per pair instead of
 // a ds_read_b64); the FMAs take the halves directly (v_fma_mix_f32: f16 operand, f32 coefficient and accumulator -- the same arithmetic)
-template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, bool PF = false, int WPE = 4, bool HW = false>
+// OTHER: the cross loss with a detached second operand (ema_embedding_loss behind convert_consistency_flip's detach), role A: xt / invp
+// are the SECOND operand and its 1 / norm plane (staged: plan_xdma mode 2), the own pixel comes from the OWN tile staged beside each
+// chunk by wave 0 (f16: 1 KB per channel, no halo), `own_inv` is the own operand's signed 1 / norm plane.  Projection first only.
+template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, bool PF = false, int WPE = 4, bool HW = false, bool OTHER = false>
 __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, const XParams C, const __half* __restrict__ xt,
                                                              const float* __restrict__ invp, const float* __restrict__ gin,
                                                              const float* __restrict__ affs, const float* __restrict__ dloss,
-                                                             __half* __restrict__ dx) {
+                                                             __half* __restrict__ dx, const __half* __restrict__ own,
+                                                             const float* __restrict__ own_inv) {
   constexpr int NT = TH * TW, PS = PSU * 256, PH = PS / 2, NP = D_T / 2;
   static_assert(TW == 32 && D_T % 2 == 0 && PS % 512 == 0, "lane mapping / channel pairs / half planes in whole 256-byte units");
+  static_assert(!OTHER || (PF && HW), "the role-A instantiation: projection first, f16 working buffer");
+  constexpr int OWNR = 5 * PS;  // OTHER: three buffers x two channels x 1 KB of own tile behind the working planes and the ring
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   char* const W = lds;            // two f32 working planes (the 1 / norm plane sits in the second one first)
@@ -170,11 +177,24 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
   int qq[2];
   x_items<TH, TW, CROP>(P, C, y0, x0, wave, lane, vo, act, qq, vo8, act8);
   const int wbase = wave * 1024;
-  const int npc = 2 * (__builtin_amdgcn_ballot_w64(act8) != 0);
+  const bool ownw = OTHER && wave == 0;  // uniform: the wave that moves the own tile (64 octs = 16 rows of 32 pixels)
+  const rsrc_t oB = mkbuf(OTHER ? own + (size_t)b * D_T * S : nullptr);
+  unsigned ownvo = kOOB;
+  if (OTHER) {
+    const int oy = y0 + (lane >> 2), ox = x0 + 8 * (lane & 3);
+    ownvo = (oy < P.Y && ox < P.X) ? (unsigned)(oy * P.X + ox) * 2u : kOOB;
+  }
+  const int npc = 2 * (__builtin_amdgcn_ballot_w64(act8) != 0) + (ownw ? 2 : 0);
 #define PEA_HDMA16(rbuf, ch)                                                                                                  \
-  if (act8) {                                                                                                               \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(R + ((rbuf) * 2) * PH + wbase), 16, vo8, hzo + (unsigned)(ch) * hcs, 0, 0);        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(R + ((rbuf) * 2 + 1) * PH + wbase), 16, vo8, hzo + (unsigned)((ch) + 1) * hcs, 0, 0); \
+  {                                                                                                                         \
+    if (act8) {                                                                                                             \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(R + ((rbuf) * 2) * PH + wbase), 16, vo8, hzo + (unsigned)(ch) * hcs, 0, 0);        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(R + ((rbuf) * 2 + 1) * PH + wbase), 16, vo8, hzo + (unsigned)((ch) + 1) * hcs, 0, 0); \
+    }                                                                                                                       \
+    if (ownw) {                                                                                                             \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(oB, (lds_ptr_t)(lds + OWNR + ((rbuf) * 2) * 1024), 16, ownvo, hzo + (unsigned)(ch) * hcs, 0, 0);        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(oB, (lds_ptr_t)(lds + OWNR + ((rbuf) * 2 + 1) * 1024), 16, ownvo, hzo + (unsigned)((ch) + 1) * hcs, 0, 0); \
+    }                                                                                                                       \
   }
   // the 1 / norm plane (f32) -> the second working plane
   if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(iB, (lds_ptr_t)(W + PS + wbase), 16, vo[0], fzo, 0, 0);
@@ -215,11 +235,13 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
     if (PF) proj = fmaf(gk, bl32(aB, k < C.npy ? o : kOOB, fzo + (unsigned)C.ygi[k] * fcs), proj);
     ay[k] = vown + C.yd[k] * TW * 4;
   }
+  float invo_g = 0.f;
+  if (OTHER) invo_g = bl32(mkbuf(own_inv + (size_t)b * S), live ? po * 4u : kOOB, fzo);
   if (NP > 1) PEA_HDMA16(1, 2)
   // the 1 / norm plane, chunk 0 and g have landed (chunk 1 may still fly)
   if (NP > 1) PEA_HWAIT1(npc)
   else PEA_HWAIT0()
-  const float invo = *(const float*)(W + PS + vown);
+  const float invo = OTHER ? invo_g : *(const float*)(W + PS + vown);
   const float inv_own = fabsf(invo);
 #pragma unroll
   for (int k = 0; k < XP; ++k) {
@@ -245,7 +267,11 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
       interleave_chunk<PS, NT>(W, R, ps % 3, C.QA);
       lds_barrier();  // the working buffer holds chunk ps
 #endif
-      const h2_t oh = *(const h2_t*)(W + vown);
+      h2_t oh = *(const h2_t*)(W + vown);
+      if (OTHER) {  // the own pixel from the own tile ([channel][512 pixels] halves)
+        oh.x = *(const _Float16*)(lds + OWNR + ((ps % 3) * 2) * 1024 + (int)threadIdx.x * 2);
+        oh.y = *(const _Float16*)(lds + OWNR + ((ps % 3) * 2 + 1) * 1024 + (int)threadIdx.x * 2);
+      }
       o = (f2){(float)oh.x, (float)oh.y} * inv_own;
 #ifndef PEA_ABL_H_NOGATHER
 #pragma unroll
@@ -352,12 +378,16 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_bwd_xdma_h(const KParams P, con
 // HW: the working buffer stays in f16 (interleave_chunk) and the gather runs on v_dot2_f32_f16
 // NXP: offsets the gather walks (kXP = 10; 8 for tables with no more, e.g. BASELINE configs[4]'s offsets[:8] -- an unused slot costs
 // its LDS read and its two dot products all the same)
-template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN, int WPE, bool HW = false, int NXP = kXP>
+// OTHER: the cross loss a_i(p) = <ehat(p), ehat_other(p + o_i)>: `e` is the SECOND operand (staged), the own pixel comes from the own
+// tile of `own` staged beside each chunk by wave 0; both 1 / norm planes are written (inv_out: own, inv_other_out: the second operand's)
+template <int D_T, int TH, int TW, int PSU, bool CROP, bool TRAIN, int WPE, bool HW = false, int NXP = kXP, bool OTHER = false>
 __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, const XParams C, const __half* __restrict__ e,
                                                              const float* __restrict__ target, const float* __restrict__ weight,
                                                              const uint8_t* __restrict__ mask, float* __restrict__ affs,
                                                              float* __restrict__ gout, LossState* __restrict__ st,
-                                                             float* __restrict__ inv_out) {
+                                                             float* __restrict__ inv_out, const __half* __restrict__ own,
+                                                             float* __restrict__ inv_other_out) {
+  static_assert(!OTHER || (HW && TRAIN), "the cross-loss instantiation: f16 working buffer, training");
   constexpr int NT = TH * TW, PS = PSU * 256, PH = PS / 2, NP = D_T / 2, TP = NT, QP = TP / 4, NSL = QP / 64;
   constexpr int KMAX = kXP;
   constexpr int ITEMS = (KMAX * QP + NT - 1) / NT;
@@ -391,11 +421,28 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
   int qq[2];
   x_items<TH, TW, CROP>(P, C, y0, x0, wave, lane, vo, act, qq, vo8, act8);
   const int wbase = wave * 1024;
-  const int npc = 2 * (__builtin_amdgcn_ballot_w64(act8) != 0);
+  constexpr int OWNR = (WP + 3) * PS;  // OTHER: three buffers x two channels x 1 KB of own tile behind the ring
+  const bool ownw = OTHER && wave == 0;  // uniform: the wave that moves the own tile
+  const rsrc_t oB = mkbuf(OTHER ? own + (size_t)b * D_T * S : nullptr);
+  unsigned ownvo = kOOB;
+  if (OTHER) {
+    const int oy = y0 + (lane >> 2), ox = x0 + 8 * (lane & 3);
+    ownvo = (oy < P.Y && ox < P.X) ? (unsigned)(oy * P.X + ox) * 2u : kOOB;
+  }
+  const int npc = 2 * (__builtin_amdgcn_ballot_w64(act8) != 0) + (ownw ? 2 : 0);
+// (ONE statement: the call sites are `if (..) PEA_HDMA16(..)` -- as two statements the own tile's DMA escaped the condition, was requested
+//  for chunks that do not exist and read past the end of the tensor: harmless bytes, and a memory fault once the tensor ended near a
+//  mapping's end.  Found at 400 x 400; tests/test_gpu_fullsize2.py runs the full size.)
 #define PEA_HDMA16(rbuf, ch)                                                                                                  \
-  if (act8) {                                                                                                               \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(R + ((rbuf) * 2) * PH + wbase), 16, vo8, hzo + (unsigned)(ch) * hcs, 0, 0);        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(R + ((rbuf) * 2 + 1) * PH + wbase), 16, vo8, hzo + (unsigned)((ch) + 1) * hcs, 0, 0); \
+  {                                                                                                                         \
+    if (act8) {                                                                                                             \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(R + ((rbuf) * 2) * PH + wbase), 16, vo8, hzo + (unsigned)(ch) * hcs, 0, 0);        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(R + ((rbuf) * 2 + 1) * PH + wbase), 16, vo8, hzo + (unsigned)((ch) + 1) * hcs, 0, 0); \
+    }                                                                                                                       \
+    if (ownw) {                                                                                                             \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(oB, (lds_ptr_t)(lds + OWNR + ((rbuf) * 2) * 1024), 16, ownvo, hzo + (unsigned)(ch) * hcs, 0, 0);        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(oB, (lds_ptr_t)(lds + OWNR + ((rbuf) * 2 + 1) * 1024), 16, ownvo, hzo + (unsigned)((ch) + 1) * hcs, 0, 0); \
+    }                                                                                                                       \
   }
   PEA_HDMA16(0, 0)
   if (NP > 1) PEA_HDMA16(1, 2)
@@ -416,6 +463,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
   // HW: scalar accumulators (the two channels of a chunk are summed by v_dot2); else packed over the two channels
   typedef typename std::conditional<HW, float, f2>::type acc_t;
   acc_t dot[NXP], ssq[NXP], oss;
+  float css = 0.f;  // OTHER: the second operand's own sum of squares (its 1 / norm goes to the backward)
   if constexpr (HW) oss = 0.f; else oss = (f2){0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < NXP; ++k) {
@@ -426,7 +474,12 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
     if constexpr (HW) {
       interleave_chunk<PS, NT>(W, R, ps % 3, C.QA);
       lds_barrier();
-      const h2_t o = *(const h2_t*)(W + vown);
+      h2_t o = *(const h2_t*)(W + vown);
+      if (OTHER) {
+        css = __builtin_amdgcn_fdot2(o, o, css, false);
+        o.x = *(const _Float16*)(lds + OWNR + ((ps % 3) * 2) * 1024 + (int)threadIdx.x * 2);
+        o.y = *(const _Float16*)(lds + OWNR + ((ps % 3) * 2 + 1) * 1024 + (int)threadIdx.x * 2);
+      }
       oss = __builtin_amdgcn_fdot2(o, o, oss, false);
 #pragma unroll
       for (int k = 0; k < NXP; ++k) {
@@ -451,6 +504,7 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
 #pragma unroll
     for (int k = 0; k < NXP; ++k) asm volatile("" : "+v"(dot[k]), "+v"(ssq[k]));
     asm volatile("" : "+v"(oss));
+    if (OTHER) asm volatile("" : "+v"(css));
     if (ps + 1 < NP) {
       if (ps + 2 < NP) PEA_HWAIT1(npc)
       else PEA_HWAIT0()
@@ -471,6 +525,10 @@ __global__ __launch_bounds__(TH* TW, WPE) void k_fwd_xdma_h(const KParams P, con
   const float inv_eps = 1.0f / P.eps;
   const float inv_own = rnorm(osum, inv_eps);
   if (inv_out) bs32(iB, osum < P.eps * P.eps ? -inv_own : inv_own, pe, ezo);
+  if (OTHER && inv_other_out) {
+    const float inv_c = rnorm(css, inv_eps);
+    bs32(mkbuf(inv_other_out + (size_t)b * S), css < P.eps * P.eps ? -inv_c : inv_c, pe, ezo);
+  }
   lds_barrier();  // every lane is done with the working planes: sA goes over them
 #pragma unroll
   for (int k = 0; k < NXP; ++k) {

@@ -40,9 +40,9 @@ int main() {
   constexpr auto kern = k_bwd_xdma_h<D, 16, 32, PSU, false, kXP, true, 4, true>;
   const dim3 grid((unsigned)(C.tiles_per_xcd * 8)), blk(512);
   hipEvent_t t0, t1; CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
-  for (int it = 0; it < 5; ++it) hipLaunchKernelGGL(kern, grid, blk, lds, 0, P, C, e, inv, g, a, (const float*)nullptr, dx);
+  for (int it = 0; it < 5; ++it) hipLaunchKernelGGL(kern, grid, blk, lds, 0, P, C, e, inv, g, a, (const float*)nullptr, dx, (const __half*)nullptr, (const float*)nullptr);
   CK(hipEventRecord(t0));
-  for (int it = 0; it < 20; ++it) hipLaunchKernelGGL(kern, grid, blk, lds, 0, P, C, e, inv, g, a, (const float*)nullptr, dx);
+  for (int it = 0; it < 20; ++it) hipLaunchKernelGGL(kern, grid, blk, lds, 0, P, C, e, inv, g, a, (const float*)nullptr, dx, (const __half*)nullptr, (const float*)nullptr);
   CK(hipEventRecord(t1)); CK(hipEventSynchronize(t1));
   float ms; CK(hipEventElapsedTime(&ms, t0, t1));
   printf("k_bwd_xdma_h<64, PF, HW> B=8 x 64 x 544^2 K=8: %.1f us per launch, %d tiles, region %d quads\n", ms * 50.f, C.ntiles, C.QA);

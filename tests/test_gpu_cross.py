@@ -267,6 +267,54 @@ def test_wide_cross_loss_with_detached_second_operand(pkg, dev, orc, synth, monk
     assert abs(l1 - l0) <= 3e-6 * abs(l0) and np.abs(a1 - a0).max() < 2e-6 and relmax(g1, g0) < 2e-5
 
 
+@pytest.mark.parametrize("D,shape,shifts,K,border", [(64, (2, 48, 96), [1, 3, 5, 9, 27], 8, 0), (32, (1, 50, 104), [1, 3, 5, 9, 11], 10, 0),
+                                                     (16, (2, 43, 96), [1, 3, 5, 9, 27], 10, 0), (64, (1, 64, 128), [1, 3, 5, 9, 27], 8, 1),
+                                                     (64, (1, 400, 400), [1, 3, 5, 9, 27], 8, 0)])
+def test_f16_cross_loss_with_detached_second_operand(pkg, dev, orc, synth, monkeypatch, D, shape, shifts, K, border):
+    """ema_embedding_loss with f16 storage (BASELINE configs[4]: D = 64 in half precision): round 5 -- k_fwd_xdma_h<.., OTHER> (own tile
+    staged beside the second operand's cross, v_dot2 gather) and k_bwd_xdma_h<.., PF, HW, OTHER>: against the oracle on the f16 values
+    (gradient tolerance 2e-3: the stored gradient is rounded to f16), bit-reproducible, and against the tiled kernels"""
+    B, H, W = shape
+    offsets = pkg.multi_offset(shifts, 4)[:K]
+    lam = [2.0, 2.0] + [1.0] * (K - 2)
+    # (no zero-norm pixels here: their clamp-branch gradient, g / eps, overflows the f16 it is stored in.  The 400 x 400 case: a 20 MB
+    #  tensor ends 0.5 MB before its mapping does -- where a request past the last channel faulted, DESIGN.md appendix B)
+    e, t, w, m = _inputs(synth, B, D, [1, H, W], K, 43, zero_px=False)
+    e, t, w, m = e[:, :, 0].astype(np.float16), t[:, :, 0], w[:, :, 0], m[:, :, 0]
+    eo = synth.synth_embedding((B, D, H * W), 981).reshape(B, D, H, W).astype(np.float16)
+    eo[0, :, 9, 11] = 0.0
+    bmode = pkg._lib.BORDER_CROP_ZERO if border else pkg._lib.BORDER_CIRCULAR
+    nmode = pkg._lib.NORM_CROPPED if border else pkg._lib.NORM_BX
+    spec = pkg.AffinitySpec(2, offsets, lam, bmode, nmode)
+    E, EO, T, Wt, M = cu(e, dev), cu(eo, dev), cu(t, dev), cu(w, dev), cu(m, dev)
+    L = pkg._lib.lib()
+    desc = pkg.affinity_op.make_desc(spec, E)
+    assert L.pea_cross_supported(ctypes.byref(desc), 2) == 1 and L.pea_cross_supported(ctypes.byref(desc), 4) == 1
+
+    def run():
+        x = E.clone().requires_grad_(True)
+        loss, a, parts = pkg.affinity_op.FusedAffinityMSE.apply(x, EO, T, Wt, M, spec)
+        (loss * 0.75).backward()
+        return loss.item(), a.cpu().numpy(), x.grad.float().cpu().numpy()
+
+    l1, a1, g1 = run()
+    ef, eof = e.astype(np.float32), eo.astype(np.float32)
+    d = orc.make_desc(B, D, [1, H, W], [[0, o[0], o[1]] for o in offsets], lam, orc.BORDER_CROP_ZERO if border else orc.BORDER_CIRCULAR,
+                      orc.NORM_CROPPED if border else orc.NORM_BX, ndim=2)
+    o_affs, o_loss = orc.c_fwd(d, ef, eof, t, w, m)
+    o_de, _ = orc.c_bwd(d, ef, eof, t, w, m, dloss=0.75)
+    assert np.abs(a1 - o_affs.reshape(a1.shape)).max() < AFFS_ATOL
+    assert abs(l1 - o_loss[0]) <= LOSS_RTOL * abs(o_loss[0])
+    assert relmax(g1, o_de.reshape(g1.shape)) < 2e-3
+    l1b, a1b, g1b = run()
+    assert l1 == l1b and np.array_equal(a1, a1b) and np.array_equal(g1, g1b)
+    monkeypatch.setenv("PEA_FWD_XDMA", "0")
+    monkeypatch.setenv("PEA_BWD_XDMA", "0")
+    assert L.pea_cross_supported(ctypes.byref(pkg.affinity_op.make_desc(spec, E)), 2) == 0
+    l0, a0, g0 = run()
+    assert abs(l1 - l0) <= 3e-6 * abs(l0) and np.abs(a1 - a0).max() < 2e-6 and relmax(g1, g0) < 2e-3
+
+
 def test_cross_2d_crop_border_ema_vs_oracle(pkg, dev, orc, synth):
     """the role-A cross kernels with the CROP_ZERO border in 2D (round 5: the border is a template argument of the cross-loss
     instantiations too): forward + backward against the oracle"""

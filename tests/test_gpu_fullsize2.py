@@ -97,6 +97,44 @@ def test_full_size_ema_cross_loss(pkg, dev, orc):
         assert relmax(npy(g1[b, :, y0:y0 + hh, x0:x0 + ww])[inner], og[inner]) < GRAD_RTOL
 
 
+@pytest.mark.parametrize("Dm,f16,shifts,K", [(32, False, [1, 3, 5, 9, 11], 10), (64, True, [1, 3, 5, 9, 27], 8)])
+def test_full_size_wide_ema_cross_loss(pkg, dev, orc, Dm, f16, shifts, K):
+    """ema_embedding_loss at D = 32 (f32, the BBBC stencil) and D = 64 (f16 storage, offsets[:8]) at B = 8 x 544^2 -- the own-tile
+    kernels of round 5 (k_fwd_xdma<.., OWNL> / k_bwd_xdma_pfo; k_fwd_xdma_h / k_bwd_xdma_h<.., OTHER>): bit-identical reruns and a
+    window against the oracle"""
+    offsets = pkg.multi_offset(shifts, 4)[:K]
+    lam = [2.0 if i < 2 else 1.0 for i in range(K)]
+    spec = pkg.AffinitySpec(2, offsets, lam, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX)
+    g = torch.Generator(device=dev).manual_seed(3001)
+    e = torch.randn([B, Dm, H, W], generator=g, device=dev)
+    ema = torch.randn([B, Dm, H, W], generator=g, device=dev)
+    if f16:
+        e, ema = e.half(), ema.half()
+    t = (torch.rand([B, K, H, W], generator=g, device=dev) < 0.6).float()
+    w = torch.rand([B, K, H, W], generator=g, device=dev) + 0.5
+    m = (torch.rand([B, K, H, W], generator=g, device=dev) < 0.9).to(torch.uint8)
+    desc = pkg.affinity_op.make_desc(spec, e)
+    L = pkg._lib.lib()
+    assert L.pea_cross_supported(ctypes.byref(desc), 2) == 1 and L.pea_cross_supported(ctypes.byref(desc), 4) == 1
+
+    def run():
+        et = e.clone().requires_grad_(True)
+        loss, affs, parts = pkg.affinity_op.FusedAffinityMSE.apply(et, ema, t, w, m, spec)
+        (loss * 0.5).backward()
+        return loss.detach().clone(), affs, et.grad
+
+    l1, a1, g1 = run()
+    l2, a2, g2 = run()
+    assert torch.equal(l1, l2) and torch.equal(a1, a2) and torch.equal(g1, g2)
+    assert torch.isfinite(g1.float()).all()
+    reach, hh, ww = max(shifts[:(K + 1) // 2]), 96, 128
+    b, y0, x0 = 6, 416, 384
+    oa, og = window_oracle_2d(orc, offsets, lam, float(B * W), b, y0, x0, hh, ww, e, ema, t, w, m, 0.5)
+    inner = (slice(None), slice(reach, hh - reach), slice(reach, ww - reach))
+    assert np.abs(npy(a1[b, :, y0:y0 + hh, x0:x0 + ww])[inner] - oa[inner]).max() < AFFS_ATOL
+    assert relmax(npy(g1[b, :, y0:y0 + hh, x0:x0 + ww])[inner], og[inner]) < (2e-3 if f16 else GRAD_RTOL)
+
+
 def _section_inputs(pkg, dev, synth):
     offsets = pkg.multi_offset(SHIFTS, 4)
     nb_half = 2
