@@ -11,14 +11,18 @@ constexpr int kTH = 16, kTW = 32;
 constexpr int kPSUB = 52;  // backward: the two-sided +-27 cross in whole 64-quad blocks (13 KB planes, 78 KB of ring)
 constexpr int kPSUF = 32;  // forward: the one-sided cross in 8 KB planes (48 KB of ring)
 
-struct ZPlan { XParams C; ZMParams M; size_t lds; };
+struct ZPlan { XParams C; ZMParams M; size_t lds; int nb; };  // nb: ring depth of the backward the LDS was sized for
 
 // mode 0: backward (both roles), 1: forward.  The tile walk of xdma_tile is reused with the SEGMENT in the place of z: blocks of
 // tile columns (one XCD's 32 workgroups march through one block: its halos are shared out of that XCD's L2), the segments of a
 // block one after the other.
 bool plan(const KParams& P, int mode, ZPlan* out) {
   static thread_local PlanCache<ZPlan, 8> cache;
-  return cache.get(P, mode * 4096 + env().zm_nb * 1024 + env().zmarch * 64 + env().zseg, out, [&](ZPlan* p) {
+  // (the segmentation depends on the CURRENT device's CU count: part of the key -- a thread that serves devices of different sizes must
+  //  not be handed the other device's plan; round-4 advice)
+  const Env& E = env();
+  return cache.get(P, mode * 4096 + E.zm_nb * 1024 + E.zmarch * 64 + E.zseg + (device_cus() << 13), out, [&](ZPlan* p) {
+    p->nb = E.zm_nb == 3 ? 3 : 4;
     if (!env().zmarch || !plan_zmarch(P, &p->M)) return false;
     if (!plan_xdma(P, kTH, kTW, mode ? kPSUF : kPSUB, &p->C, &p->lds, mode)) return false;
     XParams& C = p->C;
@@ -27,7 +31,7 @@ bool plan(const KParams& P, int mode, ZPlan* out) {
     // forward: a ring of eight buffers (16 planes) + the parked dot products [kXP + 2][tile] + the loss partials
     if (mode == 1) p->lds = (size_t)16 * kPSUF * 256 + (size_t)(kXP + 2) * kTH * kTW * 4 + 256;
     // backward: the ring of four (PEA_ZM_NB=3: three) two-plane buffers + the waves' blocks of prefetched g / a values
-    else p->lds = (size_t)2 * (env().zm_nb == 3 ? 3 : 4) * kPSUB * 256 + (size_t)(kTH * kTW / 64) * kZmG * 256;
+    else p->lds = (size_t)2 * p->nb * kPSUB * 256 + (size_t)(kTH * kTW / 64) * kZmG * 256;
     const long long cols = (long long)P.B * C.tiles_per_plane;
     // one workgroup per CU: whole columns when there are enough of them for two rounds, else segments of >= 8 planes
     int nseg = 1;
@@ -100,7 +104,7 @@ bool zmarch_bwd(const KParams& P, const float* x, const float* inv, const float*
   ZPlan Z;
   if (!plan(P, 0, &Z)) return false;
   const dim3 grid((unsigned)(Z.C.tiles_per_xcd * kXcd)), blk(kTH * kTW);
-  if (env().zm_nb == 3) {
+  if (Z.nb == 3) {  // (the ring depth the plan sized its LDS for, not a second look at the switch: round-4 advice)
     constexpr auto kern = k_bwd_zm<kTH, kTW, kPSUB, 3>;
     PEA_LAUNCH(kern, grid, blk, Z.lds, s, P, Z.C, Z.M, x, inv, g, affs, dl, dx)
   } else {
