@@ -315,17 +315,34 @@ N_BATCHES = 7  # timed batches of --steps steps each: `value` is their MEDIAN (V
                # state of the box / process silently became the round's number; now it shows as ms_min / ms_max beside the median)
 
 
-def timed_batches(step, fence, steps, dist, red_dev, nb=N_BATCHES):
+def n_batches(steps):
+    """7 batches; 21 when a batch is short (--steps < 100: a 20-step batch is 4 ms, and 3 of 7 such batches were seen to take a 1 ms
+    host stall each on one box -- profiles/r5_bench_s20_2.json: the median of 21 does not land on one)"""
+    return N_BATCHES if steps >= 100 else 3 * N_BATCHES
+
+
+def timed_batches(step, fence, steps, dist, red_dev, nb=None):
     """nb batches of EXACTLY `steps` calls of step(), each bracketed by fence() (barrier + synchronize) on both sides; per batch the MAX
-    over ranks.  Returns the list of batch durations in seconds, in the order they ran."""
+    over ranks.  Returns the list of batch durations in seconds, in the order they ran.  Python's cyclic garbage collector is
+    paused over the timed batches (autograd allocates per step; a generation-2 collection inside a 4 ms batch is a host stall, not
+    a property of the path)."""
+    import gc
+    nb = nb or n_batches(steps)
     out = []
-    for _ in range(nb):
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        fence()
-        out.append(time.perf_counter() - t0)
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        for _ in range(nb):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            fence()
+            out.append(time.perf_counter() - t0)
+    finally:
+        if was:
+            gc.enable()
     if dist is not None:
         tmax = torch.tensor(out, dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -810,7 +827,7 @@ def main():
             "metric": "affinity-map Mpixels/sec (fwd+bwd)", "value": round(value, 2), "unit": "Mpx/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
             "ms_min": round(bst["min"], 5), "ms_max": round(bst["max"], 5), "batches_ms": bst["all"],
-            "timing": "median of %d batches of %d steps (each between barrier + synchronize; max over ranks per batch)" % (N_BATCHES, args.steps),
+            "timing": "median of %d batches of %d steps (each between barrier + synchronize; max over ranks per batch)" % (n_batches(args.steps), args.steps),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: CVPPP A1 embedding_loss fwd+bwd, B=%d per GPU x D=%d x %dx%d (530x500 padded), "
                                    "K=%d offsets (shifts 1,3,5,9,27 x neighbor 4), circular border, u8 mask" % (B, D, H, W, K),
