@@ -329,9 +329,8 @@ def timed_batches(step, fence, steps, dist, red_dev, nb=None):
     import gc
     nb = nb or n_batches(steps)
     out = []
-    gc.collect()
-    was = gc.isenabled()
-    gc.disable()
+    was = gc.isenabled()  # (no gc.collect() here: 50-100 ms of host work with the GPU idle and the first batches read 5-80 % slow while its
+    gc.disable()          #  clocks come back -- gpurun_out/r5_bench_s20_3.json; the collection happens before the settle phase instead)
     try:
         for _ in range(nb):
             fence()
@@ -693,6 +692,8 @@ def main():
     # Settle first (untimed, before the W warm-up steps): a GPU that has just been handed over idles at its lowest clocks
     # and the first few hundred launches also pay the allocator's and the library's first-touch costs; a 20-step timing
     # started cold reads 25-30 % slow.  Run batches of 20 steps until two consecutive batches agree within 2 % (<= 1.5 s).
+    import gc
+    gc.collect()
     settle = settle_gpu(step)
     for _ in range(args.warmup):
         step()
@@ -810,6 +811,39 @@ def main():
                     run(which)
                 # best of three batches: a one-off allocator stall inside a 10-call batch is not the section's cost
                 out[which] = round(min(event_time_ms(lambda: run(which), 10) for _ in range(3)) * 1e3, 1)
+            # the same two sections captured through the public API (pea.graphed: both streams of the section become one graph launch,
+            # the ~25 launches' Python / ctypes / autograd time is gone); wall clock around 20 replays back to back
+            for which in ("one_node", "labels"):
+                try:
+                    xs = [e.detach().clone().requires_grad_(True) for e in embs]
+
+                    def fn(*xs):
+                        for t in xs:
+                            t.grad = None
+                        if which == "labels":
+                            loss, pred, _ = pkg.cvppp_loss_section_from_labels(xs[0], list(xs[1:]), ema, labs[0], labs[1:], crit, offsets,
+                                                                               nb_half, relu_pred=True)
+                        else:
+                            loss, pred, _ = pkg.cvppp_loss_section(xs[0], list(xs[1:]), ema, tt, ww, mm, downs, crit, offsets, nb_half,
+                                                                   relu_pred=True)
+                        loss.backward()
+                        return (loss, pred) + tuple(t.grad for t in xs)
+                    g = pkg.graphed(fn, *xs)
+                    best = None
+                    for _ in range(3):
+                        g.replay()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(20):
+                            g.replay()
+                        torch.cuda.synchronize()
+                        ms = (time.perf_counter() - t0) / 20
+                        best = ms if best is None else min(best, ms)
+                    out[which + "_graphed"] = round(best * 1e6, 1)
+                    del g
+                except Exception as ex:  # noqa: BLE001 -- an extra field, never the headline
+                    out[which + "_graphed"] = None
+                    print("section capture (%s) failed: %r" % (which, ex), file=sys.stderr)
             return out
 
         kt_iso = {name: isolated_time_ms(fn, 20) for name, fn in (("fwd", fwd), ("bwd", bwd))}

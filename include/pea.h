@@ -194,8 +194,26 @@ int pea_inv_norm(const PeaDesc *desc, const void *e, float *inv_norm_out, void *
  * volumes, csrc/pea_zmarch.h): a caller that hands `affs` over must then keep the forward's map unmodified until the backward.
  * backward == 4: the same question for the cross loss with a detached second operand (e_other != NULL, de_other == NULL): 1 at
  * D = 32 / 64, f32, 2D -- there the role-A backward is the projection-first kernel k_bwd_xdma_pfo (csrc/pea_xdma_pf.h) and runs only
- * when `affs` (the cross loss' raw map) comes along; without it the tiled kernels run. */
+ * when `affs` (the cross loss' raw map) comes along; without it the tiled kernels run.  backward == 5: 1 when
+ * pea_affinity_fwd_dual_ex runs the descriptor's self + cross forward pair as one launch. */
 int pea_cross_supported(const PeaDesc *desc, int backward);
+
+/* The FORWARD of the full-resolution pair of the 2D training loops in one launch: embedding_loss(e, target, weight, mask) and
+ * ema_embedding_loss(e, ema, target, weight, mask) on the SAME target / weight / mask (scripts_cvppp/main.py:284 and :293,
+ * scripts_bbbc039v1/main.py likewise; scripts_cvppp/loss/loss_embedding_mse.py:18-47, 79-95).  Exactly
+ *     pea_affinity_fwd_ex(desc,       e, NULL, target, weight, mask, affs, g_out,       inv_norm_out,          loss_out,       workspace, ..)
+ *     pea_affinity_fwd_ex(desc_cross, e, ema,  target, weight, mask, NULL, g_cross_out, {own, inv_norm_other}, loss_cross_out, workspace_cross, ..)
+ * -- every output bit-identical to those two calls -- but e, target, weight and mask are read once (csrc/pea_xdma_dual.h: 338
+ * instead of 532 bytes per pixel at D = 16, K = 10).  desc_cross may differ from desc in lambda (the cross loss' affs0_weight) and in
+ * the activation flags (the cross loss' map is not written); everything else must agree (PEA_E_DESC).  inv_norm_out / inv_norm_other_out:
+ * [B,Z,Y,X] each, the planes pea_affinity_bwd_dual_ex takes.  workspace / workspace_cross: two DIFFERENT state blocks
+ * (pea_workspace_init).  affs may be NULL.  Returns PEA_E_UNSUPPORTED -- before anything is launched -- where no fused kernel covers
+ * the descriptor (pea_cross_supported(desc, 5) == 0: anything but 2D, D = 16, f32, axis-aligned stencil with K <= 10; PEA_FWD_DUAL=0)
+ * or ema aliases e: the caller then makes the two calls above. */
+int pea_affinity_fwd_dual_ex(const PeaDesc *desc, const PeaDesc *desc_cross, const void *e, const void *ema, const float *target,
+                             const float *weight, const uint8_t *mask, float *affs, float *g_out, float *g_cross_out,
+                             float *inv_norm_out, float *inv_norm_other_out, float *loss_out, float *loss_cross_out, void *workspace,
+                             void *workspace_cross, size_t workspace_bytes, void *stream);
 
 /* The backward of the full-resolution pair of the training loop in one launch: g is what pea_affinity_fwd wrote for the self
  * loss (e_other = NULL), g_cross what it wrote for the detached-EMA cross loss of the same e (e_other = ema); the stencil

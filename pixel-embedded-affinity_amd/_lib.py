@@ -25,7 +25,7 @@ TGT_PADDING, TGT_BOTH_FOREGROUND, TGT_MASK_INSIDE, TGT_ACCUMULATE = 1, 2, 4, 8
 
 EXPORTS = ("pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_workspace_init", "pea_reload_env",
            "pea_affinity_infer", "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_ex", "pea_affinity_bwd_ex", "pea_affinity_bwd_ex2", "pea_inv_norm",
-           "pea_cross_supported", "pea_affinity_bwd_dual", "pea_affinity_bwd_dual_ex", "pea_scale_inplace", "pea_scale_inplace_multi", "pea_weighted_sum",
+           "pea_cross_supported", "pea_affinity_bwd_dual", "pea_affinity_bwd_dual_ex", "pea_affinity_fwd_dual_ex", "pea_scale_inplace", "pea_scale_inplace_multi", "pea_weighted_sum",
            "pea_fill_border_relu", "pea_head_workspace_bytes", "pea_head_fwd", "pea_head_bwd",
            "pea_targets_workspace_bytes", "pea_gen_targets", "pea_stitch_add", "pea_stitch_finalize",
            "pea_label_weights", "pea_affinity_fwd_bwd_labels", "pea_affinity_fwd_bwd_labels_ex", "pea_labels_scratch_bytes",
@@ -169,6 +169,8 @@ def lib():
     L.pea_inv_norm.argtypes = [dp, vp, vp, vp]
     L.pea_affinity_bwd_dual_ex.restype = ctypes.c_int
     L.pea_affinity_bwd_dual_ex.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pea_affinity_fwd_dual_ex.restype = ctypes.c_int
+    L.pea_affinity_fwd_dual_ex.argtypes = [dp, dp] + [vp] * 14 + [ctypes.c_size_t, vp]
     L.pea_affinity_bwd_dual.restype = ctypes.c_int
     L.pea_affinity_bwd_dual.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pea_scale_inplace.restype = ctypes.c_int

@@ -199,6 +199,57 @@ int pea_affinity_fwd_ex(const PeaDesc* desc, const void* e, const void* e_other,
   return PEA_OK;
 }
 
+int pea_affinity_fwd_dual_ex(const PeaDesc* desc, const PeaDesc* desc_cross, const void* e, const void* ema, const float* target,
+                             const float* weight, const uint8_t* mask, float* affs, float* g_out, float* g_cross_out,
+                             float* inv_norm_out, float* inv_norm_other_out, float* loss_out, float* loss_cross_out, void* workspace,
+                             void* workspace_cross, size_t workspace_bytes, void* stream) {
+  int rc = validate(desc);
+  if (rc) return rc;
+  rc = validate(desc_cross);
+  if (rc) return rc;
+  if (!e || !ema || !target || !weight || !g_out || !g_cross_out || !inv_norm_out || !inv_norm_other_out || !loss_out || !loss_cross_out)
+    return PEA_E_NULL;
+  // one geometry, one stencil, one normaliser: the two descriptors may differ in lambda (affs0_weight of the cross loss) and in the
+  // activation of a map (the cross loss writes none)
+  const PeaDesc &a = *desc, &b = *desc_cross;
+  bool same = a.ndim == b.ndim && a.B == b.B && a.D == b.D && a.K == b.K && a.border == b.border && a.dtype == b.dtype &&
+              a.norm == b.norm && a.eps == b.eps && ((a.flags ^ b.flags) & ~kActMask) == 0 && a.target_bstride == b.target_bstride &&
+              a.weight_bstride == b.weight_bstride && a.mask_bstride == b.mask_bstride;
+  for (int i = 0; same && i < 3; ++i) same = a.dims[i] == b.dims[i];
+  for (int i = 0; same && i < a.K; ++i) same = a.offsets[i][0] == b.offsets[i][0] && a.offsets[i][1] == b.offsets[i][1] && a.offsets[i][2] == b.offsets[i][2];
+  if (!same) return PEA_E_DESC;
+  if (misaligned(e, 4) || misaligned(ema, 4) || misaligned(affs, 4) || misaligned(g_out, 4) || misaligned(g_cross_out, 4) ||
+      misaligned(target, 4) || misaligned(weight, 4) || misaligned(loss_out, 4) || misaligned(loss_cross_out, 4) ||
+      misaligned(workspace, 8) || misaligned(workspace_cross, 8) || misaligned(inv_norm_out, 4) || misaligned(inv_norm_other_out, 4))
+    return PEA_E_ALIGN;
+  if (!workspace || !workspace_cross || workspace == workspace_cross || workspace_bytes < kStateBytes) return PEA_E_WORKSPACE;
+  if (e == ema) return PEA_E_UNSUPPORTED;  // (an aliased second operand is a self loss twice: the two calls handle it)
+  const KParams P = make_params(desc), P2 = make_params(desc_cross);
+  hipStream_t s = (hipStream_t)stream;
+  FwdArgs A = {}, A2 = {};
+  A.e = e; A.eo = e; A.t = target; A.w = weight; A.m = mask; A.affs = affs; A.gout = g_out;
+  A.st = (LossState*)workspace; A.loss_out = loss_out; A.inv_out = inv_norm_out; A.dtype = desc->dtype; A.train = true;
+  A2 = A;
+  A2.eo = ema; A2.affs = nullptr; A2.gout = g_cross_out; A2.st = (LossState*)workspace_cross; A2.loss_out = loss_cross_out;
+  A2.inv_out = inv_norm_other_out;
+  if (!xdma_fwd_dual(P, P2, A, A2, s)) {
+    const int pe = hip_rc();
+    return pe ? pe : PEA_E_UNSUPPORTED;  // nothing was launched: pea_affinity_fwd_ex twice
+  }
+  rc = hip_rc();
+  if (!rc) {
+    launch_loss_finish(P, A.st, A.loss_out, s);
+    launch_loss_finish(P2, A2.st, A2.loss_out, s);
+    rc = hip_rc();
+  }
+  if (rc) {  // (run_fwd: the state blocks must be zero between calls)
+    launch_loss_state_init(A.st, 1, s);
+    launch_loss_state_init(A2.st, 1, s);
+    (void)hipGetLastError();
+  }
+  return rc;
+}
+
 int pea_affinity_fwd(const PeaDesc* desc, const void* e, const void* e_other, const float* target,
                      const float* weight, const uint8_t* mask, float* affs, float* g_out, float* loss_out,
                      void* workspace, size_t workspace_bytes, void* stream) {
@@ -208,6 +259,7 @@ int pea_affinity_fwd(const PeaDesc* desc, const void* e, const void* e_other, co
 int pea_cross_supported(const PeaDesc* desc, int backward) {
   if (validate(desc)) return 0;
   const KParams P = make_params(desc);
+  if (backward == 5) return xdma_fwd_dual_supported(P, desc->dtype) ? 1 : 0;  // does pea_affinity_fwd_dual_ex fuse the pair?
   if (backward == 4) return xdma_cross_supported(P, desc->dtype, 4);  // ... with a detached second operand?
   if (backward == 3) {  // does pea_affinity_bwd_ex2 READ the raw affinity map for this descriptor (self loss)?
     if (zmarch_bwd_supported(P, desc->dtype)) return 1;

@@ -49,6 +49,8 @@ struct Env {
                       //   asks for first, and the next forward starts where the backward ended (-1.7 % / -0.8 %, profiles/r5_switch1.txt)
   int bwd_w3;         // PEA_BWD_W3=1: the D = 16 self-loss backward on three workgroups per CU (pea_xdma_w3.h)
   int bwd_vec;        // PEA_BWD_VEC=1: k_bwd_xdma's 16-byte g loads / stores instantiation
+  int fwd_dual;       // PEA_FWD_DUAL=0: pea_affinity_fwd_dual_ex reports PEA_E_UNSUPPORTED (the caller runs the two forwards); 2 (default): the
+                      //   one-launch pair on a ring of two four-plane buffers, two workgroups per CU; 3: a ring of three, one workgroup per CU
 };
 const Env& env();
 void env_reload();          // pea_reload_env(): tests that change a switch call it
@@ -166,6 +168,11 @@ bool xdma_bwd_other(const KParams& P, const float* e, const float* e_other, cons
                     const float* dl, float* de, bool accumulate, hipStream_t s);  // affs: the raw cosine map or null (read at D > 16)
 bool xdma_pf_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* affs,
                        const float* dl, float* de, hipStream_t s);  // D = 32 / 64, projection first (pea_k_xdma_h.hip)
+// the full-resolution pair (self loss + detached-EMA cross loss on the same target / weight / mask) as ONE forward launch
+// (pea_xdma_dual.h): A = the self loss' arguments (affs, gout, st, inv_out: the own plane), A2 = the cross loss' (eo = ema, gout,
+// st, inv_out: the second operand's plane); P2 differs from P in lambda only.  true = launched.
+bool xdma_fwd_dual_supported(const KParams& P, int dtype);
+bool xdma_fwd_dual(const KParams& P, const KParams& P2, const FwdArgs& A, const FwdArgs& A2, hipStream_t s);
 bool xdma_bwd_dual(const KParams& P, const float* e, const float* ema, const float* inv, const float* inv_other, const float* g,
                    const float* g_cross, const float* dl, const float* dl_cross, float* de, hipStream_t s);
 bool tiled_bwd(const KParams& P, int dtype, int roles, const void* x, const void* nbA, const void* nbB, const float* g,

@@ -2,6 +2,7 @@
 // One translation unit of libpea_hip.so (pea_host.h).
 #include "pea_k_xdma_plan.h"
 #include "pea_xdma_w3.h"
+#include "pea_xdma_dual.h"
 
 namespace pea {
 
@@ -117,6 +118,42 @@ bool xdma_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s) {
   if (P.D == 32) return fwd_self<32, true>(P, A, s);
   if (P.D == 64) return fwd_self<64, true>(P, A, s);
   return false;
+}
+
+// the full-resolution pair of the 2D training loops as one forward launch (pea_xdma_dual.h): 2D, D = 16, f32, axis-aligned stencil
+bool xdma_fwd_dual_supported(const KParams& P, int dtype) {
+  if (!env().fwd_dual || !env().fwd_xdma || env().force_direct || dtype != PEA_F32 || P.D != 16 || P.Z != 1 || P.K > kXP) return false;
+  XPlan X;
+  return plan(P, kXdmaPSUF, 1, &X) && X.C.nfz == 0;
+}
+
+bool xdma_fwd_dual(const KParams& P, const KParams& P2, const FwdArgs& A, const FwdArgs& A2, hipStream_t s) {
+  if (!xdma_fwd_dual_supported(P, A.dtype) || !A.gout || !A2.gout || !A.inv_out || !A2.inv_out) return false;
+  const float *e = (const float*)A.e, *e2 = (const float*)A2.eo;
+  if (misaligned(e, 16) || misaligned(e2, 16) || misaligned(A.t, 16) || misaligned(A.w, 16) || misaligned(A.affs, 16) ||
+      misaligned(A.gout, 16) || misaligned(A2.gout, 16) || misaligned(A.m, 4) || misaligned(A.inv_out, 4) || misaligned(A2.inv_out, 4))
+    return false;
+  if ((P.tbs | P.wbs | P.mbs) & 3) return false;
+  XPlan X;
+  if (!plan(P, kXdmaPSUF, 1, &X) || X.C.nfz > 0) return false;
+  DualFwdArgs DA = {};
+  DA.e2 = e2; DA.gout2 = A2.gout; DA.inv_other_out = A2.inv_out; DA.st2 = A2.st;
+  for (int i = 0; i < kXK; ++i) DA.gs2[i] = i < P2.K ? P2.gscale[i] : 0.f;
+  const dim3 grid((unsigned)(X.C.tiles_per_xcd * kXcd)), blk(kXdmaTH * kXdmaTW);
+  const bool crop = P.border != PEA_BORDER_CIRCULAR;
+#define PEA_XFD(CROP_, NB_)                                                                            \
+  {                                                                                                    \
+    constexpr auto kern = k_fwd_xdma_dual<kXdmaTH, kXdmaTW, kXdmaPSUF, CROP_, NB_>;                    \
+    const size_t lds = (size_t)NB_ * 4 * kXdmaPSUF * 256;                                              \
+    PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out, DA) \
+  }
+  if (env().fwd_dual == 3) {
+    if (crop) PEA_XFD(true, 3) else PEA_XFD(false, 3)
+  } else {
+    if (crop) PEA_XFD(true, 2) else PEA_XFD(false, 2)
+  }
+#undef PEA_XFD
+  return true;
 }
 
 // the cross loss with a second operand: D = 16, f32, axis-aligned stencil; 2D images (either border) and 3D volumes whose stencil

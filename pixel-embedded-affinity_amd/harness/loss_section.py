@@ -120,6 +120,46 @@ class _TensorSection(torch.autograd.Function):
                                                  op._stream()), "pea_affinity_fwd_ex")
                 return d, g, affs, inv, (affs if raw_ok else None)
 
+            def forward_pair(e_c, o_c):
+                """the full-resolution self loss (0) and cross loss (ncall - 1) as one forward launch where the library fuses the pair
+                (2D, D = 16, f32, axis-aligned stencil: csrc/pea_xdma_dual.h) -> (d0, dx, g0, gx, pred, the two 1 / norm planes) or None"""
+                jx = ncall - 1
+                spec0, specx = specs[0], specs[jx]
+                if specx.act:  # the cross loss' map is not written
+                    specx = copy.copy(specx)
+                    specx.act = 0
+                if spec0.K != specx.K or o_c.data_ptr() == e_c.data_ptr():
+                    return None
+                kshape = op._affs_shape(e_c, spec0.K)
+                t, w, m = tensors[0]
+                t, ts = op._batch_strided(t, "target", torch.float32, kshape)
+                w, ws = op._batch_strided(w, "weightmap", torch.float32, kshape)
+                ms = 0
+                if m is not None:
+                    if m.dtype == torch.bool:
+                        m = m.view(torch.uint8)
+                    elif m.dtype != torch.uint8:
+                        m = m.to(torch.uint8)
+                    m, ms = op._batch_strided(m, "mask", torch.uint8, kshape)
+                d0 = op.make_desc(spec0, e_c, ts, ws, ms)
+                if not op.cross_supported(d0, 5):
+                    return None
+                dx = op.make_desc(specx, e_c, ts, ws, ms)
+                work, wsb = op.workspace(dev, d0, 2)
+                half = wsb // 2
+                g0 = torch.empty(kshape, dtype=torch.float32, device=dev)
+                gx = torch.empty(kshape, dtype=torch.float32, device=dev)
+                affs = torch.empty(kshape, dtype=torch.float32, device=dev)
+                inv = torch.empty((2, e_c.shape[0]) + tuple(e_c.shape[2:]), dtype=torch.float32, device=dev)
+                rc = L.pea_affinity_fwd_dual_ex(ctypes.byref(d0), ctypes.byref(dx), op._ptr(e_c), op._ptr(o_c), op._ptr(t), op._ptr(w), op._ptr(m),
+                                                op._ptr(affs), op._ptr(g0), op._ptr(gx), op._ptr(inv[0]), op._ptr(inv[1]), op._ptr(rows[0]),
+                                                op._ptr(rows[jx]), ctypes.c_void_p(work.data_ptr()), ctypes.c_void_p(work.data_ptr() + half), half,
+                                                op._stream())
+                if rc == _lib.E_UNSUPPORTED:  # (nothing was launched)
+                    return None
+                _lib.check(rc, "pea_affinity_fwd_dual_ex")
+                return d0, dx, g0, gx, affs, inv
+
             def backward_one(j, d, e_c, o_c, g, inv=None, de=None, raw=None):
                 """raw: the forward's map, untouched (the backward runs inside this node's forward, before `pred` is handed out)"""
                 de = torch.empty_like(e_c) if de is None else de
@@ -145,11 +185,17 @@ class _TensorSection(torch.autograd.Function):
                     small.append(backward_one(j, d, e_c, None, g, inv, raw=raw))
             e0 = op._embedding_arg(embs[0], "embedding")
             ema_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e0.dtype)
-            d0, g0, pred, inv0, raw0 = forward_one(0, e0, None, True, 1)
-            dxx, gx, _, invx, rawx = forward_one(jx, e0, ema_c, False, 2 if inv0 is not None else 0)
+            pair = forward_pair(e0, ema_c)
+            if pair is not None:  # one forward launch for the two losses (pea_affinity_fwd_dual_ex: e, target, weight, mask read once)
+                d0, dxx, g0, gx, pred, invx = pair  # invx: the two planes (own, second operand's) as the cross forward writes them
+                inv0, inv_other, raw0, rawx = invx[0], invx[1], None, None
+            else:
+                d0, g0, pred, inv0, raw0 = forward_one(0, e0, None, True, 1)
+                dxx, gx, _, invx, rawx = forward_one(jx, e0, ema_c, False, 2 if inv0 is not None else 0)
+                inv_other = None if invx is None else invx[1]
             de0 = torch.empty_like(e0)
             rc = L.pea_affinity_bwd_dual_ex(ctypes.byref(d0), op._ptr(e0), op._ptr(ema_c), op._ptr(g0), op._ptr(gx), op._ptr(inv0),
-                                            op._ptr(None if invx is None else invx[1]), op._ptr(wdev[0:1]), op._ptr(wdev[jx:jx + 1]),
+                                            op._ptr(inv_other), op._ptr(wdev[0:1]), op._ptr(wdev[jx:jx + 1]),
                                             op._ptr(de0), op._stream())
             if rc == _lib.E_UNSUPPORTED:
                 de0 = backward_one(0, d0, e0, None, g0, inv0, raw=raw0)

@@ -11,7 +11,7 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -o r -- python3 $ROOT/profiles/one_kernel.py $WHICH 4 > $OUT/g$i.log 2>&1 || echo "group $i failed: $grp"
+  timeout -k 5 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -o r -- python3 $ROOT/profiles/one_kernel.py $WHICH 4 > $OUT/g$i.log 2>&1 || echo "group $i failed: $grp"
 done
 python3 - $OUT <<'PY' | tee $OUT/summary.txt
 import csv, glob, os, sys

@@ -24,7 +24,7 @@ def lib(pkg):
 def test_header_declares_the_expected_entry_points():
     assert declared_symbols() == sorted(["pea_version", "pea_strerror", "pea_desc_validate", "pea_workspace_bytes", "pea_workspace_init", "pea_reload_env",
                                          "pea_affinity_infer", "pea_affinity_fwd", "pea_affinity_bwd", "pea_affinity_fwd_ex", "pea_affinity_bwd_ex", "pea_affinity_bwd_ex2",
-                                         "pea_inv_norm", "pea_cross_supported", "pea_affinity_bwd_dual", "pea_affinity_bwd_dual_ex",
+                                         "pea_inv_norm", "pea_cross_supported", "pea_affinity_bwd_dual", "pea_affinity_bwd_dual_ex", "pea_affinity_fwd_dual_ex",
                                          "pea_scale_inplace", "pea_scale_inplace_multi", "pea_weighted_sum", "pea_fill_border_relu",
                                          "pea_targets_workspace_bytes", "pea_gen_targets",
                                          "pea_stitch_add", "pea_stitch_finalize", "pea_label_weights",

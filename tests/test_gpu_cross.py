@@ -489,6 +489,71 @@ def test_pair_backward_in_one_cross_launch(pkg, dev, orc, synth, shape, shifts):
         assert relmax(de_t.cpu().numpy(), ref) < GRAD_RTOL and relmax(de_c.cpu().numpy(), de_t.cpu().numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("shape,shifts,K,border,relu,nb", [((2, 50, 100), [1, 3, 5, 9, 27], 10, 0, True, "3"), ((2, 50, 100), [1, 3, 5, 9, 27], 10, 0, False, "2"),
+                                                        ((1, 43, 96), [1, 3, 5, 9, 27], 10, 0, False, "3"), ((3, 64, 128), [1, 3, 5, 9, 27], 10, 1, False, "3"),
+                                                        ((3, 64, 128), [1, 3, 5, 9, 27], 10, 1, True, "2"), ((2, 37, 72), [1, 3, 5, 9, 11], 8, 0, False, "3"),
+                                                        ((1, 96, 200), [1, 3, 5, 9, 27], 9, 0, False, "2"), ((2, 33, 68), [1], 2, 0, False, "3")])
+def test_dual_forward_equals_the_two_launches(pkg, dev, orc, synth, monkeypatch, shape, shifts, K, border, relu, nb):
+    """pea_affinity_fwd_dual_ex (csrc/pea_xdma_dual.h): the self loss and the detached-EMA cross loss of the same embedding on the
+    same target / weight / mask as ONE forward launch -- every output BIT-identical to the two pea_affinity_fwd_ex calls it replaces
+    (map, both g maps, both 1 / norm planes, both loss rows), for both ring depths, both borders, with and without the relu of the
+    self map; the loss rows also against the oracle, and the state blocks left ready for the next call."""
+    monkeypatch.setenv("PEA_FWD_DUAL", nb)
+    pkg._lib.reload_env()
+    try:
+        B, H, W = shape
+        D = 16
+        offsets = pkg.multi_offset(shifts, 4)[:K]
+        lamx = [3.0, 3.0] + [1.0] * (K - 2)
+        e, t, w, m = _inputs(synth, B, D, [1, H, W], K, 29, zero_px=True)
+        e, t, w, m = e[:, :, 0], t[:, :, 0], w[:, :, 0], m[:, :, 0]
+        eo = synth.synth_embedding((B, D, H * W), 979).reshape(B, D, H, W)
+        eo[0, :, 4, 6] = 0.0
+        op, L = pkg.affinity_op, pkg._lib.lib()
+        E, EO, T, Wt, M = cu(e, dev), cu(eo, dev), cu(t, dev), cu(w, dev), cu(m, dev)
+        norm = pkg._lib.NORM_BX if border == 0 else pkg._lib.NORM_CROPPED
+        d0 = op.make_desc(op.AffinitySpec(2, offsets, None, border, norm, relu=relu), E)
+        dx = op.make_desc(op.AffinitySpec(2, offsets, lamx, border, norm), E)
+        assert L.pea_cross_supported(ctypes.byref(d0), 5) == 1
+        P = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        wsb = L.pea_workspace_bytes(ctypes.byref(d0))
+        work = torch.empty(2, max(wsb, 8) // 4, device=dev)
+        assert L.pea_workspace_init(P(work), 2 * wsb, None) == 0
+        # the two launches
+        affs, g0, gx = (torch.full((B, K, H, W), 7.0, device=dev) for _ in range(3))
+        inv0, inv2 = torch.empty(B, H, W, device=dev), torch.empty(2, B, H, W, device=dev)
+        l0, lx = torch.empty(1 + K, device=dev), torch.empty(1 + K, device=dev)
+        assert L.pea_affinity_fwd_ex(ctypes.byref(d0), P(E), None, P(T), P(Wt), P(M), P(affs), P(g0), P(inv0), P(l0), P(work[0]), wsb, st) == 0
+        assert L.pea_affinity_fwd_ex(ctypes.byref(dx), P(E), P(EO), P(T), P(Wt), P(M), None, P(gx), P(inv2), P(lx), P(work[1]), wsb, st) == 0
+        # the one launch, twice (the second call finds the state blocks as the first left them)
+        for rep in range(2):
+            affs_d, g0_d, gx_d = (torch.full((B, K, H, W), -3.0, device=dev) for _ in range(3))
+            inv0_d, invo_d = torch.empty(B, H, W, device=dev), torch.empty(B, H, W, device=dev)
+            l0_d, lx_d = torch.empty(1 + K, device=dev), torch.empty(1 + K, device=dev)
+            rc = L.pea_affinity_fwd_dual_ex(ctypes.byref(d0), ctypes.byref(dx), P(E), P(EO), P(T), P(Wt), P(M), P(affs_d), P(g0_d), P(gx_d),
+                                            P(inv0_d), P(invo_d), P(l0_d), P(lx_d), P(work[0]), P(work[1]), wsb, st)
+            assert rc == 0
+            torch.cuda.synchronize()
+            for name, a, b in (("affs", affs_d, affs), ("g", g0_d, g0), ("g_cross", gx_d, gx), ("inv", inv0_d, inv0), ("inv_own_of_pair", inv0_d, inv2[0]),
+                               ("inv_other", invo_d, inv2[1]), ("loss", l0_d, l0), ("loss_cross", lx_d, lx)):
+                assert torch.equal(a, b), (name, rep)
+        offs3 = [[0] + list(o) for o in offsets]
+        o_loss = orc.c_fwd(orc.make_desc(B, D, [1, H, W], offs3, None, border, norm, ndim=3), e[:, :, None], None, t[:, :, None], w[:, :, None], m[:, :, None], want_affs=False)[1][0]
+        o_lossx = orc.c_fwd(orc.make_desc(B, D, [1, H, W], offs3, lamx, border, norm, ndim=3), e[:, :, None], eo[:, :, None], t[:, :, None], w[:, :, None], m[:, :, None],
+                            want_affs=False)[1][0]
+        assert abs(l0_d[0].item() - o_loss) <= LOSS_RTOL * abs(o_loss) and abs(lx_d[0].item() - o_lossx) <= LOSS_RTOL * abs(o_lossx)
+        # descriptors that disagree in more than lambda / activation are refused, and so is the same state block twice
+        dbad = op.make_desc(op.AffinitySpec(2, offsets, lamx, 1 - border, norm), E)
+        assert L.pea_affinity_fwd_dual_ex(ctypes.byref(d0), ctypes.byref(dbad), P(E), P(EO), P(T), P(Wt), P(M), P(affs_d), P(g0_d), P(gx_d),
+                                          P(inv0_d), P(invo_d), P(l0_d), P(lx_d), P(work[0]), P(work[1]), wsb, st) == -2
+        assert L.pea_affinity_fwd_dual_ex(ctypes.byref(d0), ctypes.byref(dx), P(E), P(EO), P(T), P(Wt), P(M), P(affs_d), P(g0_d), P(gx_d),
+                                          P(inv0_d), P(invo_d), P(l0_d), P(lx_d), P(work[0]), P(work[0]), wsb, st) == -4
+    finally:
+        monkeypatch.delenv("PEA_FWD_DUAL")
+        pkg._lib.reload_env()
+
+
 def test_second_operand_that_aliases_the_first(pkg, dev, orc, synth):
     """ema_embedding_loss(e, e.detach(), ..) -- an EMA tensor that IS the embedding's storage: the forward has the values of the self
     loss, the backward is role A only (the second operand is detached).  Round 2 took the self path in the forward (one 1 / norm
