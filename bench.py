@@ -493,7 +493,7 @@ def in_step_batches_ms(fwd, bwd, iters, nb=N_BATCHES):
 # the roofline's traffic field.)
 KERNEL_SWITCHES = ("PEA_FORCE_DIRECT", "PEA_FWD_XDMA", "PEA_BWD_XDMA", "PEA_LABELS_DUAL", "PEA_FWD_WG3", "PEA_INFER_XDMA", "PEA_BWD_PF", "PEA_BOX",
                    "PEA_H16_HW", "PEA_ZMARCH", "PEA_ZSEG", "PEA_ZM_NB", "PEA_BOXM", "PEA_XCD_STAGGER", "PEA_SKEW", "PEA_SKEW_SLOTS", "PEA_SKEW_MODE",
-                   "PEA_WALK2D", "PEA_LDS_PAD", "PEA_ZBLK_Y", "PEA_ZBLK_X", "PEA_BWD_REV", "PEA_BWD_W3", "PEA_BWD_VEC", "PEA_HIP_LIB")
+                   "PEA_WALK2D", "PEA_LDS_PAD", "PEA_ZBLK_Y", "PEA_ZBLK_X", "PEA_BWD_REV", "PEA_BWD_W3", "PEA_BWD_VEC", "PEA_FWD_DUAL", "PEA_HIP_LIB")
 
 
 def pmc_traffic(key, dom):
