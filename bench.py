@@ -61,6 +61,11 @@ CONFIGS = {
                   dims=(704, 704), shifts=[1, 3, 5, 9, 11], K=10, f16=False, ema=True),
     "c4ema": dict(what="BASELINE configs[3], the EMA cross loss: ema_embedding_loss_norm5 fwd+bwd (second operand detached), one 24x1024x1024 sub-volume",
                   ndim=3, B=1, D=16, dims=(24, 1024, 1024), stencil="norm5", K=12, f16=False, ema=True),
+    # embedding_loss_norm6 (scripts_ac3ac4/loss/loss_embedding_mse.py:346-354): generic 3D offsets with a REPLICATE
+    # border -- the reference's 17-offset table shift_func(17) (utils/shift_channels.py:25-34: diagonals, reach 27).  No shipped yaml selects
+    # it; it runs on the global-memory kernels (no LDS kernel takes a clamped border), and this line says what that costs
+    "c4r6": dict(what="AC3/AC4 sub-volume 24x1024x1024, embedding_loss_norm6 with the reference's shift_func(17) table (REPLICATE border, one normaliser)",
+                 ndim=3, B=1, D=16, dims=(24, 1024, 1024), stencil="norm6_17", K=17, f16=False),
     "c5ema": dict(what="BASELINE configs[4], the EMA cross loss: ema_embedding_loss fwd+bwd (second operand detached), f16 storage", ndim=2, B=8, D=64,
                   dims=(544, 544), shifts=[1, 3, 5, 9, 27], K=8, f16=True, ema=True),
 }
@@ -163,9 +168,15 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
     else:
         if c["stencil"] == "norm5":
             offsets = pkg.utils.affinity_ours.axis_offsets_3d(pkg.utils.affinity_ours.NORM5_SHIFTS)
+        elif c["stencil"] == "norm6_17":  # shift_func(17), scripts_ac3ac4/utils/shift_channels.py:25-34
+            offsets = [[-1, 0, 0], [0, -1, 0], [0, 0, -1], [-1, -1, -1], [-1, 1, 1], [-1, -1, 1], [-1, 1, -1], [0, -9, 0], [0, 0, -9],
+                       [0, -9, -9], [0, 9, -9], [0, -9, -4], [0, -4, -9], [0, 4, -9], [0, 9, -4], [0, -27, 0], [0, 0, -27]]
         else:
             offsets = [[dz, dy, dx] for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dz, dy, dx) != (0, 0, 0)]
-        spec = op.AffinitySpec(3, offsets, None, pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
+        if c["stencil"] == "norm6_17":
+            spec = op.AffinitySpec(3, offsets, None, pkg._lib.BORDER_REPLICATE, pkg._lib.NORM_FULL)
+        else:
+            spec = op.AffinitySpec(3, offsets, None, pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
 
     def step():
         E.grad = None
@@ -243,10 +254,13 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
                                                what="the image" if B == 1 else "1 image of the batch",
                                                ema=None if E2 is None else E2[:1].float().cpu())
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["best_cpu_value"], 1)  # vs the faster CPU line
-        elif c["stencil"] == "n26":
+        elif c["stencil"] in ("n26", "norm6_17"):
             sl = (slice(0, 1), slice(None), slice(None), slice(0, 256), slice(0, 256))
+            rep = c["stencil"] == "norm6_17"
             out["cpu_baseline"] = cpu_baseline_generic3d(offsets, Ed[sl].float().cpu().contiguous(), T[sl].cpu().contiguous(), Wt[sl].cpu().contiguous(),
-                                                         what="a 24x256x256 block of the sub-volume with the 26-neighbourhood (K=26)")
+                                                         what="a 24x256x256 block of the sub-volume with " +
+                                                         ("the shift_func(17) table, replicate border (K=17)" if rep else "the 26-neighbourhood (K=26)"),
+                                                         replicate=rep)
         else:
             sl = (slice(0, 1), slice(None), slice(None), slice(0, 256), slice(0, 256))
             out["cpu_baseline"] = cpu_baseline(None, Ed[sl].float().cpu().contiguous(), T[:, :12][sl].cpu().contiguous(), Wt[:, :12][sl].cpu().contiguous(),
@@ -416,14 +430,15 @@ def graphed_api_ms(pkg, op, E, E2, T, Wt, M, spec, iters):
         return None
 
 
-def cpu_baseline_generic3d(offsets, e, t, w, what):
+def cpu_baseline_generic3d(offsets, e, t, w, what, replicate=False):
     """a 3D stencil the torch restatement has no op sequence for (the 26-neighbourhood): the oracle's C restatement with OpenMP over
     the host cores on a bounded block, CROP_ZERO border and cropped normaliser like the GPU line it sits beside"""
     orc = ge.load_oracle()
     cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     en, tn, wn = (np.ascontiguousarray(x.numpy()) for x in (e, t, w))
     B, Dm = en.shape[:2]
-    d = orc.make_desc(B, Dm, list(en.shape[2:]), [list(o) for o in offsets], None, orc.BORDER_CROP_ZERO, orc.NORM_CROPPED, 1e-12, 0, ndim=3)
+    brd, nrm = (orc.BORDER_REPLICATE, orc.NORM_FULL) if replicate else (orc.BORDER_CROP_ZERO, orc.NORM_CROPPED)
+    d = orc.make_desc(B, Dm, list(en.shape[2:]), [list(o) for o in offsets], None, brd, nrm, 1e-12, 0, ndim=3)
 
     def once():
         t0 = time.perf_counter()
@@ -437,7 +452,7 @@ def cpu_baseline_generic3d(offsets, e, t, w, what):
     orc.c_set_threads(1)
     sub = (slice(0, 1), slice(None), slice(None), slice(0, 64), slice(0, 64))
     e1, t1, w1 = (np.ascontiguousarray(x[sub]) for x in (en, tn, wn))
-    d1 = orc.make_desc(1, Dm, list(e1.shape[2:]), [list(o) for o in offsets], None, orc.BORDER_CROP_ZERO, orc.NORM_CROPPED, 1e-12, 0, ndim=3)
+    d1 = orc.make_desc(1, Dm, list(e1.shape[2:]), [list(o) for o in offsets], None, brd, nrm, 1e-12, 0, ndim=3)
     t0 = time.perf_counter()
     orc.c_fwd(d1, e1, None, t1, w1, None)
     orc.c_bwd(d1, e1, None, t1, w1, None)

@@ -152,11 +152,13 @@ def _section_inputs(pkg, dev, synth):
     return offsets, nb_half, labs, embs, ema, tt, ww, mm, downs, small
 
 
-def test_full_size_loss_sections(pkg, dev, orc, synth):
+def test_full_size_loss_sections(pkg, dev, orc, synth, monkeypatch):
     """the training loop's loss section (scripts_cvppp/main.py:284-310) at B = 8 x 544^2: the one-node tensor path (its full-resolution
     pair's backward is ONE launch, k_bwd_xdma<.., DUAL>) and the labels-in section (k_fwd_xdma<.., LAB>, k_fused_labels_dual for the
     pair where it applies): bit-identical reruns of every output; the full-resolution gradient and map in a window against the oracle
-    (self + cross); the two small scales that the oracle finishes in seconds in full; the two sections against each other"""
+    (self + cross); the two small scales that the oracle finishes in seconds in full; the two sections against each other.  The tensor
+    section's full-resolution pair runs its FORWARD as one launch too (k_fwd_xdma_dual, pea_affinity_fwd_dual_ex): the same section
+    with PEA_FWD_DUAL=0 (two forward launches) must give every output bit for bit, and so must the ring-of-three instantiation"""
     offsets, nb_half, labs, embs, ema, tt, ww, mm, downs, small = _section_inputs(pkg, dev, synth)
     crit = pkg.WeightedMSE()
     K = len(offsets)
@@ -179,6 +181,17 @@ def test_full_size_loss_sections(pkg, dev, orc, synth):
             assert torch.equal(a, b), which
         res[which] = (l1, p1, g1)
     l, pred, grads = res["one_node"]
+    for sw in ("0", "3"):  # two forward launches / the ring of three buffers: the same bits as the default one launch on a ring of two
+        monkeypatch.setenv("PEA_FWD_DUAL", sw)
+        pkg._lib.reload_env()
+        try:
+            l0, p0, g0 = run("one_node")
+        finally:
+            monkeypatch.delenv("PEA_FWD_DUAL")
+            pkg._lib.reload_env()
+        assert torch.equal(l0, l) and torch.equal(p0, pred), sw
+        for a, b in zip(g0, grads):
+            assert torch.equal(a, b), sw
     # full resolution: d section / d embedding = 0.5 * (self gradient + cross gradient), all loss weights 1; affs0_weight 1
     reach, hh, wd = max(SHIFTS), 96, 128
     inner = (slice(None), slice(reach, hh - reach), slice(reach, wd - reach))
