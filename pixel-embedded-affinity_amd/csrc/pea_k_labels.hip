@@ -18,6 +18,7 @@ template <typename T, int D_T, bool RB>
 bool try_fused_labels(const KParams& P, const T* x, const T* nb, const int32_t* labels, const float* wtab, unsigned lflags,
                       float* affs, LossState* st, const float* dl, T* dx, hipStream_t s) {
   constexpr TileCfg c = bwd_cfg<D_T>(0);
+  if (P.border == PEA_BORDER_REPLICATE) return false;  // (the labels-in kernels test, they do not clamp)
   TParams Q;
   if (!plan_tiles_cached(P, c, RB, &Q)) return false;
   const size_t lds = Lds<D_T, c.PLQ>::kBytes + (size_t)(c.TH * c.TW / 64) * P.K * sizeof(float);
@@ -41,6 +42,7 @@ bool try_fused_labels_dual(const KParams& P, const KParams& P2, const T* x, cons
                            hipStream_t s) {
   constexpr TileCfg c = bwd_cfg<D_T>(0);
   TParams Q, Q2;
+  if (P.border == PEA_BORDER_REPLICATE) return false;
   if (!plan_tiles_cached(P, c, true, &Q) || !plan_tiles_cached(P2, c, false, &Q2)) return false;
   if (Q.n_near > kDualNear || Q2.n_near != Q.n_near || Q2.n_far != Q.n_far || Q2.ntiles != Q.ntiles) return false;
   CrossPar C2 = {};

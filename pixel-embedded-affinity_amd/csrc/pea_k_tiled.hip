@@ -1,6 +1,8 @@
 // pea_k_tiled.hip -- launchers of the LDS-tiled box kernels (pea_tiled.h) and of the channel-chunked forward (pea_chunked.h):
 // what runs where the cross kernels do not apply (diagonal / mixed-sign stencils, f16 storage, a second operand with both
 // gradients, inference).  One translation unit of libpea_hip.so (pea_host.h).
+#include <type_traits>
+
 #include "pea_plan.h"
 #include "pea_chunked.h"
 
@@ -13,6 +15,11 @@ namespace {
     if (allow_lds<kern>(lds)) return false;                   \
     hipLaunchKernelGGL(kern, grid, blk, lds, s, __VA_ARGS__); \
   }
+
+// REPLICATE tables are generic (embedding_loss_norm6: diagonals, z steps, reach 27): where the forward's one-sided region serves fewer
+// than half of the offsets from LDS the global-memory forward is faster (shift_func(17) at 24 x 1024^2: 2 near of 17, 4.06 against
+// 3.80 ms); the backward's larger two-sided region (8 near of 17) wins (4.73 against 6.20 ms) -- profiles/r5_c4r6_*.json
+inline bool rep_mostly_far(const KParams& P, const TParams& Q) { return P.border == PEA_BORDER_REPLICATE && 2 * Q.n_near < P.K; }
 
 struct FwdT {  // typed view of FwdArgs
   const void *e, *eo;
@@ -28,6 +35,7 @@ struct FwdT {  // typed view of FwdArgs
 template <typename T, int D_T, bool TRAIN>
 bool try_fwd_v(const KParams& P, const FwdT& A, float* inv_out, hipStream_t s) {
   if (P.K > kKV || P.X % 4) return false;
+  if (P.border == PEA_BORDER_REPLICATE && !(std::is_same<T, float>::value && D_T == 16)) return false;
   if (misaligned(A.t, 16) || misaligned(A.w, 16) || misaligned(A.affs, 16) || misaligned(A.gout, 16) || misaligned(A.m, 4)) return false;
   if ((P.tbs | P.wbs | P.mbs | (long long)P.S) & 3) return false;
   constexpr TileCfg c = fwdv_cfg<D_T>();
@@ -38,6 +46,7 @@ bool try_fwd_v(const KParams& P, const FwdT& A, float* inv_out, hipStream_t s) {
   if (lds > (size_t)kLdsMax) return false;
   TParams Q;
   if (!plan_tiles_cached(P, c, false, &Q) || Q.n_near > kKV || Q.n_far > kFV) return false;
+  if (rep_mostly_far(P, Q)) return false;
   const T *e = (const T*)A.e, *eo = (const T*)A.eo;
   const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(c.TH * c.TW);
 #define PEA_FV(CROP_, SELF_)                                                                                  \
@@ -56,8 +65,9 @@ template <typename T, int D_T, bool TRAIN>
 bool try_fwd_tiled(const KParams& P, const FwdT& A, float* inv_out, hipStream_t s) {
   constexpr TileCfg c = fwd_cfg<D_T>(0);
   constexpr int NT = c.TH * c.TW;
+  if (P.border == PEA_BORDER_REPLICATE && !(std::is_same<T, float>::value && D_T == 16)) return false;
   TParams Q;
-  if (!plan_tiles_cached(P, c, false, &Q, true)) return false;
+  if (!plan_tiles_cached(P, c, false, &Q, true) || rep_mostly_far(P, Q)) return false;
   const size_t lds = Lds<D_T, c.PLQ>::kBytes + (TRAIN ? (size_t)(NT / 64) * P.K * sizeof(float) : 0);
   const T *e = (const T*)A.e, *eo = (const T*)A.eo;
   const dim3 grid((unsigned)(Q.tiles_per_xcd * kXcd)), blk(NT);
@@ -78,7 +88,7 @@ bool try_fwd_tiled(const KParams& P, const FwdT& A, float* inv_out, hipStream_t 
 // training forward 255 -> 237 us at B=8 x 32 x 544^2)
 template <typename T, int D_T, int DC, bool TRAIN>
 bool try_fwd_chunked(const KParams& P, const FwdT& A, hipStream_t s) {
-  if (P.D != D_T) return false;
+  if (P.D != D_T || P.border == PEA_BORDER_REPLICATE) return false;
   constexpr TileCfg c = kCfg32;  // 16 x 32 tile, 1041 region pixels: 128 B (DC = 32) or 64 B (DC = 16) of LDS each
   TParams Q;
   if (!plan_tiles_cached(P, c, false, &Q) || Q.n_near > kChN || Q.n_far > kChF) return false;
@@ -128,6 +138,7 @@ bool fwd_any(const KParams& P, const FwdT& A, hipStream_t s, bool* wrote_inv) {
 template <typename T, int D_T, bool RA, bool RB>
 bool try_bwd_tiled(const KParams& P, const T* x, const T* nb, const float* g, const float* dl, T* dx, hipStream_t s) {
   constexpr TileCfg c = bwd_cfg<D_T>(0);
+  if (P.border == PEA_BORDER_REPLICATE && !(std::is_same<T, float>::value && D_T == 16)) return false;
   TParams Q;
   // role A alone (a detached second operand's cross loss) reaches only p + o: a one-sided halo; role B needs p - o
   if (!plan_tiles_cached(P, c, !(RA && !RB), &Q, true)) return false;

@@ -28,7 +28,7 @@ constexpr int kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup ma
 // Choose the "near" offsets (served from LDS): the largest in-plane radius whose halo'd region still fits the
 // LDS planes of this tile shape.  both_sides: the backward needs p - o as well as p + o.
 inline bool plan_tiles(const KParams& P, TileCfg c, bool both_sides, TParams* Q, bool ksplit_ok = false) {
-  if (P.border == PEA_BORDER_REPLICATE) return false;  // direct kernels only (row a-15: an unused variant of the reference)
+  // (PEA_BORDER_REPLICATE: the callers decide -- k_fwd_tiled / k_fwd_tiled_v / k_bwd_tiled take it at f32, D = 16: pea_k_tiled.hip)
   if ((long long)P.Y * P.X >= (1LL << 29)) return false;                     // plane byte offsets stay below 2^31 (kOOB)
   // A raw buffer access is in range iff voffset < num_records - soffset (gfx9 range check: the scalar offset COUNTS), and the
   // kernels select the channel / offset plane with soffset under num_records = 2^31: the [D or K, Z, Y, X] block of one batch

@@ -170,6 +170,19 @@ __device__ __forceinline__ int wrap1(int v, int n, bool& ok) {
   return v;
 }
 
+// PEA_BORDER_REPLICATE (embedding_loss_norm6, scripts_ac3ac4/loss/loss_embedding_mse.py:294-354) rides on the CROP instantiations:
+// rep (wave-uniform: P.border == PEA_BORDER_REPLICATE) CLAMPS the index into the volume instead of testing it -- every neighbour
+// exists.  f32, D = 16 only (pea_k_tiled.hip); the role-B side of the backward keeps the test and adds the border pixels' extra
+// pre-images afterwards (k_bwd_tiled).
+template <bool CROP>
+__device__ __forceinline__ int wrap1r(int v, int n, bool& ok, bool rep) {
+  if (CROP && rep) {
+    ok = true;
+    return min(max(v, 0), n - 1);
+  }
+  return wrap1<CROP>(v, n, ok);
+}
+
 // stage the normalised region of batch item `eb`, plane byte offset `zo`, into LDS.
 // WINV (training forward, self loss): the lane that stages one of the tile's OWN pixels also writes its signed 1 / norm
 // (negative where |e| < eps: the clamp branch of F.normalize) to the plane the cross backward (pea_xdma.h) reads;
@@ -184,8 +197,8 @@ __device__ __forceinline__ void stage_region_impl(const KParams& P, const TParam
 #pragma unroll 2
   for (; idx < Q.R; idx += NT) {
     bool oky, okx;
-    const int gy = wrap1<CROP>(y0 - Q.hy0 + r, P.Y, oky);
-    const int gx = wrap1<CROP>(x0 - Q.hx0 + c, P.X, okx);
+    const int gy = wrap1r<CROP>(y0 - Q.hy0 + r, P.Y, oky, P.border == PEA_BORDER_REPLICATE);
+    const int gx = wrap1r<CROP>(x0 - Q.hx0 + c, P.X, okx, P.border == PEA_BORDER_REPLICATE);
     const unsigned vo = (oky && okx) ? (unsigned)(gy * P.X + gx) * (unsigned)sizeof(T) : kOOB;  // outside => zeros
     float v[D_T];
     float ss = 0.f;
@@ -236,8 +249,8 @@ __device__ __forceinline__ void stage_region_own(const KParams& P, const TParams
     else if (j < top + bot) { const int k = j - top; const int rr = (int)(((float)k + 0.5f) * Q.inv_rw); r = Q.hy0 + TH + rr; c = k - rr * Q.RW; }
     else { const int k = j - top - bot; const int rr = (int)(((float)k + 0.5f) * Q.inv_sw); const int cc = k - rr * sw; r = Q.hy0 + rr; c = cc < Q.hx0 ? cc : cc + TW; }
     bool oky, okx;
-    const int gy = wrap1<CROP>(y0 - Q.hy0 + r, P.Y, oky);
-    const int gx = wrap1<CROP>(x0 - Q.hx0 + c, P.X, okx);
+    const int gy = wrap1r<CROP>(y0 - Q.hy0 + r, P.Y, oky, P.border == PEA_BORDER_REPLICATE);
+    const int gx = wrap1r<CROP>(x0 - Q.hx0 + c, P.X, okx, P.border == PEA_BORDER_REPLICATE);
     const unsigned vo = (oky && okx) ? (unsigned)(gy * P.X + gx) * (unsigned)sizeof(T) : kOOB;  // outside => zeros
     float v[D_T];
     float ss = 0.f;
@@ -330,6 +343,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled(const 
   typedef Lds<D_T, PLQ> L;
   constexpr int NT = TH * TW, NW = NT / 64;
   constexpr int KN = 8;  // near offsets per chunk (chunk 0 is requested before the staging loads)
+  const bool rep = CROP && P.border == PEA_BORDER_REPLICATE;  // clamped border (wrap1r): every neighbour exists
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   float* s_part = (float*)(lds + L::kBytes);  // [NW][K]
@@ -399,9 +413,9 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled(const 
   {                                                                                                \
     const OffEnt fe_ = Q.far[k];                                                                   \
     bool okz_, oky_, okx_;                                                                         \
-    const int zz_ = wrap1<CROP>(z + fe_.d, P.Z, okz_);                                             \
-    const int yy_ = wrap1<CROP>(py + ent_oy(fe_), P.Y, oky_);                                      \
-    const int xx_ = wrap1<CROP>(px + ent_ox(fe_), P.X, okx_);                                      \
+    const int zz_ = wrap1r<CROP>(z + fe_.d, P.Z, okz_, rep);                                       \
+    const int yy_ = wrap1r<CROP>(py + ent_oy(fe_), P.Y, oky_, rep);                                \
+    const int xx_ = wrap1r<CROP>(px + ent_ox(fe_), P.X, okx_, rep);                                \
     fok = live && okz_ && oky_ && okx_;                                                            \
     const unsigned zo_ = (unsigned)(CROP ? min(max(zz_, 0), P.Z - 1) : zz_) * YX * (unsigned)sizeof(T); \
     const unsigned vo_ = fok ? (unsigned)(yy_ * P.X + xx_) * (unsigned)sizeof(T) : kOOB;           \
@@ -444,7 +458,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled(const 
 #pragma unroll
         for (int c = 0; c < D_T; ++c) a = fmaf(own[c], v[c], a);
         bool valid = live;
-        if (CROP) {
+        if (CROP && !rep) {
           const bool inside = (unsigned)(py + ent_oy(en)) < (unsigned)P.Y && (unsigned)(px + ent_ox(en)) < (unsigned)P.X;
           a = inside ? a : 0.f;
           valid = valid && inside;
@@ -519,6 +533,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled_v(cons
   constexpr int NT = TH * TW, TP = NT, QP = TP / 4, NSL = QP / 64;
   constexpr int ITEMS = (kKV * QP + NT - 1) / NT;
   static_assert(QP % 64 == 0 && TW % 4 == 0, "a wave must cover quads of one offset plane");
+  const bool rep = CROP && P.border == PEA_BORDER_REPLICATE;  // clamped border (wrap1r): every neighbour exists
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   // [K][TP] dot products: OVL = laid over the staged region once every wave is done reading it (smaller LDS
@@ -599,9 +614,9 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled_v(cons
   {                                                                                                \
     const OffEnt fe_ = Q.far[k];                                                                   \
     bool okz_, oky_, okx_;                                                                         \
-    const int zz_ = wrap1<CROP>(z + fe_.d, P.Z, okz_);                                             \
-    const int yy_ = wrap1<CROP>(py + ent_oy(fe_), P.Y, oky_);                                      \
-    const int xx_ = wrap1<CROP>(px + ent_ox(fe_), P.X, okx_);                                      \
+    const int zz_ = wrap1r<CROP>(z + fe_.d, P.Z, okz_, rep);                                       \
+    const int yy_ = wrap1r<CROP>(py + ent_oy(fe_), P.Y, oky_, rep);                                \
+    const int xx_ = wrap1r<CROP>(px + ent_ox(fe_), P.X, okx_, rep);                                \
     fok = live && okz_ && oky_ && okx_;                                                            \
     const unsigned zo_ = (unsigned)(CROP ? min(max(zz_, 0), P.Z - 1) : zz_) * YX * (unsigned)sizeof(T); \
     const unsigned vo_ = fok ? (unsigned)(yy_ * P.X + xx_) * (unsigned)sizeof(T) : kOOB;           \
@@ -640,7 +655,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled_v(cons
       float a = 0.f;
 #pragma unroll
       for (int c = 0; c < D_T; ++c) a = fmaf(own[c], v[c], a);
-      if (CROP) {
+      if (CROP && !rep) {
         const bool inside = (unsigned)(py + ent_oy(en)) < (unsigned)P.Y && (unsigned)(px + ent_ox(en)) < (unsigned)P.X;
         a = inside ? a : 0.f;
       }
@@ -685,7 +700,7 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_fwd_tiled_v(cons
         const float m = (float)((m4[it] >> (8 * j)) & 0xffu);
         const float r = a4[j] * m - t4[it][j] * m;
         float wr = w4[it][j] * r;
-        if (CROP) {  // a cropped-away neighbour carries no loss term (its a is already 0)
+        if (CROP && !rep) {  // a cropped-away neighbour carries no loss term (its a is already 0)
           const bool inside = (unsigned)(igy[it] + ent_oy(en)) < (unsigned)P.Y && (unsigned)(igx[it] + j + ent_ox(en)) < (unsigned)P.X;
           const bool inz = (unsigned)(z + ioz[it]) < (unsigned)P.Z;
           wr = (inside && inz) ? wr : 0.f;
@@ -724,6 +739,9 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_bwd_tiled(const 
   constexpr int NT = TH * TW;
   constexpr int NR = (ROLE_A ? 1 : 0) + (ROLE_B ? 1 : 0);
   constexpr int KN = 8;  // near offsets per chunk (x NR roles of g values; chunk 0 requested before staging)
+  // REPLICATE: role A's neighbour is clamp(p + o) (the staged region holds the clamped pixels, far pairs clamp their index); role B
+  // keeps the in-volume test for its regular pre-image p - o and adds what the clamp folds onto border pixels at the end
+  const bool rep = CROP && P.border == PEA_BORDER_REPLICATE;
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   const int tile = tile_id(Q);
@@ -762,8 +780,8 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_bwd_tiled(const 
       const OffEnt en_ = Q.near[min((k0) + u, Q.n_near - 1)];                                                  \
       const int sg_ = (ROLE_A && r == 0) ? 1 : -1;                                                             \
       bool oky_, okx_;                                                                                         \
-      const int yy_ = wrap1<CROP>(py + sg_ * ent_oy(en_), P.Y, oky_);                                          \
-      const int xx_ = wrap1<CROP>(px + sg_ * ent_ox(en_), P.X, okx_);                                          \
+      const int yy_ = wrap1r<CROP>(py + sg_ * ent_oy(en_), P.Y, oky_, rep && sg_ > 0);                         \
+      const int xx_ = wrap1r<CROP>(px + sg_ * ent_ox(en_), P.X, okx_, rep && sg_ > 0);                         \
       const bool ok_ = live && oky_ && okx_ && ((k0) + u < Q.n_near);                                          \
       gn[u][r] = bl32((unsigned)en_.i >= ksp ? gB1 : gB, ok_ ? (sg_ > 0 ? po : (unsigned)(yy_ * P.X + xx_)) * 4u : kOOB,     \
                       kzo + ((unsigned)en_.i >= ksp ? (unsigned)en_.i - ksp : (unsigned)en_.i) * kcs);                     \
@@ -795,9 +813,9 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_bwd_tiled(const 
     const OffEnt fe_ = Q.far[(j) / NR];                                                                       \
     const int sg_ = (ROLE_A && ((j) % NR) == 0) ? 1 : -1;                                                     \
     bool okz_, oky_, okx_;                                                                                    \
-    const int zz_ = wrap1<CROP>(z + sg_ * fe_.d, P.Z, okz_);                                                  \
-    const int yy_ = wrap1<CROP>(py + sg_ * ent_oy(fe_), P.Y, oky_);                                           \
-    const int xx_ = wrap1<CROP>(px + sg_ * ent_ox(fe_), P.X, okx_);                                           \
+    const int zz_ = wrap1r<CROP>(z + sg_ * fe_.d, P.Z, okz_, rep && sg_ > 0);                                 \
+    const int yy_ = wrap1r<CROP>(py + sg_ * ent_oy(fe_), P.Y, oky_, rep && sg_ > 0);                          \
+    const int xx_ = wrap1r<CROP>(px + sg_ * ent_ox(fe_), P.X, okx_, rep && sg_ > 0);                          \
     const bool ok_ = live && okz_ && oky_ && okx_;                                                            \
     const unsigned zc_ = (unsigned)(CROP ? min(max(zz_, 0), P.Z - 1) : zz_);                                  \
     const unsigned qo_ = (unsigned)(yy_ * P.X + xx_);                                                         \
@@ -872,6 +890,37 @@ __global__ __launch_bounds__(TH* TW, (D_T > 16 ? 2 : 4)) void k_bwd_tiled(const 
   }
 #undef PEA_BWD_LOAD_FAR
 #undef PEA_BWD_FAR
+
+  // ---- REPLICATE, role B: the clamp is not invertible -- a pixel ON a face of the volume is the clamped neighbour of every p' in a
+  //      box (clamp_preimage per axis), of which only p - o (if it is inside) was gathered above.  The other ones are read from global
+  //      memory here: face pixels only (the lanes of border tiles; both z = 0 and z = Z - 1 planes when an offset steps along z).
+  if (CROP && ROLE_B && rep && live && (z == 0 || z == P.Z - 1 || py == 0 || py == P.Y - 1 || px == 0 || px == P.X - 1)) {
+    const T* nbb = nbt + (size_t)b * D_T * S;
+    const float* gb = gin + (size_t)b * P.K * S;
+    for (int i = 0; i < P.K; ++i) {
+      const int oz = P.off[i][0], oy = P.off[i][1], ox = P.off[i][2];
+      int z0, z1, ya, yb, xa, xb;
+      clamp_preimage(z, oz, P.Z, z0, z1);
+      clamp_preimage(py, oy, P.Y, ya, yb);
+      clamp_preimage(px, ox, P.X, xa, xb);
+      if (z1 < z0 || yb < ya || xb < xa || (z1 == z0 && yb == ya && xb == xa)) continue;  // empty, or p - o alone (done above)
+      for (int zz = z0; zz <= z1; ++zz)
+        for (int yy = ya; yy <= yb; ++yy)
+          for (int xx = xa; xx <= xb; ++xx) {
+            if (zz == z - oz && yy == py - oy && xx == px - ox) continue;  // the regular pre-image
+            const size_t q2 = ((size_t)zz * P.Y + yy) * P.X + xx;
+            float v2[D_T], sq2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < D_T; ++c) {
+              v2[c] = ld(nbb, c * S + q2);
+              sq2 = fmaf(v2[c], v2[c], sq2);
+            }
+            const float g2 = gb[(size_t)i * S + q2] * rnorm(sq2, Q.inv_eps);
+#pragma unroll
+            for (int c = 0; c < D_T; ++c) G[c] = fmaf(g2, v2[c], G[c]);
+          }
+    }
+  }
 
   float proj = 0.f;
 #pragma unroll

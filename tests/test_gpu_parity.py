@@ -951,6 +951,59 @@ def test_replicate_border_norm6_matches_reference_golden(pkg, dev, name):
         assert relmax(mt.grad.cpu().numpy(), g["grad_ema"]) < GRAD_RTOL
 
 
+@pytest.mark.parametrize("which,shape", [("self", (2, 5, 40, 72)), ("ema", (1, 4, 50, 64)), ("ema_both", (1, 3, 37, 68)), ("self", (1, 2, 33, 100))])
+def test_replicate_border_on_the_tiled_kernels(pkg, dev, orc, synth, monkeypatch, which, shape):
+    """PEA_BORDER_REPLICATE (row a-15) on the LDS-tiled kernels (k_fwd_tiled_v / k_fwd_tiled / k_bwd_tiled with the clamped region,
+    csrc/pea_tiled.h wrap1r) at shapes their plan takes: embedding_loss_norm6 / ema_embedding_loss_norm6 against the CPU oracle --
+    near offsets served from LDS (in-plane, radius <= 9), far ones (z steps, diagonals through planes, reach 27) from global memory,
+    border pixels collecting the pre-images the clamp folds onto them -- and against the global-memory kernels (PEA_FORCE_DIRECT=1)"""
+    B, Z, Y, X = shape
+    D = 16
+    offs = [[-1, 0, 0], [0, -1, 0], [0, 0, -1], [-1, -1, -1], [-1, 1, 1], [0, -9, 0], [0, 0, -9], [0, -9, -4], [0, 4, -9], [0, 9, -4],
+            [0, -27, 0], [0, 0, -27], [1, 2, -2], [0, -3, 3], [0, 3, 0], [0, 0, 2]]
+    K, S = len(offs), Z * Y * X
+    e = synth.synth_embedding((B, D, S), 4100 + Z).reshape(B, D, Z, Y, X)
+    e[0, :, 0, 0, 0] = 0.0               # a zero pixel in the corner that collects the largest pre-image
+    eo = synth.synth_embedding((B, D, S), 4200 + Z).reshape(B, D, Z, Y, X)
+    idx = np.arange(B * K * S, dtype=np.uint64)
+    t = (synth.hash_uniform(idx, 4300) < 0.6).astype(np.float32).reshape(B, K, Z, Y, X)
+    w = (0.5 + synth.hash_uniform(idx, 4400)).astype(np.float32).reshape(B, K, Z, Y, X)
+    crit = pkg.WeightedMSE()
+    d = orc.make_desc(B, D, [Z, Y, X], offs, None, orc.BORDER_REPLICATE, orc.NORM_FULL, ndim=3)
+    other = None if which == "self" else eo
+    o_affs, o_loss = orc.c_fwd(d, e, other, t, w, None)
+    o_grad, o_grad_o = orc.c_bwd(d, e, other, t, w, None, dloss=0.5, want_other=(which == "ema_both"))
+
+    def run():
+        et = cu(e, dev).requires_grad_(True)
+        if which == "self":
+            loss, affs = pkg.embedding_loss_norm6(et, cu(t, dev), cu(w, dev), crit, shift=offs)
+            mt = None
+        else:
+            mt = cu(eo, dev).requires_grad_(which == "ema_both")
+            loss, affs = pkg.ema_embedding_loss_norm6(et, mt, cu(t, dev), cu(w, dev), crit, shift=offs)
+        (loss * 0.5).backward()
+        return loss.item(), affs.detach().cpu().numpy(), et.grad.cpu().numpy(), None if (mt is None or mt.grad is None) else mt.grad.cpu().numpy()
+
+    res = {}
+    for force in ("0", "1"):
+        monkeypatch.setenv("PEA_FORCE_DIRECT", force)
+        pkg._lib.reload_env()
+        try:
+            res[force] = run()
+        finally:
+            monkeypatch.delenv("PEA_FORCE_DIRECT")
+            pkg._lib.reload_env()
+        loss, affs, grad, grad_o = res[force]
+        assert np.abs(affs.reshape(o_affs.shape) - o_affs).max() < AFFS_ATOL, force
+        assert abs(loss - o_loss[0]) <= LOSS_RTOL * abs(o_loss[0]), force
+        assert relmax(grad.reshape(o_grad.shape), o_grad) < GRAD_RTOL, force
+        if which == "ema_both":
+            assert relmax(grad_o.reshape(o_grad_o.shape), o_grad_o) < GRAD_RTOL, force
+    # (different kernels: the sums run in different orders -- identical bits would mean the switch did nothing)
+    assert not np.array_equal(res["0"][2], res["1"][2])
+
+
 def test_loss_section_node_equals_composed(pkg, dev, synth):
     """cvppp_loss_section as one autograd node (weights folded into the launches) against the statement-for-statement
     composition from embedding_loss / ema_embedding_loss, with non-trivial weights and an outer factor on the loss"""
