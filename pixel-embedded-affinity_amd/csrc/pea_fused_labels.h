@@ -612,14 +612,89 @@ static __global__ __launch_bounds__(256) void k_label_counts(const GParams G, co
 #pragma unroll
       for (int j = 0; j < NIT; ++j) {
         const bool live = xin && ybase + 4 * j < G.Y;
-        const bool t = in[u][j] ? (pa[j] == nb[u][j] && (!fg || (pa[j] > 0 && nb[u][j] > 0))) : pad;
-        c += (unsigned)__popcll(__ballot(live && t));
+        const bool eq = (pa[j] == nb[u][j]) & (!fg | ((pa[j] > 0) & (nb[u][j] > 0)));  // (bitwise: no branch per sample)
+        const bool t = in[u][j] ? eq : pad;
+        c += (unsigned)__popcll(__ballot(live & t));
       }
       if (i0 + u < G.K && (threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt[i0 + u], c);
     }
   }
   __syncthreads();
   // partials [b][k][workgroup of this image]
+  const int per_img = (int)(gridDim.x * gridDim.y) * G.Z, wg = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * G.Z + z;
+  if (threadIdx.x < G.K) counts[((size_t)b * G.K + threadIdx.x) * per_img + wg] = s_cnt[threadIdx.x];
+}
+
+// The same counts with the label tile staged through LDS (2D tables whose reach fits the halo: the CVPPP / BBBC stencils): the 88
+// one-dword neighbour loads per lane of k_label_counts cost 16-18 cycles of the address unit each whatever they hit (35 us at
+// B = 8 x 544^2, K = 10: DESIGN.md section 5 item 9); here a workgroup brings its 32 x 64 tile + halo in with ten 16-byte loads per
+// lane and compares out of LDS.  Same grid, same partials layout, same integers: k_weight_table and the weights are unchanged.
+// Outside the image the region holds kNoLabel (INT_MIN: no instance id).  Needs X % 4 == 0 and a 16-byte aligned label image.
+constexpr int kCntHalo = 28;  // >= the reach of the table, a multiple of 4
+constexpr int kNoLabel = (int)0x80000000;
+static __global__ __launch_bounds__(256) void k_label_counts_lds(const GParams G, const int32_t* __restrict__ labels,
+                                                          unsigned* __restrict__ counts) {
+  constexpr int R = kCntHalo, TH = 4 * kCntRows, TW = 64, RW = TW + 2 * R, RH = TH + 2 * R, QW = RW / 4, NIT = kCntRows;
+  __shared__ int s_lab[RH * RW];
+  __shared__ unsigned s_cnt[PEA_MAX_K];
+  const int b = blockIdx.z / G.Z, z = blockIdx.z - b * G.Z;
+  if (threadIdx.x < PEA_MAX_K) s_cnt[threadIdx.x] = 0;
+  const int32_t* lb = labels + (size_t)b * G.S + (size_t)z * G.Y * G.X;
+  const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+  typedef int i4v __attribute__((ext_vector_type(4)));
+  // every lane's quads are requested before the first one is stored (a loop that loads, tests and stores per trip pays the memory
+  // latency eleven times: 31 us).  x0, R, X are multiples of 4: a quad is inside the row as a whole or not at all.
+  constexpr int TRIPS = (RH * QW + 255) / 256;
+  i4v v[TRIPS];
+  bool ok[TRIPS];
+#pragma unroll
+  for (int it = 0; it < TRIPS; ++it) {
+    const int q = it * 256 + (int)threadIdx.x;
+    const int r = q / QW, c4 = (q - r * QW) * 4;
+    const int gy = y0 - R + r, gx = x0 - R + c4;
+    ok[it] = q < RH * QW && (unsigned)gy < (unsigned)G.Y && gx >= 0 && gx + 3 < G.X;
+    v[it] = *(const i4v*)(lb + (ok[it] ? (size_t)gy * G.X + gx : 0));
+  }
+#pragma unroll
+  for (int it = 0; it < TRIPS; ++it) {
+    const int q = it * 256 + (int)threadIdx.x;
+    if (q < RH * QW) *(i4v*)(s_lab + q * 4) = ok[it] ? v[it] : (i4v){kNoLabel, kNoLabel, kNoLabel, kNoLabel};
+  }
+  __syncthreads();
+  const bool pad = G.flags & PEA_TGT_PADDING, fg = G.flags & PEA_TGT_BOTH_FOREGROUND;
+  const int col = (int)(threadIdx.x & 63), row0 = (int)(threadIdx.x >> 6);
+  const bool xin = x0 + col < G.X;
+  int pa[NIT];
+  bool live[NIT];
+#pragma unroll
+  for (int j = 0; j < NIT; ++j) {
+    const int y = row0 + 4 * j;
+    pa[j] = s_lab[(R + y) * RW + R + col];
+    live[j] = xin && y0 + y < G.Y;
+  }
+  constexpr int CH = 5;  // channels per trip: CH * NIT LDS reads in flight per lane, the table's rows fetched CH at a time
+  for (int i0 = 0; i0 < G.K; i0 += CH) {
+    int nb[CH][NIT];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int i = min(i0 + u, G.K - 1);
+      const int d = G.off[i][1] * RW + G.off[i][2];
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) nb[u][j] = s_lab[(R + row0 + 4 * j) * RW + R + col + d];
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      unsigned c = 0;
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {  // (bitwise, not short-circuit: as branches the reads were waited for one by one)
+        const bool eq = (pa[j] == nb[u][j]) & (!fg | ((pa[j] > 0) & (nb[u][j] > 0)));
+        const bool t = (nb[u][j] != kNoLabel) ? eq : pad;
+        c += (unsigned)__popcll(__ballot(live[j] & t));
+      }
+      if (i0 + u < G.K && (threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt[i0 + u], c);
+    }
+  }
+  __syncthreads();
   const int per_img = (int)(gridDim.x * gridDim.y) * G.Z, wg = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * G.Z + z;
   if (threadIdx.x < G.K) counts[((size_t)b * G.K + threadIdx.x) * per_img + wg] = s_cnt[threadIdx.x];
 }

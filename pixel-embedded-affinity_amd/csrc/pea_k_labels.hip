@@ -115,7 +115,11 @@ int label_weights(const PeaDesc* desc, const int32_t* labels, unsigned flags, fl
   const GParams G = gparams(desc, flags);
   if ((long long)G.B * G.Z > 65535 || (G.Y + 4 * kCntRows - 1) / (4 * kCntRows) > 65535) return PEA_E_UNSUPPORTED;
   const dim3 cgrid((unsigned)((G.X + 63) / 64), (unsigned)((G.Y + 4 * kCntRows - 1) / (4 * kCntRows)), (unsigned)(G.B * G.Z));
-  hipLaunchKernelGGL(k_label_counts, cgrid, dim3(256), 0, s, G, labels, (unsigned*)ws);
+  // in-plane tables within the halo, quads inside rows: the LDS-staged counts (the same integers)
+  bool lds_ok = G.X % 4 == 0 && !misaligned(labels, 16) && !env().force_direct;
+  for (int i = 0; i < G.K && lds_ok; ++i) lds_ok = G.off[i][0] == 0 && abs(G.off[i][1]) <= kCntHalo && abs(G.off[i][2]) <= kCntHalo;
+  if (lds_ok) hipLaunchKernelGGL(k_label_counts_lds, cgrid, dim3(256), 0, s, G, labels, (unsigned*)ws);
+  else hipLaunchKernelGGL(k_label_counts, cgrid, dim3(256), 0, s, G, labels, (unsigned*)ws);
   const int per_img = (int)(cgrid.x * cgrid.y) * G.Z;
   const int n = G.B * G.K;
   hipLaunchKernelGGL(k_weight_table, dim3((unsigned)n), dim3(64), 0, s, G.S, per_img, (const unsigned*)ws, wtab);

@@ -871,6 +871,38 @@ def test_labels_step_matches_targets_path(pkg, dev, synth, case, two_launch, mon
     assert (sb > 0) == (case in ("self_nb4", "ema", "d32", "d32_ema"))   # (the descriptor qualifies; a second operand opts out per call)
 
 
+@pytest.mark.parametrize("shape,shifts,nb,flags", [((3, 80, 136), [1, 3, 5, 9, 27], 4, 5), ((2, 37, 100), [1, 3, 5, 9, 27], 4, 1), ((1, 544, 544), [1, 3, 5, 9, 27], 4, 5),
+                                                   ((2, 33, 68), [1, 3, 9], 8, 7), ((1, 64, 64), [1], 4, 4), ((2, 50, 72), [1, 28], 4, 3)])
+def test_label_weights_lds_counts_equal_the_global_memory_counts(pkg, dev, synth, monkeypatch, shape, shifts, nb, flags):
+    """pea_label_weights: the LDS-staged count kernel (k_label_counts_lds: 32 x 64 label tiles + a halo of 28 through LDS) against the
+    one-dword-loads kernel it replaces for 2D tables (PEA_FORCE_DIRECT=1 selects the latter): the counts are integers, so the weight
+    tables must be EQUAL -- ragged tiles, every target flag, a diagonal table, the largest reach the halo takes (28)"""
+    B, H, W = shape
+    offsets = pkg.multi_offset(shifts, nb)
+    lab = torch.from_numpy(synth.synth_labels(B, (1, H, W), 171, cell=9)[:, 0].copy()).to(dev)
+    op, L = pkg.affinity_op, pkg._lib.lib()
+    E = torch.zeros(B, 16, H, W, device=dev)
+    d = op.make_desc(op.AffinitySpec(2, offsets, None, pkg._lib.BORDER_CIRCULAR, pkg._lib.NORM_BX), E)
+    K = len(offsets)
+    cb = L.pea_targets_workspace_bytes(ctypes.byref(d))
+    P = lambda x: ctypes.c_void_p(x.data_ptr())
+    out = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("PEA_FORCE_DIRECT", force)
+        pkg._lib.reload_env()
+        try:
+            wtab = torch.full((B * K * 2,), -1.0, device=dev)
+            cnt = torch.empty(cb // 4, dtype=torch.int32, device=dev)
+            assert L.pea_label_weights(ctypes.byref(d), P(lab), flags, P(wtab), P(cnt), cb, None) == 0
+            torch.cuda.synchronize()
+            out.append(wtab)
+        finally:
+            monkeypatch.delenv("PEA_FORCE_DIRECT")
+            pkg._lib.reload_env()
+    assert torch.equal(out[0], out[1])
+    assert (out[0] >= 1.0).all() and (out[0] > 1.0).any()  # (real tables: some channel is re-weighted)
+
+
 def test_labels_step_3d_and_section(pkg, dev, orc, synth):
     """3D labels-in losses (seg_to_aff(pad='') targets, both-foreground, no mask, cropped border) against gen_targets +
     the tensor API; and the multi-scale 2D loss section from label images against the tensor section"""
