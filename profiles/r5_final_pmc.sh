@@ -6,7 +6,7 @@ cd $ROOT && mkdir -p gpurun_out && rm -f profiles/traffic.json
 bash profiles/pmc_step.sh r5f g h > gpurun_out/r5f_pmc_c2.txt 2>&1
 python3 profiles/make_traffic.py c2 gpurun_out/pmcs_r5f_g gpurun_out/pmcs_r5f_h >> gpurun_out/r5f_pmc_c2.txt 2>&1
 echo "c2 done"
-for cfg in c1 c1k8 c3 c3crop c4 c4n26 c5 c5f32 c2ema c3ema c4ema c5ema; do
+for cfg in c1 c1k8 c3 c3crop c4 c4n26 c5 c5f32 c2ema c3ema c4ema c5ema c4r6; do
   bash profiles/pmc_cfg.sh r5f_$cfg $cfg g h > gpurun_out/r5f_pmc_$cfg.txt 2>&1
   python3 profiles/make_traffic.py $cfg gpurun_out/pmcc_r5f_${cfg}_g gpurun_out/pmcc_r5f_${cfg}_h >> gpurun_out/r5f_pmc_$cfg.txt 2>&1
   echo "$cfg done"
