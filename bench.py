@@ -461,7 +461,8 @@ def cpu_baseline_generic3d(offsets, e, t, w, what, replicate=False):
     px = B * int(np.prod(en.shape[2:]))
     v = round(px / dco / 1e6, 4)
     return {"value": v, "unit": "Mpx/s", "cores": cores, "kind": "port",
-            "sample": "best of 2 fwd + bwd of %s, oracle/pea_oracle.c with OpenMP (%d threads), %.2f s" % (what, cores, dco),
+            "sample": "best of 2 fwd + bwd of %s, oracle/pea_oracle.c with OpenMP (%d threads), %.2f s%s"
+                      % (what, cores, dco, " -- the restatement's replicate-border BACKWARD is a serial scatter: most of this time runs on one core" if replicate else ""),
             "c_omp": {"value": v, "unit": "Mpx/s", "cores": cores, "kind": "port", "sample": "the same run"},
             "c_1thread": {"value": round(int(np.prod(e1.shape[2:])) / d1t / 1e6, 4), "unit": "Mpx/s", "cores": 1, "kind": "port",
                           "sample": "one fwd + bwd of a 24x64x64 block, oracle/pea_oracle.c, 1 thread, %.2f s" % d1t},
