@@ -49,8 +49,9 @@ struct Env {
                       //   asks for first, and the next forward starts where the backward ended (-1.7 % / -0.8 %, profiles/r5_switch1.txt)
   int bwd_w3;         // PEA_BWD_W3=1: the D = 16 self-loss backward on three workgroups per CU (pea_xdma_w3.h)
   int bwd_vec;        // PEA_BWD_VEC=1: k_bwd_xdma's 16-byte g loads / stores instantiation
-  int fwd_dual;       // PEA_FWD_DUAL=0: pea_affinity_fwd_dual_ex reports PEA_E_UNSUPPORTED (the caller runs the two forwards); 2 (default): the
-                      //   one-launch pair on a ring of two four-plane buffers, two workgroups per CU; 3: a ring of three, one workgroup per CU
+  int fwd_dual;       // PEA_FWD_DUAL=0: pea_affinity_fwd_dual_ex reports PEA_E_UNSUPPORTED (the caller runs the two forwards); 4 (default): the
+                      //   one-launch pair on a ring of two four-plane buffers handed over in HALVES (e pair, ema pair), two workgroups per CU;
+                      //   2: the same ring handed over buffer by buffer (+2.6 %); 3: a ring of three, one workgroup per CU (+21 %)
 };
 const Env& env();
 void env_reload();          // pea_reload_env(): tests that change a switch call it

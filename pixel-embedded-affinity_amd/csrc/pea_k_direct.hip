@@ -54,7 +54,7 @@ const Env* env_make() {
   e->bwd_rev = env_int("PEA_BWD_REV", 1);
   e->bwd_w3 = env_int("PEA_BWD_W3", 0);
   e->bwd_vec = env_int("PEA_BWD_VEC", 0);
-  e->fwd_dual = env_int("PEA_FWD_DUAL", 2);
+  e->fwd_dual = env_int("PEA_FWD_DUAL", 4);
   return e;
 }
 std::atomic<unsigned> g_env_gen{1};

@@ -144,13 +144,15 @@ bool xdma_fwd_dual(const KParams& P, const KParams& P2, const FwdArgs& A, const 
 #define PEA_XFD(CROP_, NB_)                                                                            \
   {                                                                                                    \
     constexpr auto kern = k_fwd_xdma_dual<kXdmaTH, kXdmaTW, kXdmaPSUF, CROP_, NB_>;                    \
-    const size_t lds = (size_t)NB_ * 4 * kXdmaPSUF * 256;                                              \
+    const size_t lds = (size_t)(NB_ == 3 ? 3 : 2) * 4 * kXdmaPSUF * 256;                               \
     PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out, DA) \
   }
   if (env().fwd_dual == 3) {
     if (crop) PEA_XFD(true, 3) else PEA_XFD(false, 3)
-  } else {
+  } else if (env().fwd_dual == 2) {
     if (crop) PEA_XFD(true, 2) else PEA_XFD(false, 2)
+  } else {
+    if (crop) PEA_XFD(true, 4) else PEA_XFD(false, 4)
   }
 #undef PEA_XFD
   return true;

@@ -9,8 +9,11 @@
 //
 // Structure = k_fwd_xdma (pea_xdma.h) with four planes per chunk instead of two: a ring of NB buffers of (e ch 2c, e ch 2c + 1,
 // ema ch 2c, ema ch 2c + 1) in the forward's one-sided 7.5 KB planes.  NB = 2: 60 KB, two workgroups per CU, the next chunk is
-// requested when this one's buffer is free (one chunk of look-ahead, the other workgroup covers the rest); NB = 3: 90 KB, one
-// workgroup per CU, two chunks of look-ahead.  40 packed accumulators (dot and neighbour |.|^2, self and cross, ten offsets).
+// requested when this one's buffer is free (one chunk of look-ahead, the other workgroup covers the rest); NB = 4 (the default): the
+// SAME two buffers handed over in halves -- the e pair is gathered, its planes are requested again, then the ema pair: twice the
+// barriers, but a half is on its way one and a half chunks ahead and the requests leave in a steadier stream (190 against 195 us);
+// NB = 3: 90 KB, one workgroup per CU, two chunks of look-ahead (230 us).  40 packed accumulators (dot and neighbour |.|^2, self and
+// cross, ten offsets).
 // The sums run in the order of the single kernels -- even channels in .x, odd in .y, chunks ascending -- so every output is
 // bit-identical to the two launches it replaces (tests/test_gpu_cross.py::test_dual_forward_equals_the_two_launches).
 // 2D, D = 16, f32, axis-aligned stencil, K <= kXP; either border.  The cross loss' map is not written (the training loop drops it).
@@ -28,7 +31,7 @@ struct DualFwdArgs {
 };
 
 template <int TH, int TW, int PSU, bool CROP, int NB>
-__global__ __launch_bounds__(TH* TW, NB == 2 ? 4 : 2) void k_fwd_xdma_dual(const KParams P, const XParams C, const float* __restrict__ e,
+__global__ __launch_bounds__(TH* TW, NB == 3 ? 2 : 4) void k_fwd_xdma_dual(const KParams P, const XParams C, const float* __restrict__ e,
                                                                            const float* __restrict__ target,
                                                                            const float* __restrict__ weight,
                                                                            const uint8_t* __restrict__ mask, float* __restrict__ affs,
@@ -36,9 +39,10 @@ __global__ __launch_bounds__(TH* TW, NB == 2 ? 4 : 2) void k_fwd_xdma_dual(const
                                                                            float* __restrict__ inv_out, const DualFwdArgs DA) {
   constexpr int D_T = 16, NT = TH * TW, PS = PSU * 256, NP = D_T / 2, TP = NT, QP = TP / 4, NSL = QP / 64, KMAX = kXP;
   constexpr int ITEMS = (KMAX * QP + NT - 1) / NT, BUF = 4 * PS;
+  constexpr int NBUF = NB == 3 ? 3 : 2;  // whole four-plane buffers (NB = 4: the ring of two, handed over in HALVES -- e pair, ema pair)
   static_assert(TW == 32 && QP % 64 == 0, "lane mapping");
-  static_assert(NB == 2 || NB == 3, "ring depth");
-  static_assert(2 * (KMAX * TP * 4 + KMAX * NSL * 4) <= NB * BUF && KMAX <= kXK, "the parked dot products fit the ring");
+  static_assert(NB == 2 || NB == 3 || NB == 4, "ring depth");
+  static_assert(2 * (KMAX * TP * 4 + KMAX * NSL * 4) <= NBUF * BUF && KMAX <= kXK, "the parked dot products fit the ring");
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   float* sA = (float*)lds;          // [K][TP] self dot products, laid over the ring once it is dead
@@ -118,8 +122,39 @@ __global__ __launch_bounds__(TH* TW, NB == 2 ? 4 : 2) void k_fwd_xdma_dual(const
     else if (fly_ == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");      \
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                     \
   }
+// half a chunk: the e pair (op_ = 0, planes 0 and 1 of the buffer) or the ema pair (op_ = 1, planes 2 and 3)
+#define PEA_DDMAH(buf, ch, op_)                                                          \
+  {                                                                                      \
+    const unsigned so_ = ezo + (unsigned)(2 * (ch)) * ecs;                               \
+    const int pb_ = (buf) * BUF + (op_) * 2 * PS;                                        \
+    if (act[0]) {                                                                        \
+      PEA_DDMA1((op_) ? yB : xB, pb_ + wbase, vo[0], so_)                                \
+      PEA_DDMA1((op_) ? yB : xB, pb_ + PS + wbase, vo[0], so_ + ecs)                     \
+    }                                                                                    \
+    if (act[1]) {                                                                        \
+      PEA_DDMA1((op_) ? yB : xB, pb_ + w1, vo[1], so_)                                   \
+      PEA_DDMA1((op_) ? yB : xB, pb_ + PS + w1, vo[1], so_ + ecs)                        \
+    }                                                                                    \
+  }
+// at most `loads_` (a wave-uniform multiple of 2 up to 16) younger DMA instructions may still fly; then the barrier
+#define PEA_DWAITL(loads_)                                                                            \
+  {                                                                                                   \
+    const int fl_ = (loads_);                                                                         \
+    if (fl_ >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");          \
+    else if (fl_ >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");     \
+    else if (fl_ >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
+    else if (fl_ >= 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
+    else if (fl_ >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
+    else if (fl_ >= 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                     \
+  }
+  const int nh = npt / 2;  // DMA instructions of this wave per HALF chunk
+  if (NB == 4) {  // (half by half: a wait counts whole halves)
+    PEA_DDMAH(0, 0, 0) PEA_DDMAH(0, 0, 1) PEA_DDMAH(1, 1, 0) PEA_DDMAH(1, 1, 1)
+  } else {
 #pragma unroll
-  for (int c = 0; c < NB; ++c) PEA_DDMA(c, c)
+    for (int c = 0; c < NBUF; ++c) PEA_DDMA(c, c)
+  }
 
   // ---- LDS slot of every offset's neighbour
   int an[kXP];
@@ -131,7 +166,8 @@ __global__ __launch_bounds__(TH* TW, NB == 2 ? 4 : 2) void k_fwd_xdma_dual(const
     const int a_x = (unsigned)c < (unsigned)TW ? vown + d * 4 : hrow + (c & C.fm[k]) * 4;
     an[k] = C.fax[k] ? a_x : vown + d * TW * 4;  // unused offsets: d = 0, the own slot
   }
-  PEA_DWAIT(NB - 1)
+  if (NB == 4) PEA_DWAITL(3 * nh)  // the first e pair has landed
+  else PEA_DWAIT(NBUF - 1)
 
   f2 dot[kXP], ssq[kXP], dotc[kXP], ssqc[kXP], oss = {0.f, 0.f}, css = {0.f, 0.f};
 #pragma unroll
@@ -165,7 +201,63 @@ __global__ __launch_bounds__(TH* TW, NB == 2 ? 4 : 2) void k_fwd_xdma_dual(const
     _Pragma("unroll") for (int k = 0; k < kXP; ++k) asm volatile("" : "+v"(dot[k]), "+v"(ssq[k]), "+v"(dotc[k]), "+v"(ssqc[k])); \
     asm volatile("" : "+v"(oss), "+v"(css));                                                                             \
   }
-  if constexpr (NB == 2) {
+// the same chunk in two parts (NB = 4): the e pair first -- own pixel kept in o_ --, then the ema pair
+#define PEA_DPROC_E(bo_, o_)                                                                                             \
+  {                                                                                                                      \
+    o_.x = *(const float*)(lds + (bo_) + vown);                                                                          \
+    o_.y = *(const float*)(lds + (bo_) + PS + vown);                                                                     \
+    oss = __builtin_elementwise_fma(o_, o_, oss);                                                                        \
+    _Pragma("unroll") for (int k = 0; k < kXP; ++k) {                                                                    \
+      f2 v;                                                                                                              \
+      v.x = *(const float*)(lds + (bo_) + an[k]);                                                                        \
+      v.y = *(const float*)(lds + (bo_) + PS + an[k]);                                                                   \
+      dot[k] = __builtin_elementwise_fma(o_, v, dot[k]);                                                                 \
+      ssq[k] = __builtin_elementwise_fma(v, v, ssq[k]);                                                                  \
+      if (k % 2 == 1) asm volatile("" ::: "memory");                                                                     \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int k = 0; k < kXP; ++k) asm volatile("" : "+v"(dot[k]), "+v"(ssq[k]));                       \
+    asm volatile("" : "+v"(oss), "+v"(o_));                                                                              \
+  }
+#define PEA_DPROC_E2(bo_, o_)                                                                                            \
+  {                                                                                                                      \
+    f2 oc;                                                                                                               \
+    oc.x = *(const float*)(lds + (bo_) + 2 * PS + vown);                                                                 \
+    oc.y = *(const float*)(lds + (bo_) + 3 * PS + vown);                                                                 \
+    css = __builtin_elementwise_fma(oc, oc, css);                                                                        \
+    _Pragma("unroll") for (int k = 0; k < kXP; ++k) {                                                                    \
+      f2 u;                                                                                                              \
+      u.x = *(const float*)(lds + (bo_) + 2 * PS + an[k]);                                                               \
+      u.y = *(const float*)(lds + (bo_) + 3 * PS + an[k]);                                                               \
+      dotc[k] = __builtin_elementwise_fma(o_, u, dotc[k]);                                                               \
+      ssqc[k] = __builtin_elementwise_fma(u, u, ssqc[k]);                                                                \
+      if (k % 2 == 1) asm volatile("" ::: "memory");                                                                     \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int k = 0; k < kXP; ++k) asm volatile("" : "+v"(dotc[k]), "+v"(ssqc[k]));                     \
+    asm volatile("" : "+v"(css));                                                                                        \
+  }
+  if constexpr (NB == 4) {
+    // the ring of two buffers handed over in HALVES: a half is requested as soon as its planes are free, three halves (one and a half
+    // chunks) ahead of the gather instead of one chunk -- twice the barriers, a steadier stream of requests
+#pragma unroll 1
+    for (int it = 0; it < NP / 2; ++it) {
+      const bool more = it + 1 < NP / 2;
+      f2 o0, o1;
+      PEA_DPROC_E(0, o0)
+      PEA_DWAITL(2 * nh)  // (buffer 0, ema) landed; (1, e) and (1, ema) may fly
+      if (more) PEA_DDMAH(0, 2 * it + 2, 0)
+      PEA_DPROC_E2(0, o0)
+      PEA_DWAITL(more ? 2 * nh : nh)  // (1, e) landed
+      if (more) PEA_DDMAH(0, 2 * it + 2, 1)
+      PEA_DPROC_E(BUF, o1)
+      PEA_DWAITL(more ? 2 * nh : 0)  // (1, ema) landed
+      if (more) PEA_DDMAH(1, 2 * it + 3, 0)
+      PEA_DPROC_E2(BUF, o1)
+      if (more) {
+        PEA_DWAITL(2 * nh)  // the next (0, e) landed
+        PEA_DDMAH(1, 2 * it + 3, 1)
+      }
+    }
+  } else if constexpr (NB == 2) {
     // a ROLLED loop over pairs of chunks (buffer 0, buffer 1): unrolled eight times the compiler renames the 84 accumulator registers
     // from chunk to chunk and spills the neighbour slots inside the loop -- behind scratch loads whose s_waitcnt vmcnt(0) also waits
     // for the DMA in flight
@@ -184,14 +276,18 @@ __global__ __launch_bounds__(TH* TW, NB == 2 ? 4 : 2) void k_fwd_xdma_dual(const
   } else {
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
-      PEA_DPROC((ps % NB) * BUF)
+      PEA_DPROC((ps % NBUF) * BUF)
       if (ps + 1 < NP) {
-        PEA_DWAIT(NB - 2 < NP - 2 - ps ? NB - 2 : NP - 2 - ps)
-        if (ps + NB < NP) PEA_DDMA(ps % NB, ps + NB)
+        PEA_DWAIT(NBUF - 2 < NP - 2 - ps ? NBUF - 2 : NP - 2 - ps)
+        if (ps + NBUF < NP) PEA_DDMA(ps % NBUF, ps + NBUF)
       }
     }
   }
 #undef PEA_DPROC
+#undef PEA_DPROC_E
+#undef PEA_DPROC_E2
+#undef PEA_DDMAH
+#undef PEA_DWAITL
 #undef PEA_DDMA
 #undef PEA_DDMA1
 #undef PEA_DWAIT

@@ -58,7 +58,7 @@ def timed(fn, n=50):
 
 two(); ref = [x.clone() for x in (affs, g0, gx, inv, l0, lx)]
 for rnd in range(3):
-    for name, env, fn in (("two launches", None, two), ("dual ring 2", "2", dual), ("dual ring 3", "3", dual)):
+    for name, env, fn in (("two launches", None, two), ("dual ring 2", "2", dual), ("dual ring 3", "3", dual), ("dual halves", "4", dual)):
         if env is not None:
             os.environ["PEA_FWD_DUAL"] = env
             pkg._lib.reload_env()

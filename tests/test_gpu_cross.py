@@ -492,7 +492,9 @@ def test_pair_backward_in_one_cross_launch(pkg, dev, orc, synth, shape, shifts):
 @pytest.mark.parametrize("shape,shifts,K,border,relu,nb", [((2, 50, 100), [1, 3, 5, 9, 27], 10, 0, True, "3"), ((2, 50, 100), [1, 3, 5, 9, 27], 10, 0, False, "2"),
                                                         ((1, 43, 96), [1, 3, 5, 9, 27], 10, 0, False, "3"), ((3, 64, 128), [1, 3, 5, 9, 27], 10, 1, False, "3"),
                                                         ((3, 64, 128), [1, 3, 5, 9, 27], 10, 1, True, "2"), ((2, 37, 72), [1, 3, 5, 9, 11], 8, 0, False, "3"),
-                                                        ((1, 96, 200), [1, 3, 5, 9, 27], 9, 0, False, "2"), ((2, 33, 68), [1], 2, 0, False, "3")])
+                                                        ((1, 96, 200), [1, 3, 5, 9, 27], 9, 0, False, "2"), ((2, 33, 68), [1], 2, 0, False, "3"),
+                                                        ((2, 50, 100), [1, 3, 5, 9, 27], 10, 0, True, "4"), ((3, 64, 128), [1, 3, 5, 9, 27], 10, 1, False, "4"),
+                                                        ((2, 37, 72), [1, 3, 5, 9, 11], 8, 0, False, "4")])
 def test_dual_forward_equals_the_two_launches(pkg, dev, orc, synth, monkeypatch, shape, shifts, K, border, relu, nb):
     """pea_affinity_fwd_dual_ex (csrc/pea_xdma_dual.h): the self loss and the detached-EMA cross loss of the same embedding on the
     same target / weight / mask as ONE forward launch -- every output BIT-identical to the two pea_affinity_fwd_ex calls it replaces

@@ -181,7 +181,7 @@ def test_full_size_loss_sections(pkg, dev, orc, synth, monkeypatch):
             assert torch.equal(a, b), which
         res[which] = (l1, p1, g1)
     l, pred, grads = res["one_node"]
-    for sw in ("0", "3"):  # two forward launches / the ring of three buffers: the same bits as the default one launch on a ring of two
+    for sw in ("0", "2", "3"):  # two forward launches / whole-buffer hand-offs / the ring of three: the same bits as the default (halves)
         monkeypatch.setenv("PEA_FWD_DUAL", sw)
         pkg._lib.reload_env()
         try:
