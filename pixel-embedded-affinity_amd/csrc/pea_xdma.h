@@ -220,20 +220,21 @@ struct DualArgs {
   const float* g_cross;     // [B, K, S] d loss_cross / d affs
   const float* dloss_cross;
 };
-// second phase of k_bwd_xdma<.., DUAL>: role-A pairs of the second operand into G (D = 16: NP = 8 chunk pairs), 2D, no z
-template <int TH, int TW, int PSU, bool CROP, int XP>
-__device__ __forceinline__ void bwd_phase_role_a(const KParams& P, const XParams& C, char* lds, const rsrc_t xB, const rsrc_t iB,
-                                                 const rsrc_t gB, const float dlx, const int y0, const int x0, const unsigned ezo,
-                                                 const unsigned ecs, f2 (&G)[8]) {
-  constexpr int NT = TH * TW, PS = PSU * 256, NP = 8;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
-  const int py = y0 + ly, px = x0 + lx;
-  const bool live = py < P.Y && px < P.X;
-  const unsigned po4 = (unsigned)(py * P.X + px) * 4u;
-  lds_barrier();  // every wave is done with the first phase's last chunk: the ring is free
+// second phase of k_bwd_xdma<.., DUAL>: role-A pairs of the second operand into G (D = 16: NP = 8 chunk pairs), 2D, no z.
+// Round 5: the phase no longer starts from an empty pipeline.  While the first phase gathers its last two chunks the kernel has
+// already requested this phase's 1 / norm plane (into plane 4, free behind chunk NP - 3), its g values (cx / cy: role A, the own
+// pixel) and its first chunk (into buffer 0, free behind chunk NP - 2) -- dual_geom / the hand-offs of k_bwd_xdma; here the
+// coefficients are formed at once, chunks 1 and 2 follow, and the ring runs as before.
+struct DualGeom {
   unsigned vo[2];
   bool act[2];
+  int npc;
+};
+template <int TH, int TW, bool CROP>
+__device__ __forceinline__ DualGeom dual_geom(const KParams& P, const XParams& C, const int y0, const int x0) {
+  constexpr int NT = TH * TW;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  DualGeom g;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int q = (s * (NT / 64) + wave) * 64 + lane;
@@ -248,50 +249,55 @@ __device__ __forceinline__ void bwd_phase_role_a(const KParams& P, const XParams
       gy = y0 + (k >> sh);
       gx = cc < C.split ? x0 + TW + cc : x0 - C.SW + cc;
     }
-    act[s] = q < C.QA;
+    g.act[s] = q < C.QA;
     bool oky, okx;
     gy = wrap1<CROP>(gy, P.Y, oky);
     gx = wrap1<CROP>(gx, P.X, okx);
-    vo[s] = (act[s] && oky && okx) ? (unsigned)(gy * P.X + gx) * 4u : kOOB;
+    g.vo[s] = (g.act[s] && oky && okx) ? (unsigned)(gy * P.X + gx) * 4u : kOOB;
   }
-  const int wbase = wave * 1024, w1 = wbase + (NT / 64) * 1024;
-  const int npc = 2 * ((__builtin_amdgcn_ballot_w64(act[0]) != 0) + (__builtin_amdgcn_ballot_w64(act[1]) != 0));
+  g.npc = 2 * ((__builtin_amdgcn_ballot_w64(g.act[0]) != 0) + (__builtin_amdgcn_ballot_w64(g.act[1]) != 0));
+  return g;
+}
+#define PEA_X2DMA(rsrc, plane_byte, so)                                                                                             \
+  {                                                                                                                                 \
+    if (DG.act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase2), 16, DG.vo[0], so, 0, 0); \
+    if (DG.act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + w12), 16, DG.vo[1], so, 0, 0);    \
+  }
+template <int TH, int TW, int PSU, bool CROP, int XP>
+__device__ __forceinline__ void bwd_phase_role_a(const KParams& P, const XParams& C, char* lds, const rsrc_t xB, const DualGeom& DG,
+                                                 float (&cx)[XP], float (&cy)[XP], const float dlx, const unsigned ezo,
+                                                 const unsigned ecs, f2 (&G)[8]) {
+  constexpr int NT = TH * TW, PS = PSU * 256, NP = 8;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
+  const int wbase2 = wave * 1024, w12 = wbase2 + (NT / 64) * 1024;
+  const int npc = DG.npc;
 #define PEA_X2WAIT1()                                                                            \
   {                                                                                              \
     if (npc == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
     else if (npc == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                \
   }
-#define PEA_X2DMA(rsrc, plane_byte, so)                                                                                          \
-  {                                                                                                                              \
-    if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, 0);    \
-    if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + w1), 16, vo[1], so, 0, 0);       \
-  }
-  PEA_X2DMA(iB, 4 * PS, ezo)
-  PEA_X2DMA(xB, 0, ezo)
-  PEA_X2DMA(xB, PS, ezo + ecs)
-  const unsigned pg = live ? po4 : kOOB;  // role A: g at the own pixel
-  float cx[XP], cy[XP];
   int ax[XP], ay[XP];
   const int vown = ((C.hy0 + ly) * TW + lx) * 4;
   const int hrow = (C.QV * 4 + ly * C.SW) * 4;
 #pragma unroll
   for (int k = 0; k < XP; ++k) {
-    cx[k] = bl32(gB, k < C.npx ? pg : kOOB, ezo + (unsigned)C.xgi[k] * ecs);
     const int d = C.xd[k], c = lx + d;
     ax[k] = (unsigned)c < (unsigned)TW ? vown + d * 4 : hrow + (c & C.xm[k]) * 4;
-    cy[k] = bl32(gB, k < C.npy ? pg : kOOB, ezo + (unsigned)C.ygi[k] * ecs);
     ay[k] = vown + C.yd[k] * TW * 4;
   }
-  PEA_X2DMA(xB, 2 * PS, ezo + 2u * ecs)
-  PEA_X2DMA(xB, 3 * PS, ezo + 3u * ecs)
-  PEA_X2WAIT1()
+  // every wave is done with the first phase's last chunk; this phase's 1 / norm plane, g values and first chunk -- requested one and
+  // two chunks ago -- have landed
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
   for (int k = 0; k < XP; ++k) {
     cx[k] *= fabsf(*(const float*)(lds + 4 * PS + ax[k])) * dlx;
     cy[k] *= fabsf(*(const float*)(lds + 4 * PS + ay[k])) * dlx;
     asm volatile("" : "+v"(cx[k]), "+v"(cy[k]));
   }
+  PEA_X2DMA(xB, 2 * PS, ezo + 2u * ecs)  // chunk 1 into buffer 1 (the first phase's last chunk is done)
+  PEA_X2DMA(xB, 3 * PS, ezo + 3u * ecs)
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the inv plane is dead: buffer 2 may be filled
   PEA_X2DMA(xB, 4 * PS, ezo + 4u * ecs)
   PEA_X2DMA(xB, 5 * PS, ezo + 5u * ecs)
@@ -326,7 +332,6 @@ __device__ __forceinline__ void bwd_phase_role_a(const KParams& P, const XParams
       }
     }
   }
-#undef PEA_X2DMA
 #undef PEA_X2WAIT1
 }
 
@@ -399,6 +404,16 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
     vo[s] = (act[s] && oky && okx) ? (unsigned)(gy * P.X + gx) * 4u : kOOB;
   }
   const int wbase = wave * 1024;  // this wave's first block inside a plane; its second one is NW KiB further
+  // DUAL: the second phase's staging geometry, buffers and g registers (requested from the first phase's last hand-offs)
+  DualGeom DG = {};
+  float cx2[DUAL ? XP : 1], cy2[DUAL ? XP : 1];
+  rsrc_t x2B = xB, i2B = xB, g2B = xB;
+  if constexpr (DUAL) {
+    DG = dual_geom<TH, TW, CROP>(P, Q.C2, y0, x0);
+    x2B = mkbuf(Q.ema + (size_t)b * D_T * S);
+    i2B = mkbuf(Q.inv_other + (size_t)b * S);
+    g2B = mkbuf(Q.g_cross + (size_t)b * P.K * S);
+  }
   // SDMA (the 3D instantiation): every wave issues BOTH slots for every plane, unconditionally -- a wave without a second block
   // repeats its first one (same bytes to the same place), the tail lanes of the last block write zeros into the plane's
   // padding.  The count of DMA instructions per chunk is then a compile-time 4, which is what lets the compiler wait for the
@@ -634,7 +649,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       v.x = *(const float*)(lds + bo + ax[k]);
       v.y = *(const float*)(lds + bo + PS + ax[k]);
       acc = __builtin_elementwise_fma((f2){cx[k], cx[k]}, v, acc);
-      if (k % 5 == 4) asm volatile("" ::: "memory");  // bound the ds_read hoisting
+      if (k % (DUAL ? 2 : 5) == (DUAL ? 1 : 4)) asm volatile("" ::: "memory");  // bound the ds_read hoisting (DUAL: the second phase's 20 g registers are live too)
     }
 #pragma unroll
     for (int k = 0; k < XP; ++k) {
@@ -644,7 +659,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       v.x = *(const float*)(lds + bo + ay[k]);
       v.y = *(const float*)(lds + bo + PS + ay[k]);
       acc = __builtin_elementwise_fma((f2){cy[k], cy[k]}, v, acc);
-      if (k % 5 == 4) asm volatile("" ::: "memory");
+      if (k % (DUAL ? 2 : 5) == (DUAL ? 1 : 4)) asm volatile("" ::: "memory");
     }
 #else
     acc.x = cx[ps % XP] + cy[ps % XP];
@@ -672,6 +687,22 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
         PEA_XDMA(xB, bo + PS, ezo + (unsigned)(2 * ps + 7) * ecs)
       }
 #endif
+      if constexpr (DUAL) {  // the second phase's first requests ride in the ring slots the first phase no longer needs (see bwd_phase_role_a)
+        const int wbase2 = wbase, w12 = wbase + (NT / 64) * 1024;
+        if (ps == NP - 3) {  // buffer 2 is free: the second operand's 1 / norm plane into plane 4, and the cross loss' g values
+          PEA_X2DMA(i2B, 4 * PS, ezo)
+          const unsigned pg2 = live ? po4 : kOOB;  // role A: g at the own pixel
+#pragma unroll
+          for (int k = 0; k < XP; ++k) {
+            cx2[k] = bl32(g2B, k < Q.C2.npx ? pg2 : kOOB, ezo + (unsigned)Q.C2.xgi[k] * ecs);
+            cy2[k] = bl32(g2B, k < Q.C2.npy ? pg2 : kOOB, ezo + (unsigned)Q.C2.ygi[k] * ecs);
+          }
+        }
+        if (ps == NP - 2) {  // buffer 0 is free: the second phase's chunk 0
+          PEA_X2DMA(x2B, 0, ezo)
+          PEA_X2DMA(x2B, PS, ezo + ecs)
+        }
+      }
       PEA_STAMP(5 + 3 * ps)
     }
   }
@@ -685,9 +716,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   if constexpr (DUAL) {
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) G[ps] = G[ps] * dl;
-    bwd_phase_role_a<TH, TW, PSU, CROP, XP>(P, Q.C2, lds, mkbuf(Q.ema + (size_t)b * D_T * S), mkbuf(Q.inv_other + (size_t)b * S),
-                                            mkbuf(Q.g_cross + (size_t)b * P.K * S), Q.dloss_cross ? Q.dloss_cross[0] : 1.f, y0, x0, ezo,
-                                            ecs, G);
+    bwd_phase_role_a<TH, TW, PSU, CROP, XP>(P, Q.C2, lds, x2B, DG, cx2, cy2, Q.dloss_cross ? Q.dloss_cross[0] : 1.f, ezo, ecs, G);
   }
   if (KEEP) {
 #pragma unroll

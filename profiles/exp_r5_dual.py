@@ -46,14 +46,18 @@ def bwd():
     assert L.pea_affinity_bwd_dual_ex(ctypes.byref(d0), P(E), P(EO), P(g0), P(gx), P(inv[0]), P(inv[1]), P(one), P(one), P(dE), st) == 0
 
 
+BWD_US = [0.0]
+
+
 def timed(fn, n=50):
     for _ in range(5):
         fn(); bwd()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(n)]
-    for a, b in ev:
-        a.record(); fn(); b.record(); bwd()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
+    for a, b, c in ev:
+        a.record(); fn(); b.record(); bwd(); c.record()
     torch.cuda.synchronize()
-    return sum(a.elapsed_time(b) for a, b in ev) / n * 1e3
+    BWD_US[0] = sum(b.elapsed_time(c) for a, b, c in ev) / n * 1e3
+    return sum(a.elapsed_time(b) for a, b, c in ev) / n * 1e3
 
 
 two(); ref = [x.clone() for x in (affs, g0, gx, inv, l0, lx)]
@@ -64,4 +68,4 @@ for rnd in range(3):
             pkg._lib.reload_env()
         us = timed(fn)
         same = all(torch.equal(a, b) for a, b in zip((affs, g0, gx, inv, l0, lx), ref))
-        print("round %d  %-14s %7.1f us (forward pair inside the alternating forward / dual backward step)   bit-equal to the two launches: %s" % (rnd, name, us, same), flush=True)
+        print("round %d  %-14s %7.1f us (forward pair inside the alternating forward / dual backward step)   bit-equal to the two launches: %s   [pair backward %.1f us]" % (rnd, name, us, same, BWD_US[0]), flush=True)
