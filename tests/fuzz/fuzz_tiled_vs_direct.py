@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised agreement sweep: the LDS-tiled kernels (default dispatch) against the direct kernels (PEA_FORCE_DIRECT=1)
 on shapes wide enough for the tiles: D in {16, 32, 64}, f32 / f16, self / EMA (with and without a gradient for the second
-operand), 2D circular / 3D cropped, random stencils (both signs, up to +-30), masks on / off, every normaliser.
+operand), 2D circular / 3D cropped / replicate (f32), random stencils (both signs, up to +-30), masks on / off, every normaliser.
 Prints the worst deviations; exits non-zero on a disagreement.  usage: fuzz_tiled_vs_direct.py [cases] [seed]"""
 import importlib, os, sys
 import numpy as np, torch
@@ -33,6 +33,8 @@ for it in range(ncase):
             o[2] = -1
         offs.append(o)
     border = 1 if three_d else int(rng.integers(0, 2))
+    if not f16 and rng.random() < 0.3:
+        border = 2  # REPLICATE (embedding_loss_norm6): the clamped region of the tiled kernels at f32, D = 16 against the global-memory kernels
     norm = int(rng.integers(0, 3))
     lam = [float(v) for v in rng.uniform(0.25, 2.0, K)]
     shape_e, shape_k = [B, D] + dims, [B, K] + dims
