@@ -179,9 +179,10 @@ class _TensorSection(torch.autograd.Function):
             with fork:  # the deep-supervision scales, on their own stream beside the full-resolution pair
                 for j in range(1, jx):
                     e_c = op._embedding_arg(embs[j], "embedding")
-                    # (no 1 / norm plane and no raw map for the small scales: their grids are launch-sized, the tiled backward that
-                    #  computes the norms itself is one launch and one allocation less; the march kernels need >= 256 tile columns)
-                    d, g, _, inv, raw = forward_one(j, e_c, None, False, 0)
+                    # (the 1 / norm plane goes along wherever the cross backward takes the scale -- 272^2 down to 68^2 -- : round 4 kept
+                    #  the small scales on the tiled backward "because their grids are launch-sized"; measured in round 5 the cross
+                    #  backward is worth 36 us of the section, profiles/r5_section_small.txt.  No raw map: D = 16 reads none.)
+                    d, g, _, inv, raw = forward_one(j, e_c, None, False, 1)
                     small.append(backward_one(j, d, e_c, None, g, inv, raw=raw))
             e0 = op._embedding_arg(embs[0], "embedding")
             ema_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e0.dtype)
