@@ -11,10 +11,10 @@ for W in one_node labels; do
 import csv, glob, os, sys
 f = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-# bursts: a gap of > 200 us between one kernel's end and the next one's start separates the calls (each drained by a synchronize)
+# bursts: a gap of > 150 us between one kernel's end and the next one's start separates the calls (each drained by a synchronize)
 bursts, cur = [], []
 for r in rows:
-    if cur and int(r["Start_Timestamp"]) - max(int(x["End_Timestamp"]) for x in cur) > 200000:
+    if cur and int(r["Start_Timestamp"]) - max(int(x["End_Timestamp"]) for x in cur) > 150000:
         bursts.append(cur); cur = []
     cur.append(r)
 bursts.append(cur)
