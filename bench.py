@@ -44,6 +44,9 @@ CONFIGS = {
                shifts=[1, 3, 5, 9, 11], K=10, f16=False),
     "c4": dict(what="BASELINE configs[3]: AC3/AC4 embedding_loss_norm5 fwd+bwd, one 24x1024x1024 sub-volume per GPU, the reference's 12 axis offsets",
                ndim=3, B=1, D=16, dims=(24, 1024, 1024), stencil="norm5", K=12, f16=False),
+    # the shape the reference TRAINS on (scripts_ac3ac4/config/ac3ac4.yaml:52 batch_size 2; data_provider_labeled_deep.py:53 crops of 18 x 160 x 160)
+    "c4crop": dict(what="BASELINE configs[3], the reference's training crops: AC3/AC4 embedding_loss_norm5 fwd+bwd on 18x160x160 crops, batch 2",
+                   ndim=3, B=2, D=16, dims=(18, 160, 160), stencil="norm5", K=12, f16=False),
     "c4n26": dict(what="BASELINE configs[3]: AC3/AC4 sub-volume 24x1024x1024, synthetic 26-neighbourhood (CROP_ZERO, cropped normaliser)",
                   ndim=3, B=1, D=16, dims=(24, 1024, 1024), stencil="n26", K=26, f16=False),
     "c5": dict(what="BASELINE configs[4]: D=64 embedding_loss fwd+bwd, f16 storage / f32 accumulate, offsets[:8]", ndim=2, B=8, D=64, dims=(544, 544),
@@ -141,12 +144,17 @@ def train_leg(pkg, dev, world, rank, dist, shared, fence, b=2, steps=8, warm=3):
                              "loss": float(loss.item())}}
 
 
-def other_config(args, pkg, dev, world, rank, dist, fence):
+def other_config(args, pkg, dev, world, rank, dist, fence, cname=None, compact=False):
     """--config c3 | c4 | c4n26 | c5: same step timing, roofline (from the entry points' in-step HIP-event durations) and a
     bounded cpu_baseline; inputs are drawn on the GPU (torch.Generator, seed 555 + rank): N(0,1) embeddings,
-    Bernoulli(0.6) targets, U(0.5,1.5) weights, Bernoulli(0.9) masks (2D)."""
-    c = CONFIGS[args.config]
-    B, Dm, dims, K = (args.batch if args.batch != B_PER_GPU else c["B"]), c["D"], list(c["dims"]), c["K"]
+    Bernoulli(0.6) targets, U(0.5,1.5) weights, Bernoulli(0.9) masks (2D).
+    compact=True (the default run's "configs" field: every BASELINE config inside the line the driver records): the same step and
+    in-step kernel timing on batches of COMPACT_STEPS steps, GPU legs only -- no autograd-seed / graph / CPU legs -- returned as
+    {ms_per_step, ms_min, ms_max, kernel_ms, frac, pair_frac, traffic, workload}."""
+    cname = cname or args.config
+    c = CONFIGS[cname]
+    steps = COMPACT_STEPS if compact else args.steps
+    B, Dm, dims, K = (args.batch if (args.batch != B_PER_GPU and not compact) else c["B"]), c["D"], list(c["dims"]), c["K"]
     g = torch.Generator(device=dev).manual_seed(555 + rank)
     E = torch.randn([B, Dm] + dims, generator=g, device=dev)
     if c["f16"]:
@@ -183,11 +191,11 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
         loss, affs, _ = op.FusedAffinityMSE.apply(E, E2, T, Wt, M, spec)
         pkg.backward(loss)  # loss.backward() seeded with a cached ones-scalar (no per-step fill kernel)
 
-    settle = settle_gpu(step)
-    for _ in range(max(args.warmup, 3)):
+    settle = settle_gpu(step, 0.6 if compact else 1.5)
+    for _ in range(3 if compact else max(args.warmup, 3)):
         step()
-    bst = batch_stats(timed_batches(step, fence, args.steps, dist, dev), args.steps)  # median of N_BATCHES batches (see main())
-    dt = bst["median"] * 1e-3 * args.steps
+    bst = batch_stats(timed_batches(step, fence, steps, dist, dev), steps)  # median of N_BATCHES batches (see main())
+    dt = bst["median"] * 1e-3 * steps
     # the same step started with plain loss.backward() -- what a drop-in caller of INTEGRATION.md section 2 executes (autograd seeds
     # the scalar's backward with a ones_like fill kernel); untimed for `value`, reported beside it
     def step_seed():
@@ -195,9 +203,9 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
         loss, affs, _ = op.FusedAffinityMSE.apply(E, E2, T, Wt, M, spec)
         loss.backward()
 
-    dt_seed = wall_time_s(step_seed, fence, args.steps)
+    dt_seed = None if compact else wall_time_s(step_seed, fence, steps)
     npx = B * int(np.prod(dims))
-    value = world * npx * args.steps / dt / 1e6
+    value = world * npx * steps / dt / 1e6
     if rank != 0:
         return None
     Ed = E.detach()
@@ -219,27 +227,33 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
     raw_in = P(affs) if (not ema or L.pea_cross_supported(ctypes.byref(desc), 4)) else None
     bwd = lambda: L.pea_affinity_bwd_ex2(ctypes.byref(desc), P(Ed), P(E2), P(G), P(INV), raw_in, P(one), P(dE), None, cur())
     in_step_times_ms(fwd, bwd, 3)
-    kf, kb, kspread = in_step_batches_ms(fwd, bwd, max(10, min(args.steps, 50)), nb=5)
+    kf, kb, kspread = in_step_batches_ms(fwd, bwd, max(10, min(steps, 50)), nb=5)
     ab = algorithmic_bytes_per_px(Dm, K, 2 if c["f16"] else 4, mask=M is not None, ema=ema)
     dom = "bwd" if kb >= kf else "fwd"
     achieved = ab[dom] * npx / (max(kf, kb) * 1e-3) / 1e9
     step_gbs = ab["step"] * npx / ((kf + kb) * 1e-3) / 1e9
+    if compact:
+        return {"workload": "%s: B=%d x D=%d x %s, K=%d" % (c["what"], B, Dm, "x".join(str(v) for v in dims), K),
+                "ms_per_step": round(bst["median"], 5), "ms_min": round(bst["min"], 5), "ms_max": round(bst["max"], 5),
+                "mpx_s": round(value, 1), "kernel_ms": {"fwd": round(kf, 5), "bwd": round(kb, 5)}, "dominant": dom,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "pair_frac": round(step_gbs / HBM_PEAK_GBS, 4),
+                "traffic": pmc_traffic(cname, dom)}
     out = {
         "metric": "affinity-map Mpixels/sec (fwd+bwd)", "value": round(value, 2), "unit": "Mpx/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
+        "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 5),
         "ms_min": round(bst["min"], 5), "ms_max": round(bst["max"], 5), "batches_ms": bst["all"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 storage / f32 arithmetic" if c["f16"] else "f32",
         "data": "synthetic",
         "config": {"workload": "%s: B=%d per GPU x D=%d x %s, K=%d offsets" % (c["what"], B, Dm, "x".join(str(v) for v in dims), K),
                    "images_per_gpu": B, "embedding_dim": Dm, "dims": dims, "offsets": K, "sharding": "batch across ranks, no data-path collective"},
-        "ms_per_step_autograd_seed": round(dt_seed / args.steps * 1e3, 5), "settle_steps": settle,
+        "ms_per_step_autograd_seed": round(dt_seed / steps * 1e3, 5), "settle_steps": settle,
         "kernel_ms": {"fwd": round(kf, 5), "bwd": round(kb, 5)}, "kernel_ms_spread": kspread,
         # the launch floor as a number: the entry points' launches (forward + loss finish + backward) captured in a
         # HIP graph and replayed back to back -- no Python, no ctypes, no autograd between them
-        "graph_replay_ms": graph_replay_ms(fwd, bwd, max(20, min(args.steps, 200))),
+        "graph_replay_ms": graph_replay_ms(fwd, bwd, max(20, min(steps, 200))),
         # the same step through the PUBLIC API captured with pea.graphed (one graph launch per step: no Python / ctypes / autograd
         # bookkeeping per launch) -- what a caller of a small, static shape gets; host wall time per replay, replays queued back to back
-        "graphed_api_ms": graphed_api_ms(pkg, op, E, E2, T, Wt, M, spec, max(20, min(args.steps, 200))),
+        "graphed_api_ms": graphed_api_ms(pkg, op, E, E2, T, Wt, M, spec, max(20, min(steps, 200))),
         "cross_kernels": ({"fwd+bwd (second operand)": int(L.pea_cross_supported(ctypes.byref(desc), 2))} if ema else
                           {"fwd": int(L.pea_cross_supported(ctypes.byref(desc), 0)), "bwd": int(L.pea_cross_supported(ctypes.byref(desc), 1))}),
         "roofline": {"bound": "hbm", "kernel": "pea_affinity_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -265,8 +279,92 @@ def other_config(args, pkg, dev, world, rank, dist, fence):
             sl = (slice(0, 1), slice(None), slice(None), slice(0, 256), slice(0, 256))
             out["cpu_baseline"] = cpu_baseline(None, Ed[sl].float().cpu().contiguous(), T[:, :12][sl].cpu().contiguous(), Wt[:, :12][sl].cpu().contiguous(),
                                                None, shifts3d=pkg.utils.affinity_ours.NORM5_SHIFTS,
-                                               what="a 24x256x256 block of the sub-volume with the norm5 stencil (K=12)",
+                                               what=("a %dx%dx%d block of the sub-volume with the norm5 stencil (K=12)" % tuple(min(a, b) for a, b in zip(dims, (24, 256, 256))))
+                                               if cname != "c4crop" else "one 18x160x160 crop of the batch with the norm5 stencil (K=12)",
                                                ema=None if E2 is None else E2[sl].float().cpu().contiguous())
+    return out
+
+
+COMPACT_STEPS = 20  # steps per timed batch of the default run's "configs" leg (21 batches each: n_batches)
+# the default run's "configs" field: every BASELINE.json config that fits one GPU beside the headline (c2), the EMA cross loss of the
+# headline shape and the reference's 3D training crops
+LINE_CONFIGS = ("c1", "c3", "c4", "c5", "c2ema", "c4crop")
+
+
+def best_event_us(run, calls=10, rounds=3, warm=3):
+    """best of `rounds` batches of `calls` calls, HIP events on the launch stream, in microseconds per call (a one-off allocator stall
+    inside a batch is not the section's cost)"""
+    for _ in range(warm):
+        run()
+    return round(min(event_time_ms(run, calls) for _ in range(rounds)) * 1e3, 1)
+
+
+def graphed_us(pkg, fn, xs, replays=20, rounds=3):
+    """fn(*xs) captured once through the public API (pea.graphed: every stream of the section becomes one graph launch) and replayed back
+    to back; wall clock per replay in microseconds, best of `rounds` batches.  None if the capture fails."""
+    try:
+        g = pkg.graphed(fn, *xs)
+        best = None
+        for _ in range(rounds):
+            g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(replays):
+                g.replay()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / replays
+            best = ms if best is None else min(best, ms)
+        del g
+        return round(best * 1e6, 1)
+    except Exception as ex:  # noqa: BLE001 -- an extra field, never the headline
+        print("section capture failed: %r" % (ex,), file=sys.stderr)
+        return None
+
+
+def ac3ac4_section_us(pkg, dev, rank, B=2, dims=(18, 160, 160)):
+    """The 3D training loop's loss section at the shape the reference trains on (scripts_ac3ac4/main.py:219-237; ac3ac4.yaml:52 batch 2,
+    data_provider_labeled_deep.py:53 crops of 18 x 160 x 160; deep supervision at 1/2 .. 1/16 in y and x, :225-232): embedding_loss_norm5 +
+    ema_embedding_loss_norm5 + four embedding_loss_norm1 + backward + border fill + relu.  Microseconds per section: one autograd node
+    (eager / captured with pea.graphed), the call-by-call composition (what INTEGRATION.md section 2's import-line change runs), and the
+    in-step kernel sum of the six losses' entry points for comparison."""
+    g = torch.Generator(device=dev).manual_seed(900 + rank)
+    Z, Y, X = dims
+    crit = pkg.WeightedMSE()
+    emb = torch.randn(B, 16, Z, Y, X, generator=g, device=dev)
+    ema = torch.randn(B, 16, Z, Y, X, generator=g, device=dev)
+    emds = [torch.randn(B, 16, Z, Y >> j, X >> j, generator=g, device=dev) for j in (4, 3, 2, 1)]  # emd1 (1/16) .. emd4 (1/2)
+    target = (torch.rand(B, 12, Z, Y, X, generator=g, device=dev) < 0.6).float()
+    weight = torch.rand(B, 12, Z, Y, X, generator=g, device=dev) + 0.5
+    downs = [torch.cat([(torch.rand(B, 3, Z, Y >> j, X >> j, generator=g, device=dev) < 0.6).float(),
+                        torch.rand(B, 3, Z, Y >> j, X >> j, generator=g, device=dev) + 0.5], dim=1) for j in (1, 2, 3, 4)]  # down1 .. down4
+
+    def run(which):
+        xs = [emb.detach().requires_grad_(True)] + [e.detach().requires_grad_(True) for e in emds]
+        fn = pkg.ac3ac4_loss_section if which == "one_node" else pkg.ac3ac4_loss_section_composed
+        loss, pred = fn(xs[0], xs[1:], ema, target, weight, downs, crit, embedding_mode=5)
+        loss.backward()
+        pkg.finish_pred_3d_(pred)
+
+    out = {"shape": "B=%d x 16 x %dx%dx%d, norm5 + ema_norm5 + 4 x norm1 (1/16 .. 1/2 in y, x)" % (B, Z, Y, X)}
+    for which in ("composed", "one_node"):
+        out[which] = best_event_us(lambda: run(which))
+    for which in ("one_node", "composed"):
+        xs = [emb.detach().clone().requires_grad_(True)] + [e.detach().clone().requires_grad_(True) for e in emds]
+
+        def fn(*xs):
+            for t in xs:
+                t.grad = None
+            f = pkg.ac3ac4_loss_section if which == "one_node" else pkg.ac3ac4_loss_section_composed
+            loss, pred = f(xs[0], list(xs[1:]), ema, target, weight, downs, crit, embedding_mode=5)
+            loss.backward()
+            return (loss, pkg.finish_pred_3d_(pred)) + tuple(t.grad for t in xs)
+        out[which + "_graphed"] = graphed_us(pkg, fn, xs)
+    # algorithmic bytes of the six losses (SURVEY 8d, 3D: 12D + 20K per voxel; the cross loss + 8D) at 8 TB/s
+    vox = B * Z * Y * X
+    small = sum(B * Z * (Y >> j) * (X >> j) for j in (1, 2, 3, 4))
+    abytes = vox * (12 * 16 + 20 * 12) + vox * (20 * 16 + 20 * 12) + small * (12 * 16 + 20 * 3)
+    out["algorithmic_MB"] = round(abytes / 1e6, 1)
+    out["roofline_us"] = round(abytes / (HBM_PEAK_GBS * 1e9) * 1e6, 1)
     return out
 
 
@@ -508,8 +606,8 @@ def in_step_batches_ms(fwd, bwd, iters, nb=N_BATCHES):
 # profiled one may be running.  (Round-4 advice: the bare PEA_ prefix also caught PEA_BENCH_EXTRA, PEA_STEPS, ... and silently nulled
 # the roofline's traffic field.)
 KERNEL_SWITCHES = ("PEA_FORCE_DIRECT", "PEA_FWD_XDMA", "PEA_BWD_XDMA", "PEA_LABELS_DUAL", "PEA_FWD_WG3", "PEA_INFER_XDMA", "PEA_BWD_PF", "PEA_BOX",
-                   "PEA_H16_HW", "PEA_ZMARCH", "PEA_ZSEG", "PEA_ZM_NB", "PEA_BOXM", "PEA_XCD_STAGGER", "PEA_SKEW", "PEA_SKEW_SLOTS", "PEA_SKEW_MODE",
-                   "PEA_WALK2D", "PEA_LDS_PAD", "PEA_ZBLK_Y", "PEA_ZBLK_X", "PEA_BWD_REV", "PEA_BWD_W3", "PEA_BWD_VEC", "PEA_FWD_DUAL", "PEA_HIP_LIB")
+                   "PEA_H16_HW", "PEA_ZMARCH", "PEA_ZSEG", "PEA_ZM_NB", "PEA_ZM_SUP", "PEA_BOXM", "PEA_ZBLK_Y", "PEA_ZBLK_X", "PEA_BWD_REV",
+                   "PEA_FWD_DUAL", "PEA_HIP_LIB")
 
 
 def pmc_traffic(key, dom):
@@ -634,6 +732,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="c2 = the headline workload (default); c3 / c4 / c4n26 / c5: see CONFIGS")
     ap.add_argument("--no-train", action="store_true", help="skip the train imgs/s leg (backbone + DDP)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the default run's `configs` leg (every other BASELINE config, compact)")
     ap.add_argument("--no-section", action="store_true",
                     help="skip the multi-scale loss-section timings (profiling runs: per-kernel averages then cover the full-size launches only)")
     args = ap.parse_args()
@@ -829,37 +928,26 @@ def main():
                 out[which] = round(min(event_time_ms(lambda: run(which), 10) for _ in range(3)) * 1e3, 1)
             # the same two sections captured through the public API (pea.graphed: both streams of the section become one graph launch,
             # the ~25 launches' Python / ctypes / autograd time is gone); wall clock around 20 replays back to back
-            for which in ("one_node", "labels"):
-                try:
-                    xs = [e.detach().clone().requires_grad_(True) for e in embs]
+            # (composed_graphed: INTEGRATION.md section 2's drop-in sequence -- import lines only -- under pea.graphed)
+            for which in ("one_node", "labels", "composed"):
+                xs = [e.detach().clone().requires_grad_(True) for e in embs]
 
-                    def fn(*xs):
-                        for t in xs:
-                            t.grad = None
-                        if which == "labels":
-                            loss, pred, _ = pkg.cvppp_loss_section_from_labels(xs[0], list(xs[1:]), ema, labs[0], labs[1:], crit, offsets,
-                                                                               nb_half, relu_pred=True)
-                        else:
-                            loss, pred, _ = pkg.cvppp_loss_section(xs[0], list(xs[1:]), ema, tt, ww, mm, downs, crit, offsets, nb_half,
-                                                                   relu_pred=True)
-                        loss.backward()
-                        return (loss, pred) + tuple(t.grad for t in xs)
-                    g = pkg.graphed(fn, *xs)
-                    best = None
-                    for _ in range(3):
-                        g.replay()
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        for _ in range(20):
-                            g.replay()
-                        torch.cuda.synchronize()
-                        ms = (time.perf_counter() - t0) / 20
-                        best = ms if best is None else min(best, ms)
-                    out[which + "_graphed"] = round(best * 1e6, 1)
-                    del g
-                except Exception as ex:  # noqa: BLE001 -- an extra field, never the headline
-                    out[which + "_graphed"] = None
-                    print("section capture (%s) failed: %r" % (which, ex), file=sys.stderr)
+                def fn(*xs):
+                    for t in xs:
+                        t.grad = None
+                    if which == "labels":
+                        loss, pred, _ = pkg.cvppp_loss_section_from_labels(xs[0], list(xs[1:]), ema, labs[0], labs[1:], crit, offsets,
+                                                                           nb_half, relu_pred=True)
+                    elif which == "one_node":
+                        loss, pred, _ = pkg.cvppp_loss_section(xs[0], list(xs[1:]), ema, tt, ww, mm, downs, crit, offsets, nb_half,
+                                                               relu_pred=True)
+                    else:
+                        loss, pred, _ = pkg.cvppp_loss_section_composed(xs[0], list(xs[1:]), ema, tt, ww, mm, downs, crit, offsets, nb_half)
+                    loss.backward()
+                    if which == "composed":
+                        pred = pkg.finish_pred_2d_(pred)
+                    return (loss, pred) + tuple(t.grad for t in xs)
+                out[which + "_graphed"] = graphed_us(pkg, fn, xs)
             return out
 
         kt_iso = {name: isolated_time_ms(fn, 20) for name, fn in (("fwd", fwd), ("bwd", bwd))}
@@ -867,6 +955,22 @@ def main():
         in_step_times_ms(fwd, bwd, 10)
         kt["fwd"], kt["bwd"], kspread = in_step_batches_ms(fwd, bwd, max(20, min(args.steps, 200)))
         section = None if args.no_section else section_us()
+        section3d = None
+        if not args.no_section:
+            try:
+                section3d = ac3ac4_section_us(pkg, dev, rank)
+            except Exception as ex:  # noqa: BLE001 -- an extra field, never the headline
+                section3d = {"error": repr(ex)[:300]}
+        # every other BASELINE config inside the driver's line (GPU legs only; rank 0 of a one-GPU run: the driver's BENCH command)
+        configs_line = None
+        if world == 1 and not args.no_configs:
+            configs_line = {}
+            for cn in LINE_CONFIGS:
+                try:
+                    configs_line[cn] = other_config(args, pkg, dev, world, rank, None, fence, cname=cn, compact=True)
+                except Exception as ex:  # noqa: BLE001
+                    configs_line[cn] = {"error": repr(ex)[:300]}
+                torch.cuda.empty_cache()
         ab = algorithmic_bytes_per_px(D, K)
         dom = "bwd" if kt["bwd"] >= kt["fwd"] else "fwd"
         launch_bytes = ab[dom] * B * H * W
@@ -904,6 +1008,8 @@ def main():
             "infer_mpx_s": round(B * H * W / (kt["infer"] * 1e-3) / 1e6, 1),
             "labels_step_mpx_s": round(B * H * W / (kt["labels_step"] * 1e-3) / 1e6, 1),
             "loss_section_us": section,
+            "ac3ac4_section_us": section3d,
+            "configs": configs_line,
             "roofline": {"bound": "hbm", "kernel": "pea_affinity_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_px": ab[dom], "px_per_launch": B * H * W,

@@ -127,10 +127,11 @@ size_t pea_workspace_bytes(const PeaDesc *desc);
 int pea_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
 
 /* Re-read the PEA_* environment switches (they are read once, at the first call): PEA_FORCE_DIRECT, PEA_FWD_XDMA, PEA_BWD_XDMA,
- * PEA_LABELS_DUAL, PEA_FWD_WG3, PEA_INFER_XDMA, PEA_BWD_PF, PEA_BOX, PEA_H16_HW, PEA_ZMARCH, PEA_ZSEG, PEA_ZBLK_Y / _X, PEA_WALK2D,
- * PEA_LDS_PAD, PEA_BWD_REV, PEA_BWD_W3, PEA_BWD_VEC -- A/B and debugging switches (csrc/pea_host.h says what each does); tests that
- * change one call this.  Memoised launch plans are dropped with it.  Safe against launches on other threads: the switch set is
- * replaced as a whole, a concurrent launch sees the old set or the new one. */
+ * PEA_LABELS_DUAL, PEA_FWD_WG3, PEA_INFER_XDMA, PEA_BWD_PF, PEA_BOX, PEA_BOXM, PEA_H16_HW, PEA_ZMARCH, PEA_ZSEG, PEA_ZM_NB, PEA_ZM_SUP,
+ * PEA_ZBLK_Y / _X, PEA_BWD_REV, PEA_FWD_DUAL -- A/B and debugging switches (csrc/pea_host.h says what each does); tests that change
+ * one call this.  Memoised launch plans are dropped with it.  The switch set is replaced as a whole (no half-written set is ever
+ * seen), but one entry point may read it more than once: a launch that runs CONCURRENTLY with a reload may mix the two sets.
+ * Call it between launches (tests and A/B runs do). */
 void pea_reload_env(void);
 
 /* Inference: affs[B,K,Z,Y,X] only.  e_other may be NULL. */

@@ -224,6 +224,8 @@ int pea_affinity_fwd_dual_ex(const PeaDesc* desc, const PeaDesc* desc_cross, con
     return PEA_E_ALIGN;
   if (!workspace || !workspace_cross || workspace == workspace_cross || workspace_bytes < kStateBytes) return PEA_E_WORKSPACE;
   if (e == ema) return PEA_E_UNSUPPORTED;  // (an aliased second operand is a self loss twice: the two calls handle it)
+  // ONE kernel writes both losses' outputs: aliased outputs would interleave (the two calls this replaces give the last writer's)
+  if (g_out == g_cross_out || inv_norm_out == inv_norm_other_out || loss_out == loss_cross_out) return PEA_E_DESC;
   const KParams P = make_params(desc), P2 = make_params(desc_cross);
   hipStream_t s = (hipStream_t)stream;
   FwdArgs A = {}, A2 = {};

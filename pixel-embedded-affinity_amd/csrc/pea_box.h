@@ -52,8 +52,7 @@ constexpr int kBoxBias = kBoxRP * 4 + (kBoxRW + 1) * 4;  // 3044 = -box_lds(0): 
 
 struct BParams {
   int tiles_y, tiles_x, tiles_per_plane, ntiles, tiles_per_xcd;
-  int stagger, rev, zrun, zgy, zgx; // the tile walk of pea_xdma.h (xdma_tile)
-  int skew, skew_slots, skew_mode;  // PEA_SKEW (pea_xdma.h xdma_tile)
+  int rev, zrun, zgy, zgx, sup_y, sup_x;  // the tile walk of pea_xdma.h (xdma_tile)
   int slot[PEA_MAX_K];         // offset k -> displacement slot
   int kA[kBoxND], kB[kBoxND];  // slot -> offset with o == d (role A) / o == -d (role B), or -1
   float gs[PEA_MAX_K];

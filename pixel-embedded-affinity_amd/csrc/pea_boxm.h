@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kBoxTH* kBoxTW, 2) void k_bwd_boxm(const KParams P,
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   int tile, b, seg, y0, x0;
-  if (!xdma_tile<TH, TW, BParams>(C, P, tile, b, seg, y0, x0)) return;
+  if (!march_tile<TH, TW, BParams>(C, P, tile, b, seg, y0, x0)) return;
   const int zb = seg * M.zseg, ze = min(zb + M.zseg, P.Z);
   const size_t S = (size_t)P.S;
   const rsrc_t xB = mkbuf(xt + (size_t)b * D_T * S), dB = mkbuf(dx + (size_t)b * D_T * S);

@@ -23,6 +23,7 @@ namespace pea {
 
 // ---- process-wide switches (debugging / A-B runs), read ONCE: getenv on every launch showed up in the host profile ------------
 struct Env {
+  unsigned gen;       // generation of this switch set (env_generation(): memoised plans carry the generation they were made under)
   int force_direct;   // PEA_FORCE_DIRECT=1: global-memory kernels only
   int fwd_xdma;       // PEA_FWD_XDMA=0: no LDS-DMA forward
   int bwd_xdma;       // PEA_BWD_XDMA=0: no LDS-DMA backward
@@ -37,25 +38,20 @@ struct Env {
                       //   kernels (pea_zmarch.h); 2: the march also on volumes with fewer tile columns than CUs
   int boxm;           // PEA_BOXM=0: the unit-box backward per (z, tile) (pea_box.h) instead of marching (pea_boxm.h)
   int zm_nb;          // PEA_ZM_NB=3: the z-march backward with a ring of three buffers instead of four (5 % slower once the waits count loads only)
+  int zm_sup;         // PEA_ZM_SUP=sx (1, 2, 4, 8): the z-march kernels' eight XCD blocks of a round lie side by side, (8 / sx) x sx, as one
+                      //   super-block (xdma_tile); 0: every XCD walks its own contiguous range of blocks (rounds 4-5)
   int zseg;           // PEA_ZSEG=n: planes per segment of a tile column (0: whole columns where there are enough of them)
-  int skew, skew_slots, skew_mode;  // PEA_SKEW (experiment, off by default: units of 2048 cycles) / PEA_SKEW_SLOTS /
-                                    // PEA_SKEW_MODE: the first workgroups of a CU start apart (pea_xdma.h xdma_tile)
-  int xcd_stagger;    // PEA_XCD_STAGGER=1: the eight XCDs start at different points of their tile ranges (cross kernels)
-  int walk2d;         // PEA_WALK2D=n: 2D images walk strips of n tiles in x down y (0: row-major)
-  int lds_pad;        // PEA_LDS_PAD=bytes: extra dynamic LDS on the cross kernels' launches (occupancy experiments)
   int zblk_y, zblk_x; // PEA_ZBLK_Y / PEA_ZBLK_X: tiles per block of the z-fastest walk of 3D volumes (0: the default 4 x 2; Y < 0: plane-major)
   int bwd_rev;        // PEA_BWD_REV=0: the 2D cross backward walks every XCD's tile range first tile first.  Default 1: LAST tile first -- what
                       //   the forward touched last (the bottom rows of every image: e read, g and 1 / norm written) is what the backward
                       //   asks for first, and the next forward starts where the backward ended (-1.7 % / -0.8 %, profiles/r5_switch1.txt)
-  int bwd_w3;         // PEA_BWD_W3=1: the D = 16 self-loss backward on three workgroups per CU (pea_xdma_w3.h)
-  int bwd_vec;        // PEA_BWD_VEC=1: k_bwd_xdma's 16-byte g loads / stores instantiation
   int fwd_dual;       // PEA_FWD_DUAL=0: pea_affinity_fwd_dual_ex reports PEA_E_UNSUPPORTED (the caller runs the two forwards); 4 (default): the
                       //   one-launch pair on a ring of two four-plane buffers handed over in HALVES (e pair, ema pair), two workgroups per CU;
                       //   2: the same ring handed over buffer by buffer (+2.6 %); 3: a ring of three, one workgroup per CU (+21 %)
 };
 const Env& env();
 void env_reload();          // pea_reload_env(): tests that change a switch call it
-unsigned env_generation();  // bumped by every env_reload(): memoised plans that baked a switch in (PEA_ZBLK_*, PEA_WALK2D, ..) are dropped
+unsigned env_generation();  // = env().gen; a new one with every env_reload(): memoised plans that baked a switch in (PEA_ZBLK_*, ..) are dropped
 
 inline bool misaligned(const void* p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
 int& g_pending_error();  // per thread: an error met while preparing a launch (allow_lds), reported by the next hip_rc()
@@ -91,9 +87,10 @@ struct PlanCache {
   unsigned gen = 0;
   template <typename F>
   bool get(const KParams& P, int mode, PLAN* out, F&& make) {
-    if (gen != env_generation()) {  // a switch changed since these plans were made
+    const unsigned now = env_generation();
+    if (gen != now) {  // a switch changed since these plans were made
       for (int i = 0; i < N; ++i) ent[i].used = false;
-      gen = env_generation();
+      gen = now;
     }
     for (int i = 0; i < N; ++i)
       if (ent[i].used && ent[i].mode == mode && memcmp(&ent[i].key, &P, sizeof(KParams)) == 0) {

@@ -28,8 +28,10 @@ int env_int(const char* name, int dflt) {
 // a half-written mix (round-4 advice: a plan sized for one ring depth launched with another).
 std::atomic<const Env*> g_env_cur{nullptr};
 std::mutex g_env_mu;
+std::atomic<unsigned> g_env_gen{0};
 const Env* env_make() {
   Env* e = new Env();
+  e->gen = g_env_gen.fetch_add(1, std::memory_order_relaxed) + 1;  // published WITH the set: a plan made from it is memoised under it
   e->force_direct = env_int("PEA_FORCE_DIRECT", 0);
   e->fwd_xdma = env_int("PEA_FWD_XDMA", 1);
   e->bwd_xdma = env_int("PEA_BWD_XDMA", 1);
@@ -43,21 +45,13 @@ const Env* env_make() {
   e->zseg = env_int("PEA_ZSEG", 0);
   e->zm_nb = env_int("PEA_ZM_NB", 4);
   e->boxm = env_int("PEA_BOXM", 1);
-  e->xcd_stagger = env_int("PEA_XCD_STAGGER", 0);
-  e->skew = env_int("PEA_SKEW", 0);
-  e->skew_slots = env_int("PEA_SKEW_SLOTS", 4);
-  e->skew_mode = env_int("PEA_SKEW_MODE", 0);
-  e->walk2d = env_int("PEA_WALK2D", 0);
-  e->lds_pad = env_int("PEA_LDS_PAD", 0);
+  e->zm_sup = env_int("PEA_ZM_SUP", 0);
   e->zblk_y = env_int("PEA_ZBLK_Y", 0);
   e->zblk_x = env_int("PEA_ZBLK_X", 0);
   e->bwd_rev = env_int("PEA_BWD_REV", 1);
-  e->bwd_w3 = env_int("PEA_BWD_W3", 0);
-  e->bwd_vec = env_int("PEA_BWD_VEC", 0);
   e->fwd_dual = env_int("PEA_FWD_DUAL", 4);
   return e;
 }
-std::atomic<unsigned> g_env_gen{1};
 }  // namespace
 const Env& env() {
   const Env* e = g_env_cur.load(std::memory_order_acquire);
@@ -74,9 +68,8 @@ const Env& env() {
 void env_reload() {
   std::lock_guard<std::mutex> lk(g_env_mu);
   g_env_cur.store(env_make(), std::memory_order_release);
-  g_env_gen.fetch_add(1, std::memory_order_release);
 }
-unsigned env_generation() { return g_env_gen.load(std::memory_order_relaxed); }
+unsigned env_generation() { return env().gen; }
 
 // CUs of the CURRENT device (asked every time: the reference runs replicas under nn.DataParallel threads, one device each, so a
 // process-wide cache of the first device's answer would be wrong for the others)

@@ -1,7 +1,6 @@
 // pea_k_xdma.hip -- launchers of the LDS-DMA cross kernels (pea_xdma.h): plan, pick the instantiation, launch.
 // One translation unit of libpea_hip.so (pea_host.h).
 #include "pea_k_xdma_plan.h"
-#include "pea_xdma_w3.h"
 #include "pea_xdma_dual.h"
 
 namespace pea {
@@ -74,20 +73,6 @@ bool bwd_self(const KParams& P, const float* x, const float* inv, const float* g
   if constexpr (D_T == 16) {
     if (z3) {
       if (crop) PEA_XB(true, 8, kXdmaPSU3, kXZ) else PEA_XB(false, 8, kXdmaPSU3, kXZ)
-      return true;
-    }
-  }
-  if constexpr (D_T == 16) {
-    // switches (off: both lose 3-5 % to the plain instantiation, profiles/r5_bwd_vec.txt, r5_bwd_w3.txt; bit-identical results)
-    if (env().bwd_w3 && C.npx <= kXP && C.npy <= kXP && !misaligned(g, 16) && !misaligned(dx, 16)) {
-      const size_t lds3 = (size_t)4 * kXdmaPSU * 256;
-      if (crop) { constexpr auto kern = k_bwd_xdma_w3<kXdmaTH, kXdmaTW, kXdmaPSU, true>; PEA_LAUNCH(kern, grid, blk, lds3, s, P, C, x, inv, g, dl, dx) }
-      else { constexpr auto kern = k_bwd_xdma_w3<kXdmaTH, kXdmaTW, kXdmaPSU, false>; PEA_LAUNCH(kern, grid, blk, lds3, s, P, C, x, inv, g, dl, dx) }
-      return true;
-    }
-    if (env().bwd_vec && !misaligned(g, 16) && !misaligned(dx, 16)) {
-      if (crop) { constexpr auto kern = k_bwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, true, kXP, kAuxNT, 0, false, false, true>; PEA_LAUNCH(kern, grid, blk, X.lds, s, P, C, x, inv, g, dl, dx, OtherArgs{}, DualArgs{}) }
-      else { constexpr auto kern = k_bwd_xdma<16, kXdmaTH, kXdmaTW, kXdmaPSU, false, kXP, kAuxNT, 0, false, false, true>; PEA_LAUNCH(kern, grid, blk, X.lds, s, P, C, x, inv, g, dl, dx, OtherArgs{}, DualArgs{}) }
       return true;
     }
   }

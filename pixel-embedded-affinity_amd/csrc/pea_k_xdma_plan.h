@@ -32,11 +32,7 @@ bool plan(const KParams& P, int psu, int mode, XPlan* out, int th = kXdmaTH, int
     if (env().zblk_y > 0) p->C.zgy = env().zblk_y;
     if (env().zblk_x > 0) p->C.zgx = env().zblk_x;
     if (env().zblk_y < 0) p->C.zrun = 0;  // plane-major walk
-    if (P.Z == 1 && env().walk2d > 0) { p->C.zrun = 1; p->C.zgy = p->C.tiles_y; p->C.zgx = env().walk2d; }
-    p->C.stagger = env().xcd_stagger;
     p->C.rev = (mode == 0 || mode == 2) && P.Z == 1 && env().bwd_rev ? 1 : 0;  // backward plans of 2D images
-    p->C.skew = env().skew > 0 ? env().skew : 0; p->C.skew_slots = env().skew_slots > 0 ? env().skew_slots : 1; p->C.skew_mode = env().skew_mode;
-    p->lds += (size_t)env().lds_pad;
     return true;
   });
 }

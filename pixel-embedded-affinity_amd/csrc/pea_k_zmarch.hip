@@ -21,7 +21,7 @@ bool plan(const KParams& P, int mode, ZPlan* out) {
   // (the segmentation depends on the CURRENT device's CU count: part of the key -- a thread that serves devices of different sizes must
   //  not be handed the other device's plan; round-4 advice)
   const Env& E = env();
-  return cache.get(P, mode * 4096 + E.zm_nb * 1024 + E.zmarch * 64 + E.zseg + (device_cus() << 13), out, [&](ZPlan* p) {
+  return cache.get(P, mode * 4096 + E.zm_nb * 1024 + E.zmarch * 64 + E.zseg + (device_cus() << 13) + (E.zm_sup << 24), out, [&](ZPlan* p) {
     p->nb = E.zm_nb == 3 ? 3 : 4;
     if (!env().zmarch || !plan_zmarch(P, &p->M)) return false;
     if (!plan_xdma(P, kTH, kTW, mode ? kPSUF : kPSUB, &p->C, &p->lds, mode)) return false;
@@ -52,6 +52,15 @@ bool plan(const KParams& P, int mode, ZPlan* out) {
     if (nt > 0x7fffff00LL) return false;
     C.ntiles = (int)nt;
     C.tiles_per_xcd = (C.ntiles + kXcd - 1) / kXcd;
+    const int sx = E.zm_sup;
+    if (sx == 1 || sx == 2 || sx == 4 || sx == 8) {  // the XCDs' blocks of a round side by side (xdma_tile's super-block walk)
+      C.sup_x = sx;
+      C.sup_y = kXcd / sx;
+      const long long nsx = (C.tiles_x + C.zgx * sx - 1) / (C.zgx * sx), nsy = (C.tiles_y + C.zgy * C.sup_y - 1) / (C.zgy * C.sup_y);
+      const long long per_xcd = (long long)P.B * nsx * nsy * C.zgy * C.zgx * p->M.nseg;
+      if (per_xcd * kXcd > 0x7fffff00LL) return false;
+      C.tiles_per_xcd = (int)per_xcd;
+    }
     return true;
   });
 }

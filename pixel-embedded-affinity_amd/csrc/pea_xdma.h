@@ -47,9 +47,6 @@ __device__ unsigned long long* g_stamps;
 #endif
 constexpr int kStampLast = 95;
 
-#ifndef PEA_BWD_DMA_AUX  // (diagnostic builds of profiles/microbench/bwd_vec.hip: cache policy of the backward's LDS-DMA; 2 = nt)
-#define PEA_BWD_DMA_AUX 0
-#endif
 constexpr int kXP = 10;  // (offset, role) pairs per axis held in registers (CVPPP: 5 shifts x 2 roles)
 constexpr int kXZ = 8;   // (offset, role) pairs along z (AC3/AC4 norm5: shifts 1, 2, 3, 4)
 constexpr int kXK = 16;  // channels (offsets) the forward's epilogue handles
@@ -74,10 +71,6 @@ struct XParams {
   int QV, QA;     // quads (4 x-adjacent pixels) in VF; in VF + strips.  Blocks of 64 quads go round the waves.
   int tiles_y, tiles_x, tiles_per_plane, ntiles, tiles_per_xcd;
   int npx, npy;
-  int vhx;                 // backward: the reach of the x offsets (a tile whose columns x0 - vhx .. x0 + TW - 1 + vhx leave the image takes
-                           // the one-dword g loads: a quad of g at p - o would straddle the wrap)
-  unsigned vq_go[kXP / 2], vq_gi[kXP / 2];  // VEC: per quad-load instruction i, byte j = slot 4 i + j (x pair s < kXP, else y pair s - kXP):
-                                            // its g displacement + 128; its g channel (0xff: unused pair)
   int xd[kXP], yd[kXP];    // pixel displacement of the neighbour along x / y  (0 for unused pairs)
   int xm[kXP];             // strip coordinate mask of the x pair: d < 0 ? SW - 1 : TW - 1
   int xgi[kXP], ygi[kXP];  // g channel
@@ -88,12 +81,12 @@ struct XParams {
   int npz;                 // backward: (offset, role) pairs along z
   int zd[kXZ];             // plane displacement of the neighbour
   int zgi[kXZ], zgo[kXZ];  // g channel; plane displacement of the g sample (role A: 0, role B: -oz)
-  int stagger;             // the XCDs start at different points of their tile ranges (xdma_tile)
   int rev;                 // every XCD walks its tile range from the last tile to the first (PEA_BWD_REV: the backward starts where the
                            // forward ended)
-  int skew, skew_slots, skew_mode;  // PEA_SKEW (experiment, off by default): the first workgroups of a CU start a fraction of a tile time apart
   int zrun;                // > 1: tiles walk z fastest (= Z), so the planes a z offset reaches were staged just before
   int zgy, zgx;            // ... inside blocks of zgy x zgx tiles
+  int sup_y, sup_x;        // > 0 (sup_y * sup_x == 8): the eight XCDs' blocks of one round lie side by side as ONE super-block of
+                           // (sup_y zgy) x (sup_x zgx) tiles (march kernels: what the round fetches from HBM is the super-block's halo)
   // forward (role A only): in-plane offsets in their own order (nf <= kXP), z offsets (nfz <= kXZ / 2)
   int nf, nfz;
   int fd[kXP];             // displacement along the offset's axis
@@ -131,26 +124,13 @@ template <int TH, int TW, typename CP = XParams>
 __device__ __forceinline__ bool xdma_tile(const CP& C, const KParams& P, int& tile, int& b, int& z, int& y0, int& x0) {
   const int bid = blockIdx.x;
   int slot = bid / kXcd;
-  // stagger (PEA_XCD_STAGGER): XCD g starts g / 8 of the way into its tile range and wraps -- with one image per XCD the eight XCDs
-  // otherwise request the same position of eight images at the same time, a fixed distance apart
-  if (C.stagger) { slot += (bid % kXcd) * (C.tiles_per_xcd / kXcd); slot -= slot >= C.tiles_per_xcd ? C.tiles_per_xcd : 0; }
   if (C.rev) slot = C.tiles_per_xcd - 1 - slot;
   const int lin = (bid % kXcd) * C.tiles_per_xcd + slot;
   if (lin >= C.ntiles) return false;
-  if (C.skew) {
-    // the workgroups resident on a CU start together and run the same phases: they ask for memory at the same time and compute at the
-    // same time.  Delay the j-th of the first `skew_slots` workgroups of each CU by j * skew * 2048 cycles
-    const int w = bid / kXcd;
-    const int j = C.skew_mode ? w % C.skew_slots : w / 32;
-    if (w < 32 * C.skew_slots)
-      for (int i = 0; i < j * C.skew; ++i) __builtin_amdgcn_s_sleep(32);
-  }
   int plane, rem;
   if (C.zrun >= 1) {
     // walk: blocks of kGY x kGX tiles; inside a block z, then y, then x fastest -- the tiles in flight on an XCD (64) are a few
     // planes of one block: the z neighbours were staged 1-4 planes ago, the in-plane halos are shared inside the block.
-    // zrun == 1 (2D images, PEA_WALK2D): the same walk without a z run -- strips of kGX tiles walked down y, so that the tiles in
-    // flight on an XCD share their y halos out of its L2
     const int kGY = C.zgy, kGX = C.zgx;
     const int per_b = C.tiles_per_plane * C.zrun;
     b = lin / per_b;
@@ -183,23 +163,31 @@ __device__ __forceinline__ bool xdma_tile(const CP& C, const KParams& P, int& ti
   return true;
 }
 
-// ---- VEC (k_bwd_xdma<.., VEC>): the backward's g loads and gradient stores as 16-byte instructions --------------------------------
-// A vector-memory wave instruction costs the CU's address path 16-18 cycles whatever its width (profiles/microbench/vmem_issue.hip), and
-// per 16 x 32 tile the kernel issued 160 one-dword g loads and 128 one-dword stores beside its 208 DMA pieces: 8.8 k cycles of
-// 30 k per tile.  With lane = pixel in the gather both are dword shaped; as QUADS (a lane takes 4 x-adjacent pixels of one plane)
-// they are 40 + 32 instructions.  The two shapes are exchanged through a wave-private LDS slot (a wave owns two tile rows = 16 quads,
-// so one dwordx4 instruction carries four planes of them: lane = plane j * 16 + quad q; read back as dword j * 64 + lane).
-// The g loads are inline asm: the compiler then inserts no vmcnt wait of its own for them (it would have to assume that none of the
-// conditional DMA instructions issued after them exists, i.e. vmcnt(0): the whole next chunk drained before the coefficients).
-typedef int i4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i4 mkbuf_words(const void* base) {  // the four words of mkbuf(base), for asm operands
-  const unsigned long long a = (unsigned long long)base;
-  return (i4){(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)kOOB, 0x00020000};
-}
-__device__ __forceinline__ f4 asm_load_b128(i4 rs, unsigned vo, unsigned so) {
-  f4 r;
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r) : "v"(vo), "s"(rs), "s"(so) : "memory");
-  return r;
+// The march kernels' tile walk (zrun = segments per tile column).  sup_x > 0: the SUPER-BLOCK walk -- round r of the launch = super-block
+// r, XCD g = its block (g / sup_x, g % sup_x) of zgy x zgx tile columns.  What one XCD's block shares with its neighbours' it finds in
+// the Infinity Cache (they are fetched in the same round), so HBM sees the halo of (sup_y zgy) x (sup_x zgx) tiles, not of each block.
+// Super-blocks are padded to the tile grid: a workgroup whose tile lies beyond it leaves.  (Its own function: inside xdma_tile the
+// second path cost the 80-VGPR forward one spilled register.)
+template <int TH, int TW, typename CP = XParams>
+__device__ __forceinline__ bool march_tile(const CP& C, const KParams& P, int& tile, int& b, int& z, int& y0, int& x0) {
+  if (C.sup_x <= 0) return xdma_tile<TH, TW, CP>(C, P, tile, b, z, y0, x0);
+  const int bid = blockIdx.x, slot = bid / kXcd;
+  const int G = C.zgy * C.zgx * C.zrun;
+  const int sb = slot / G;
+  int r = slot - sb * G;
+  const int nsx = (C.tiles_x + C.zgx * C.sup_x - 1) / (C.zgx * C.sup_x), nsy = (C.tiles_y + C.zgy * C.sup_y - 1) / (C.zgy * C.sup_y);
+  b = sb / (nsx * nsy);
+  if (b >= P.B) return false;
+  const int s2 = sb - b * nsx * nsy, sby = s2 / nsx, sbx = s2 - sby * nsx;
+  const int xcd = bid % kXcd, xy = xcd / C.sup_x, xx = xcd - xy * C.sup_x;
+  z = r / (C.zgy * C.zgx);
+  r -= z * C.zgy * C.zgx;
+  const int ty_ = (sby * C.sup_y + xy) * C.zgy + r / C.zgx, tx_ = (sbx * C.sup_x + xx) * C.zgx + r % C.zgx;
+  if (ty_ >= C.tiles_y || tx_ >= C.tiles_x) return false;
+  tile = (b * C.zrun + z) * C.tiles_per_plane + ty_ * C.tiles_x + tx_;
+  y0 = ty_ * TH;
+  x0 = tx_ * TW;
+  return true;
 }
 
 // self-loss backward (both roles, nb == x); f32 storage; X % 4 == 0 and 16-byte aligned planes (host-checked)
@@ -344,24 +332,20 @@ struct OtherArgs {
   const float* own_inv;  // [B, S] its signed 1 / norm plane
   int accumulate;
 };
-// VEC: g arrives and the gradient leaves in 16-byte instructions (see above); D = 16, in-plane, self loss
-template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, int AUXS = kAuxNT, int ZP = 0, bool OTHER = false, bool DUAL = false,
-          bool VEC = false>
+template <int D_T, int TH, int TW, int PSU, bool CROP, int XP = kXP, int AUXS = kAuxNT, int ZP = 0, bool OTHER = false, bool DUAL = false>
 __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const XParams C, const float* __restrict__ xt,
                                                          const float* __restrict__ invp, const float* __restrict__ gin,
                                                          const float* __restrict__ dloss, float* __restrict__ dx,
                                                          const OtherArgs O, const DualArgs Q) {
   static_assert(!OTHER || D_T <= 16, "role-A instantiation: D <= 16 (z pairs: role A only, ZP = kXZ / 2)");
   static_assert(!DUAL || (D_T == 16 && ZP == 0 && !OTHER), "pair instantiation: D = 16, in-plane");
-  static_assert(!VEC || (D_T == 16 && ZP == 0 && !OTHER && !DUAL && TH == 16 && (2 * XP) % 4 == 0 && PSU * 256 >= 8 * 1024),
-                "16-byte g loads / stores: D = 16, in-plane self loss, a wave = two tile rows");
-  static_assert(!VEC || XP == kXP, "plan_xdma packs the quad-load slots for kXP pairs per axis");
   constexpr int NT = TH * TW, PS = PSU * 256, NP = D_T / 2;
   static_assert(TW == 32 && D_T % 2 == 0, "lane mapping / channel pairs");
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   int tile, b, z, y0, x0;
   if (!xdma_tile<TH, TW>(C, P, tile, b, z, y0, x0)) return;
+  __builtin_amdgcn_sched_barrier(0);
   const size_t S = (size_t)P.S;
   const unsigned YX = (unsigned)(P.Y * P.X);
   const rsrc_t xB = mkbuf(xt + (size_t)b * D_T * S), dB = mkbuf(dx + (size_t)b * D_T * S);
@@ -393,11 +377,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       gy = y0 + (k >> sh);
       gx = cc < C.split ? x0 + TW + cc : x0 - C.SW + cc;
     }
-#ifdef PEA_ABL_NOSTRIP  // (diagnostic builds of profiles/microbench/bwd_vec.hip only: what does the L2 -> LDS fill cost?  wrong results)
-    act[s] = q < C.QV - PEA_ABL_NOSTRIP * 8;
-#else
     act[s] = q < C.QA;
-#endif
     bool oky, okx;
     gy = wrap1<CROP>(gy, P.Y, oky);
     gx = wrap1<CROP>(gx, P.X, okx);
@@ -440,8 +420,8 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, 0); \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + w1), 16, vo1, so, 0, 0);      \
     } else {                                                                                                        \
-      if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, PEA_BWD_DMA_AUX);        \
-      if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + w1), 16, vo1, so, 0, PEA_BWD_DMA_AUX); \
+      if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + wbase), 16, vo[0], so, 0, 0);        \
+      if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + (plane_byte) + w1), 16, vo1, so, 0, 0); \
     }                                                                                                               \
   }
   PEA_STAMP(0)
@@ -462,7 +442,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
     ax[k] = (unsigned)c < (unsigned)TW ? vown + d * 4 : hrow + (c & C.xm[k]) * 4;
     ay[k] = vown + C.yd[k] * TW * 4;
   }
-  // one dword per lane and pair (the lane's own pixel): every instantiation but VEC, and VEC's border tiles
+  // one dword per lane and pair (the lane's own pixel)
 #define PEA_XG_DWORDS()                                                                                                              \
   {                                                                                                                                  \
     _Pragma("unroll") for (int k = 0; k < XP; ++k) {                                                                                 \
@@ -482,41 +462,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       cy[k] = bl32(gB, k < C.npy ? o : kOOB, ezo + (unsigned)C.ygi[k] * ecs);                                                        \
     }                                                                                                                                \
   }
-  // VEC: quads.  Slot s = 4 i + j of instruction i (lanes 16 j .. 16 j + 15): x pair s (s < XP) or y pair s - XP; the lane's quad
-  // q = lane & 15 of the wave's two tile rows, displaced by the pair's g displacement (role B: the quad at p - o, 4-byte aligned
-  // only -- the buffer instructions take that).  A tile from which an x displacement leaves the image (the outermost tile
-  // columns) keeps the dword loads: its quads would straddle the wrap.
-  constexpr int NQG = VEC ? (2 * XP) / 4 : 1;
-  f4 gq[NQG];
-  bool vec_tile = false;  // uniform
-  if constexpr (VEC) {
-    vec_tile = x0 >= C.vhx && x0 + TW + C.vhx <= P.X;
-    if (vec_tile) {
-      const i4 gW = mkbuf_words(gin + (size_t)b * P.K * S);
-      const int j4 = lane >> 4, qq = lane & 15;
-      const int qy = y0 + 2 * wave + (qq >> 3), qx = x0 + 4 * (qq & 7);
-      const bool qlive = qy < P.Y && qx < P.X;
-#pragma unroll
-      for (int i = 0; i < NQG; ++i) {
-        const int go = (int)((C.vq_go[i] >> (8 * j4)) & 0xffu) - 128, gi = (int)((C.vq_gi[i] >> (8 * j4)) & 0xffu);
-        const bool used = gi != 0xff;
-        const unsigned xm_ = (4 * i < XP ? 1u : 0u) | (4 * i + 1 < XP ? 2u : 0u) | (4 * i + 2 < XP ? 4u : 0u) | (4 * i + 3 < XP ? 8u : 0u);
-        const bool isx = (xm_ >> j4) & 1u;
-        bool ok;
-        const int ty = wrap1<CROP>(qy + (isx ? 0 : go), P.Y, ok), tx = qx + (isx ? go : 0);
-        const unsigned vo = (qlive && used && ok) ? (unsigned)gi * ecs + (unsigned)(ty * P.X + tx) * 4u : kOOB;
-        gq[i] = asm_load_b128(gW, vo, ezo);
-      }
-    } else {
-      PEA_XG_DWORDS()
-      // used here, inside the branch: the compiler's wait for these loads then sits here and not behind the join, where it would
-      // also hold the quad tiles (and drain the DMA issued in between)
-#pragma unroll
-      for (int k = 0; k < XP; ++k) asm volatile("" : "+v"(cx[k]), "+v"(cy[k]));
-    }
-  } else {
-    PEA_XG_DWORDS()
-  }
+  PEA_XG_DWORDS()
 #undef PEA_XG_DWORDS
   // z pairs: g and the neighbour's 1 / norm (another plane, same (y, x): scalar plane offsets); a pair whose plane does not
   // exist gets the coefficient 0 and reads plane z itself
@@ -551,25 +497,6 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   PEA_XWAIT1()
   PEA_STAMP(2)
 
-  if constexpr (VEC) {
-    if (vec_tile) {
-      // the g quads are older than chunk 1's DMA: landed.  Quads -> pixels through the wave's own 1 KB of plane 5 (free until the
-      // barrier below; LDS instructions of one wave execute in order, so the slot is reused without a wait)
-#pragma unroll
-      for (int i = 0; i < NQG; ++i) asm volatile("" : "+v"(gq[i]));
-      char* const gs = lds + 5 * PS + wave * 1024;
-#pragma unroll
-      for (int i = 0; i < NQG; ++i) {
-        *(f4*)(gs + lane * 16) = gq[i];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float v = *(const float*)(gs + j * 256 + lane * 4);
-          if (4 * i + j < XP) cx[4 * i + j] = v;
-          else cy[4 * i + j - XP] = v;
-        }
-      }
-    }
-  }
   // coefficient of a pair = g * 1 / |e(q)|
   const float invo = OTHER ? invo_g : *(const float*)(lds + 4 * PS + vown);
   const float inv_own = fabsf(invo);
@@ -595,30 +522,10 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
   }
   PEA_XZLOAD(0)
   if (NP > 1) PEA_XZLOAD(1)
-  if (NP > 2 && !VEC) {
+  if (NP > 2) {
     PEA_XDMA(xB, 4 * PS, ezo + 4u * ecs)
     PEA_XDMA(xB, 5 * PS, ezo + 5u * ecs)
   }
-  // VEC: the four DMA instructions of chunk ps + 2 are issued INSIDE the gather of chunk ps, a quarter of the pairs apart (its
-  // buffer (ps + 2) % 3 was freed by the barrier before this gather): issued in one burst behind the barrier, all sixteen waves of
-  // the CU queue at the address unit at once and stand there (557 of a chunk's 2900 cycles, profiles/r3_stamps_bwd.txt)
-#ifdef PEA_VEC_NOSPREAD  // (diagnostic builds of profiles/microbench/bwd_vec.hip only: the four pieces in one burst)
-#define PEA_XDMA_PIECE(ps_, n_) PEA_XDMA_PIECE_((ps_), ((n_) == 0 ? 0 : 4)) PEA_XDMA_PIECE_((ps_), ((n_) == 0 ? 1 : 4)) \
-  PEA_XDMA_PIECE_((ps_), ((n_) == 0 ? 2 : 4)) PEA_XDMA_PIECE_((ps_), ((n_) == 0 ? 3 : 4))
-#else
-#define PEA_XDMA_PIECE(ps_, n_) PEA_XDMA_PIECE_(ps_, n_)
-#endif
-#define PEA_XDMA_PIECE_(ps_, n_)                                                                                                    \
-  if (VEC && (ps_) + 2 < NP && (n_) < 4) {                                                                                                      \
-    const int pb_ = (((ps_) + 2) % 3) * 2 * PS + ((n_) >> 1) * PS;                                                                  \
-    const unsigned so_ = ezo + (unsigned)(2 * (ps_) + 4 + ((n_) >> 1)) * ecs;                                                       \
-    if (((n_) & 1) == 0) {                                                                                                          \
-      if (act[0]) __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + pb_ + wbase), 16, vo[0], so_, 0, 0);               \
-    } else {                                                                                                                        \
-      if (act[1]) __builtin_amdgcn_raw_ptr_buffer_load_lds(xB, (lds_ptr_t)(lds + pb_ + w1), 16, vo1, so_, 0, 0);                    \
-    }                                                                                                                               \
-  }
-
   // D_T <= 16: the lane keeps its own normalised pixel (eh) for the projection at the end; wider embeddings have no
   // registers for it (G alone is D_T of them): <ehat, G> is accumulated chunk by chunk and the own pixel is read again
   // from global memory (an L2 hit: its tile was just staged) for the final (G - ehat <ehat, G>) / n
@@ -643,23 +550,19 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
 #ifndef PEA_ABL_NOGATHER  // (diagnostic builds of profiles/microbench/stamp_bwd.hip only)
 #pragma unroll
     for (int k = 0; k < XP; ++k) {
-      if (k == 0) PEA_XDMA_PIECE(ps, 0)
-      if (k == XP / 2) PEA_XDMA_PIECE(ps, 1)
       f2 v;
       v.x = *(const float*)(lds + bo + ax[k]);
       v.y = *(const float*)(lds + bo + PS + ax[k]);
       acc = __builtin_elementwise_fma((f2){cx[k], cx[k]}, v, acc);
-      if (k % (DUAL ? 2 : 5) == (DUAL ? 1 : 4)) asm volatile("" ::: "memory");  // bound the ds_read hoisting (DUAL: the second phase's 20 g registers are live too)
+      if (DUAL || k % 5 == 4) asm volatile("" ::: "memory");  // bound the ds_read hoisting (DUAL: the second phase's 20 g registers are live too)
     }
 #pragma unroll
     for (int k = 0; k < XP; ++k) {
-      if (k == 0) PEA_XDMA_PIECE(ps, 2)
-      if (k == XP / 2) PEA_XDMA_PIECE(ps, 3)
       f2 v;
       v.x = *(const float*)(lds + bo + ay[k]);
       v.y = *(const float*)(lds + bo + PS + ay[k]);
       acc = __builtin_elementwise_fma((f2){cy[k], cy[k]}, v, acc);
-      if (k % (DUAL ? 2 : 5) == (DUAL ? 1 : 4)) asm volatile("" ::: "memory");
+      if (DUAL || k % 5 == 4) asm volatile("" ::: "memory");
     }
 #else
     acc.x = cx[ps % XP] + cy[ps % XP];
@@ -682,7 +585,7 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       PEA_STAMP(4 + 3 * ps)
       if (ps + 2 < NP) PEA_XZLOAD(ps + 2)
 #ifndef PEA_ABL_NODMA
-      if (ps + 3 < NP && !VEC) {
+      if (ps + 3 < NP) {
         PEA_XDMA(xB, bo, ezo + (unsigned)(2 * ps + 6) * ecs)
         PEA_XDMA(xB, bo + PS, ezo + (unsigned)(2 * ps + 7) * ecs)
       }
@@ -707,8 +610,6 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
     }
   }
 #undef PEA_XDMA
-#undef PEA_XDMA_PIECE
-#undef PEA_XDMA_PIECE_
 #undef PEA_XWAIT1
 #undef PEA_XWAITZ
 #undef PEA_XZLOAD
@@ -734,25 +635,6 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       old[ps].y = bl32(dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs);
     }
   }
-  if constexpr (VEC) {
-    // pixels -> quads through 4 KB of the wave's own ([channel][64 pixels]; buffers 0 and 2 are dead: the last chunk sits in buffer
-    // (NP - 1) % 3 = 1 and every wave is past the barrier in front of it), then four planes of 16 quads per dwordx4 store
-    static_assert((NP - 1) % 3 == 1, "the store transpose goes over buffers 0 and 2");
-    char* const sc_ = lds + (wave < 4 ? wave * 4096 : 4 * PS + (wave - 4) * 4096);
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-      *(float*)(sc_ + (2 * ps) * 256 + lane * 4) = __builtin_fmaf(-eh[ps].x, proj, G[ps].x) * sc;
-      *(float*)(sc_ + (2 * ps + 1) * 256 + lane * 4) = __builtin_fmaf(-eh[ps].y, proj, G[ps].y) * sc;
-    }
-    const int j4 = lane >> 4, qq = lane & 15;
-    const int qy = y0 + 2 * wave + (qq >> 3), qx = x0 + 4 * (qq & 7);
-    const unsigned qo = (qy < P.Y && qx < P.X) ? (unsigned)(qy * P.X + qx) * 4u : kOOB;
-#pragma unroll
-    for (int s2 = 0; s2 < D_T / 4; ++s2) {
-      const f4 v = *(const f4*)(sc_ + (4 * s2 + j4) * 256 + qq * 16);
-      bs128<AUXS == kAuxNT>(dB, v, qo == kOOB ? kOOB : qo + (unsigned)(4 * s2 + j4) * ecs, ezo);
-    }
-  } else {
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
     // (G - ehat <ehat, G>) / n with ONE rounding of the difference in every channel: left to the compiler, one channel of sixteen came out
@@ -766,7 +648,6 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
     if (OTHER && accum) { vx += old[ps].x; vy += old[ps].y; }
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), dB, pe, ezo + (unsigned)(2 * ps) * ecs, AUXS);
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs, AUXS);
-  }
   }
   PEA_STAMP(kStampLast)
 }
@@ -1265,17 +1146,6 @@ inline bool plan_xdma(const KParams& P, int TH, int TW, int psu, XParams* out, s
   C.zgy = 4; C.zgx = 2;
   if (fwd || role_a) { hx = left > right ? left : right; C.hy0 = up; C.hy1 = down; }
   else { C.hy0 = C.hy1 = hy; left = right = hx; }
-  C.vhx = hx;
-  for (int i = 0; i < kXP / 2; ++i) {
-    C.vq_go[i] = C.vq_gi[i] = 0;
-    for (int j = 0; j < 4; ++j) {
-      const int sl = 4 * i + j, k = sl < kXP ? sl : sl - kXP;
-      const bool isx = sl < kXP, used = isx ? k < C.npx : k < C.npy;
-      const int go = isx ? C.xgo[k] : C.ygo[k], gi = isx ? C.xgi[k] : C.ygi[k];
-      C.vq_go[i] |= (unsigned)((used ? go : 0) + 128) << (8 * j);
-      C.vq_gi[i] |= (unsigned)(used ? gi : 0xff) << (8 * j);
-    }
-  }
   if (hx > TW) return false;  // a neighbour column is inside the tile or in the strip next to it
   if (left > 0 && right > 0) { C.SW = hx <= 16 ? 32 : 64; C.split = C.SW / 2; }
   else { C.SW = 32; C.split = right > 0 ? 32 : 0; }  // one strip (or none: still one row of 32 per tile row)

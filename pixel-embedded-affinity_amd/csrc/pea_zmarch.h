@@ -288,7 +288,7 @@ __global__ __launch_bounds__(TH* TW, 2) void k_bwd_zm(const KParams P, const XPa
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   int tile, b, seg, y0, x0;
-  if (!xdma_tile<TH, TW>(C, P, tile, b, seg, y0, x0)) return;
+  if (!march_tile<TH, TW>(C, P, tile, b, seg, y0, x0)) return;
   const int zb = seg * M.zseg, ze = min(zb + M.zseg, P.Z);
   const size_t S = (size_t)P.S;
   const unsigned YX4 = (unsigned)(P.Y * P.X) * 4u, ecs = (unsigned)P.S * 4u;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(TH* TW, 2) void k_fwd_zm(const KParams P, const XPa
   float* sA = (float*)(lds + RING);                      // [K][TP] dot products of the plane
   float* s_part = (float*)(lds + RING + KMAX * TP * 4);  // [K][NSL]
   int tile, b, seg, y0, x0;
-  if (!xdma_tile<TH, TW>(C, P, tile, b, seg, y0, x0)) return;
+  if (!march_tile<TH, TW>(C, P, tile, b, seg, y0, x0)) return;
   const int zb = seg * M.zseg, ze = min(zb + M.zseg, P.Z);
   const size_t S = (size_t)P.S;
   const unsigned YX4 = (unsigned)(P.Y * P.X) * 4u, ecs = (unsigned)P.S * 4u;

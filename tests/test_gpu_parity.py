@@ -247,10 +247,11 @@ def test_graphed_step_equals_eager(pkg, dev, synth):
     assert grad.shape == E.shape and torch.isfinite(grad).all()
 
 
-@pytest.mark.parametrize("switch,value", [("PEA_SKEW", "6"), ("PEA_WALK2D", "5"), ("PEA_XCD_STAGGER", "1")])
+@pytest.mark.parametrize("switch,value", [("PEA_BWD_REV", "0"), ("PEA_FWD_WG3", "0")])
 def test_walk_and_placement_switches_change_no_bit(pkg, dev, synth, monkeypatch, switch, value):
-    """The tile-walk / start-placement experiments kept as switches (csrc/pea_xdma.h xdma_tile)
-    decide WHEN and WHERE a tile is worked on, never what it computes: loss, map and gradient bit for bit, B=4 x 16 x 272 x 320"""
+    """The tile walk of the backward (last tile first / first tile first, csrc/pea_xdma.h xdma_tile) and the forward's workgroups per CU
+    decide WHEN and WHERE a tile is worked on, never what it computes: loss, map and gradient bit for bit, B=4 x 16 x 272 x 320.
+    (Round 6: the walk / placement experiments that lost -- PEA_SKEW, PEA_WALK2D, PEA_XCD_STAGGER -- left the library.)"""
     offsets = pkg.multi_offset([1, 3, 5, 9, 27], 4)
     B, D, H, W = 4, 16, 272, 320
     e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, 77)
@@ -265,8 +266,6 @@ def test_walk_and_placement_switches_change_no_bit(pkg, dev, synth, monkeypatch,
 
     ref = run()
     monkeypatch.setenv(switch, value)
-    if switch == "PEA_SKEW":
-        monkeypatch.setenv("PEA_SKEW_SLOTS", "2")
     got = run()
     assert all(torch.equal(a, b) for a, b in zip(ref, got))
 

@@ -82,6 +82,44 @@ def test_zmarch_norm5_vs_oracle(pkg, dev, orc, synth, monkeypatch, shape, zseg):
     assert relmax(et.grad.cpu().numpy(), e2.grad.cpu().numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("sup", [0, 1, 2, 4, 8])
+@pytest.mark.parametrize("shape,zseg,blk", [((2, 6, 80, 160), 0, None), ((1, 9, 43, 96), 4, (2, 1)), ((1, 5, 272, 352), 0, (4, 2))])
+def test_zmarch_walks_change_no_bit(pkg, dev, orc, synth, monkeypatch, shape, zseg, blk, sup):
+    """PEA_ZM_SUP (csrc/pea_xdma.h march_tile): the eight XCDs' blocks of a round side by side as one super-block, (8 / sx) x sx, or every
+    XCD on its own range of blocks (0).  The walk decides WHEN and WHERE a tile column is marched through, never what it computes: loss,
+    map and gradient bit for bit against the other walk, on tile grids that are no multiple of the block / super-block (padded
+    super-blocks: workgroups beyond the grid leave), with segments, and against the oracle"""
+    B, Z, Y, X = shape
+    monkeypatch.setenv("PEA_ZMARCH", "2")
+    if zseg:
+        monkeypatch.setenv("PEA_ZSEG", str(zseg))
+    if blk:
+        monkeypatch.setenv("PEA_ZBLK_Y", str(blk[0]))
+        monkeypatch.setenv("PEA_ZBLK_X", str(blk[1]))
+    offs = orc.norm_offsets(NORM5)
+    e, t, w = synth.synth_inputs_3d(B, 16, Z, Y, X, offs, 91 + Z)
+    spec = pkg.AffinitySpec(3, offs, None, pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
+
+    def run():
+        x = cu(e, dev).requires_grad_(True)
+        assert _march_on(pkg, spec, x)
+        loss, affs = pkg.embedding_loss_norm5(x, cu(t, dev), cu(w, dev), pkg.WeightedMSE())
+        loss.backward()
+        return loss.detach().clone(), affs.clone(), x.grad.clone()
+
+    monkeypatch.setenv("PEA_ZM_SUP", str(sup))
+    got = run()
+    monkeypatch.setenv("PEA_ZM_SUP", "0" if sup else "8")
+    ref = run()
+    assert all(torch.equal(a, b) for a, b in zip(ref, got))
+    d = orc.desc_3d(e, NORM5)
+    o_affs, o_loss = orc.c_fwd(d, e, None, t, w, None)
+    o_grad, _ = orc.c_bwd(d, e, None, t, w, None)
+    assert np.abs(got[1].cpu().numpy() - o_affs).max() < AFFS_ATOL
+    assert abs(got[0].item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+    assert relmax(got[2].cpu().numpy(), o_grad) < GRAD_RTOL
+
+
 @pytest.mark.parametrize("shift,zseg", [(1, 0), (2, 0), (1, 4)])
 def test_zmarch_norm1_vs_oracle(pkg, dev, orc, synth, monkeypatch, shift, zseg):
     """embedding_loss_norm1 (one step along z, y, x; shift 1 and 2): only one of the window's four z slots carries a coefficient"""
