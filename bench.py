@@ -338,26 +338,30 @@ def ac3ac4_section_us(pkg, dev, rank, B=2, dims=(18, 160, 160)):
     downs = [torch.cat([(torch.rand(B, 3, Z, Y >> j, X >> j, generator=g, device=dev) < 0.6).float(),
                         torch.rand(B, 3, Z, Y >> j, X >> j, generator=g, device=dev) + 0.5], dim=1) for j in (1, 2, 3, 4)]  # down1 .. down4
 
-    def run(which):
-        xs = [emb.detach().requires_grad_(True)] + [e.detach().requires_grad_(True) for e in emds]
-        fn = pkg.ac3ac4_loss_section if which == "one_node" else pkg.ac3ac4_loss_section_composed
-        loss, pred = fn(xs[0], xs[1:], ema, target, weight, downs, crit, embedding_mode=5)
+    def section(which, xs):
+        """composed: call by call + finish_pred_3d_; one_node: one autograd node + finish_pred_3d_; finished: one node that hands the
+        map out finished (the forward clamps it, only the border slices are touched afterwards)"""
+        if which == "composed":
+            loss, pred = pkg.ac3ac4_loss_section_composed(xs[0], list(xs[1:]), ema, target, weight, downs, crit, embedding_mode=5)
+        else:
+            loss, pred = pkg.ac3ac4_loss_section(xs[0], list(xs[1:]), ema, target, weight, downs, crit, embedding_mode=5,
+                                                 finish_pred=which == "finished")
         loss.backward()
-        pkg.finish_pred_3d_(pred)
+        return loss, (pred if which == "finished" else pkg.finish_pred_3d_(pred))
+
+    def run(which):
+        section(which, [emb.detach().requires_grad_(True)] + [e.detach().requires_grad_(True) for e in emds])
 
     out = {"shape": "B=%d x 16 x %dx%dx%d, norm5 + ema_norm5 + 4 x norm1 (1/16 .. 1/2 in y, x)" % (B, Z, Y, X)}
-    for which in ("composed", "one_node"):
+    for which in ("composed", "one_node", "finished"):
         out[which] = best_event_us(lambda: run(which))
-    for which in ("one_node", "composed"):
+    for which in ("one_node", "finished", "composed"):
         xs = [emb.detach().clone().requires_grad_(True)] + [e.detach().clone().requires_grad_(True) for e in emds]
 
         def fn(*xs):
             for t in xs:
                 t.grad = None
-            f = pkg.ac3ac4_loss_section if which == "one_node" else pkg.ac3ac4_loss_section_composed
-            loss, pred = f(xs[0], list(xs[1:]), ema, target, weight, downs, crit, embedding_mode=5)
-            loss.backward()
-            return (loss, pkg.finish_pred_3d_(pred)) + tuple(t.grad for t in xs)
+            return section(which, xs) + tuple(t.grad for t in xs)
         out[which + "_graphed"] = graphed_us(pkg, fn, xs)
     # algorithmic bytes of the six losses (SURVEY 8d, 3D: 12D + 20K per voxel; the cross loss + 8D) at 8 TB/s
     vox = B * Z * Y * X

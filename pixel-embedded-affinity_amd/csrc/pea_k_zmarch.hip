@@ -27,7 +27,6 @@ bool plan(const KParams& P, int mode, ZPlan* out) {
     if (!plan_xdma(P, kTH, kTW, mode ? kPSUF : kPSUB, &p->C, &p->lds, mode)) return false;
     XParams& C = p->C;
     if (mode == 0 && (C.npx > 8 || C.npy > 8)) return false;
-    if (mode == 1 && P.K > kXP + 2) return false;
     // forward: a ring of eight buffers (16 planes) + the parked dot products [kXP + 2][tile] + the loss partials
     if (mode == 1) p->lds = (size_t)16 * kPSUF * 256 + (size_t)(kXP + 2) * kTH * kTW * 4 + 256;
     // backward: the ring of four (PEA_ZM_NB=3: three) two-plane buffers + the waves' blocks of prefetched g / a values
@@ -43,23 +42,29 @@ bool plan(const KParams& P, int mode, ZPlan* out) {
     p->M.zseg = (P.Z + nseg - 1) / nseg;
     p->M.nseg = (P.Z + p->M.zseg - 1) / p->M.zseg;
     C.zrun = p->M.nseg;
-    // blocks of 16 x 2 tile columns (256 rows x 64 pixels; an XCD's 32 workgroups = one block): measured best of nineteen shapes on
-    // the 24 x 1024^2 sub-volume -- 8 x 4 (the squarest) is 9 % / 3 % slower for forward / backward: with 32 tile columns across,
-    // every XCD then walks its own block ROW in step with the others, 512 KB apart (profiles/r4_zm_blocks.txt)
-    C.zgy = env().zblk_y > 0 ? env().zblk_y : 16;
-    C.zgx = env().zblk_x > 0 ? env().zblk_x : 2;
+    // The walk.  Round 6 (profiles/r6_sup.txt, same process): the eight XCDs' blocks of a round as ONE super-block -- blocks of 4 x 8
+    // tile columns (64 rows x 256 pixels), the XCDs' eight blocks stacked in y (512 rows x 256 pixels per round; march_tile) -- 1.511 +
+    // 1.776 ms against 1.546 + 1.805 for round 4's walk (every XCD on its own contiguous range of 16 x 2 blocks: best of nineteen
+    // shapes then, profiles/r4_zm_blocks.txt; 8 x 4 is 3 % slower either way).  Super-blocks are padded to the tile grid, so they are
+    // taken only where the grid is a whole number of them (else XCDs would idle: 16 x 2 stacked eight high on 64 tile rows takes 2x).
+    const int sx = E.zm_sup < 0 ? 1 : E.zm_sup;
+    const bool sup_ok = sx == 1 || sx == 2 || sx == 4 || sx == 8;
+    C.zgy = E.zblk_y > 0 ? E.zblk_y : 16;
+    C.zgx = E.zblk_x > 0 ? E.zblk_x : 2;
     const long long nt = cols * p->M.nseg;
     if (nt > 0x7fffff00LL) return false;
     C.ntiles = (int)nt;
     C.tiles_per_xcd = (C.ntiles + kXcd - 1) / kXcd;
-    const int sx = E.zm_sup;
-    if (sx == 1 || sx == 2 || sx == 4 || sx == 8) {  // the XCDs' blocks of a round side by side (xdma_tile's super-block walk)
-      C.sup_x = sx;
-      C.sup_y = kXcd / sx;
-      const long long nsx = (C.tiles_x + C.zgx * sx - 1) / (C.zgx * sx), nsy = (C.tiles_y + C.zgy * C.sup_y - 1) / (C.zgy * C.sup_y);
-      const long long per_xcd = (long long)P.B * nsx * nsy * C.zgy * C.zgx * p->M.nseg;
-      if (per_xcd * kXcd > 0x7fffff00LL) return false;
-      C.tiles_per_xcd = (int)per_xcd;
+    if (sup_ok) {
+      const int gy = E.zblk_y > 0 ? E.zblk_y : 4, gx = E.zblk_x > 0 ? E.zblk_x : 8, sy = kXcd / sx;
+      const bool whole = C.tiles_y % (gy * sy) == 0 && C.tiles_x % (gx * sx) == 0;
+      if (whole || E.zm_sup > 0) {  // (an explicit PEA_ZM_SUP: also on ragged grids -- the tests' padded super-blocks)
+        C.zgy = gy; C.zgx = gx; C.sup_x = sx; C.sup_y = sy;
+        const long long nsx = (C.tiles_x + gx * sx - 1) / (gx * sx), nsy = (C.tiles_y + gy * sy - 1) / (gy * sy);
+        const long long per_xcd = (long long)P.B * nsx * nsy * gy * gx * p->M.nseg;
+        if (per_xcd * kXcd > 0x7fffff00LL) return false;
+        C.tiles_per_xcd = (int)per_xcd;
+      }
     }
     return true;
   });

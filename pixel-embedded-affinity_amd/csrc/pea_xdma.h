@@ -645,7 +645,12 @@ __global__ __launch_bounds__(TH* TW, 4) void k_bwd_xdma(const KParams P, const X
       vx = __builtin_fmaf(-bl32(xB, pe, ezo + (unsigned)(2 * ps) * ecs), pn, G[ps].x) * sc;
       vy = __builtin_fmaf(-bl32(xB, pe, ezo + (unsigned)(2 * ps + 1) * ecs), pn, G[ps].y) * sc;
     }
-    if (OTHER && accum) { vx += old[ps].x; vy += old[ps].y; }
+    if (OTHER && accum) {
+      // the product is a rounded f32 BEFORE the sum (left alone the compiler contracts x * sc + old into one FMA): de then holds, bit
+      // for bit, what the two launches and an add over [B,D,...] give (tests/test_gpu_zmarch.py::test_ac3ac4_section_backward_runs_the_march)
+      asm volatile("" : "+v"(vx), "+v"(vy));
+      vx += old[ps].x; vy += old[ps].y;
+    }
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vx), dB, pe, ezo + (unsigned)(2 * ps) * ecs, AUXS);
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vy), dB, pe, ezo + (unsigned)(2 * ps + 1) * ecs, AUXS);
   }

@@ -34,27 +34,32 @@ _SIDE_STREAMS = {}
 
 
 class _side_stream(object):
-    """`with fork:` (fork = _side_stream(dev)) runs its launches on a second HIP stream of the device, forked from the
-    current stream on entry; `fork.join()`, called after the full-resolution kernels are enqueued on the main stream,
-    makes the main stream wait for them.  The deep-supervision scales are small grids (578 tiles at 272^2 down to 8 at 34^2):
-    one after the other on the full-resolution kernels' stream they cost their launch latencies, 150-200 us per
-    section; on their own stream they fill the CUs the big kernels leave idle.  Capturable in a HIP graph (fork / join
-    are stream waits).  PEA_SECTION_STREAMS=0 keeps everything on one stream."""
+    """fork = _side_stream(dev) forks a second HIP stream of the device from the current stream AT THIS POINT; `with fork:` runs
+    its launches there; `fork.join()`, called after the full-resolution kernels are enqueued on the main stream, makes the main
+    stream wait for them.  The deep-supervision scales are small grids (578 tiles at 272^2 down to 8 at 34^2): one after the other
+    on the full-resolution kernels' stream they cost their launch latencies, 150-200 us per section; on their own stream they fill
+    the CUs the big kernels leave idle.  Capturable in a HIP graph (fork / join are stream waits).  PEA_SECTION_STREAMS=0 keeps
+    everything on one stream.
+    Round 6: the fork point is the constructor, not `with`: the sections enqueue the full-resolution FORWARD first and the small
+    scales after it (the eager host needs 100-150 us to launch them -- profiles/r6_section3d_timeline_before.txt: the main stream's
+    first kernel started 156 us after the section did -- and the GPU now works on the long kernel meanwhile); forked at `with`, the
+    side stream would wait for that forward."""
 
     def __init__(self, dev):
         self.on = os.environ.get("PEA_SECTION_STREAMS", "1") != "0"
         self.dev = dev
+        if self.on:
+            self.main = torch.cuda.current_stream(self.dev)
+            side = _SIDE_STREAMS.get(self.dev.index)
+            if side is None:
+                side = _SIDE_STREAMS[self.dev.index] = torch.cuda.Stream(device=self.dev)
+            self.side = side
+            side.wait_stream(self.main)  # fork: everything the callers produced is ordered before the side work
 
     def __enter__(self):
         if not self.on:
             return self
-        self.main = torch.cuda.current_stream(self.dev)
-        side = _SIDE_STREAMS.get(self.dev.index)
-        if side is None:
-            side = _SIDE_STREAMS[self.dev.index] = torch.cuda.Stream(device=self.dev)
-        self.side = side
-        side.wait_stream(self.main)  # fork: everything the callers produced is ordered before the side work
-        self.ctx = torch.cuda.stream(side)
+        self.ctx = torch.cuda.stream(self.side)
         self.ctx.__enter__()
         return self
 
@@ -175,15 +180,7 @@ class _TensorSection(torch.autograd.Function):
             #      stencil), else the tiled two-phase kernel, else two launches and an add
             jx = ncall - 1
             small = []
-            fork = _side_stream(dev)
-            with fork:  # the deep-supervision scales, on their own stream beside the full-resolution pair
-                for j in range(1, jx):
-                    e_c = op._embedding_arg(embs[j], "embedding")
-                    # (the 1 / norm plane goes along wherever the cross backward takes the scale -- 272^2 down to 68^2 -- : round 4 kept
-                    #  the small scales on the tiled backward "because their grids are launch-sized"; measured in round 5 the cross
-                    #  backward is worth 36 us of the section, profiles/r5_section_small.txt.  No raw map: D = 16 reads none.)
-                    d, g, _, inv, raw = forward_one(j, e_c, None, False, 1)
-                    small.append(backward_one(j, d, e_c, None, g, inv, raw=raw))
+            fork = _side_stream(dev)  # (the fork point: the small scales wait for nothing this section launches)
             e0 = op._embedding_arg(embs[0], "embedding")
             ema_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e0.dtype)
             pair = forward_pair(e0, ema_c)
@@ -194,13 +191,24 @@ class _TensorSection(torch.autograd.Function):
                 d0, g0, pred, inv0, raw0 = forward_one(0, e0, None, True, 1)
                 dxx, gx, _, invx, rawx = forward_one(jx, e0, ema_c, False, 2 if inv0 is not None else 0)
                 inv_other = None if invx is None else invx[1]
+            with fork:  # the deep-supervision scales, on their own stream beside the full-resolution pair
+                for j in range(1, jx):
+                    e_c = op._embedding_arg(embs[j], "embedding")
+                    # (the 1 / norm plane goes along wherever the cross backward takes the scale -- 272^2 down to 68^2 -- : round 4 kept
+                    #  the small scales on the tiled backward "because their grids are launch-sized"; measured in round 5 the cross
+                    #  backward is worth 36 us of the section, profiles/r5_section_small.txt.  No raw map: D = 16 reads none.)
+                    d, g, _, inv, raw = forward_one(j, e_c, None, False, 1)
+                    small.append(backward_one(j, d, e_c, None, g, inv, raw=raw))
             de0 = torch.empty_like(e0)
             rc = L.pea_affinity_bwd_dual_ex(ctypes.byref(d0), op._ptr(e0), op._ptr(ema_c), op._ptr(g0), op._ptr(gx), op._ptr(inv0),
                                             op._ptr(inv_other), op._ptr(wdev[0:1]), op._ptr(wdev[jx:jx + 1]),
                                             op._ptr(de0), op._stream())
             if rc == _lib.E_UNSUPPORTED:
                 de0 = backward_one(0, d0, e0, None, g0, inv0, raw=raw0)
-                de0.add_(backward_one(jx, dxx, e0, ema_c, gx, invx, raw=rawx))
+                # the cross loss' gradient ADDED by its kernel (PEA_FLAG_ACCUMULATE_DE: the role-A cross backward, 2D and 3D) -- else a
+                # second buffer and an add over [B,D,...] (27 us of the 3D section, profiles/r6_section3d_timeline_before.txt)
+                if backward_one(jx, _accumulating(dxx), e0, ema_c, gx, invx, de=de0, raw=rawx) is None:
+                    de0.add_(backward_one(jx, dxx, e0, ema_c, gx, invx, raw=rawx))
             else:
                 _lib.check(rc, "pea_affinity_bwd_dual_ex")
             grads.append(de0)
@@ -214,6 +222,21 @@ class _TensorSection(torch.autograd.Function):
         return total, pred, losses
 
     backward = staticmethod(lambda ctx, dtotal, _dp, _dl: _section_backward(ctx, dtotal))
+
+
+_ACC_DESC = {}
+
+
+def _accumulating(d):
+    """the memoised descriptor d with PEA_FLAG_ACCUMULATE_DE set (pea_affinity_bwd_ex2 then adds to de)"""
+    hit = _ACC_DESC.get(id(d))
+    if hit is None or hit[0] is not d:
+        if len(_ACC_DESC) > 256:
+            _ACC_DESC.clear()
+        da = type(d).from_buffer_copy(d)
+        da.flags |= _lib.FLAG_ACCUMULATE_DE
+        hit = _ACC_DESC[id(d)] = (d, da)  # (d is kept: its id cannot be reused while the entry lives)
+    return hit[1]
 
 
 def _section_total(L, rows, wdev, ncall):
@@ -297,7 +320,7 @@ def _section_backward(ctx, dtotal):
     with op._on_device(dev):
         # one launch rescales every gradient by grad_output (and returns untouched when that is exactly 1); pea.backward(loss) seeds
         # the backward with ITS cached ones-scalar: recognised by identity, the launch is skipped
-        if any(dtotal is one for one in op._ONES.values()):
+        if any(dtotal is one for one in tuple(op._ONES.values())):  # (a snapshot: another thread's pea.backward may add a device's entry)
             return (None, None, None, None) + tuple(g if ctx.needs_input_grad[4 + k] else None for k, g in enumerate(grads))
         dl = dtotal.to(device=dev, dtype=torch.float32).contiguous()
         bufs = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
@@ -436,18 +459,32 @@ def _specs_3d(embedding_mode, affs0_weight):
     return specs, [1.0] * 6
 
 
-def ac3ac4_loss_section(embedding, emds, ema_embedding, target, weightmap, downs, criterion, embedding_mode=5, affs0_weight=1):
+def ac3ac4_loss_section(embedding, emds, ema_embedding, target, weightmap, downs, criterion, embedding_mode=5, affs0_weight=1,
+                        finish_pred=False):
     """scripts_ac3ac4/main.py:219-231: full-resolution self + EMA cross loss (norm1 or norm5) and four norm1 losses on
     the deep-supervision heads; downs = (down1, .., down4) packed [B, 6, z, y, x] = (target[:3] | weight[3:]),
     paired emd1<->down4 .. emd4<->down1 as in the reference.  Returns (loss, pred before the border fill / relu);
     call finish_pred_3d_(pred) after backward (:233-237).  One autograd node with the fused criterion and a detached
-    EMA operand, the call-by-call composition otherwise."""
+    EMA operand, the call-by-call composition otherwise.
+
+    finish_pred=True: pred comes back FINISHED -- the reference's next five statements (:233-237: border fill of the three shift-1
+    channels, F.relu) applied: where no backward kernel reads the raw map (the reference's training crops) the forward clamps the
+    map on the way out and only the border slices are touched afterwards (pea_fill_border_relu with relu = 0: 5 us instead of a pass
+    over [B,12,Z,Y,X]); else one fill + relu pass.  Do not call finish_pred_3d_ again (it would be harmless: both are idempotent)."""
     if getattr(criterion, 'pea_fused', False) and not ema_embedding.requires_grad and embedding_mode in (1, 5):
         specs, weights = _specs_3d(embedding_mode, affs0_weight)
         tensors = [(target, weightmap, None)] + [(d[:, :3], d[:, 3:], None) for d in downs[::-1]]
+        clamped = False
+        if finish_pred and embedding.is_cuda:
+            # (the z-march backward of large volumes reads the forward's RAW map: pea_cross_supported mode 3)
+            clamped = not op.cross_supported(op.make_desc(specs[0], op._embedding_arg(embedding, "embedding")), 3)
+            specs[0].relu = clamped
         loss, pred, _ = _TensorSection.apply(specs, weights, ema_embedding, tensors, embedding, *emds)
+        if finish_pred:
+            fill_border_relu_(pred, shift=1, relu=not clamped)
         return loss, pred
-    return ac3ac4_loss_section_composed(embedding, emds, ema_embedding, target, weightmap, downs, criterion, embedding_mode, affs0_weight)
+    loss, pred = ac3ac4_loss_section_composed(embedding, emds, ema_embedding, target, weightmap, downs, criterion, embedding_mode, affs0_weight)
+    return loss, (finish_pred_3d_(pred.detach().clone()) if finish_pred else pred)
 
 
 def ac3ac4_loss_section_from_labels(embedding, emds, ema_embedding, labels, label_downs, criterion, embedding_mode=5, affs0_weight=1):
@@ -591,13 +628,7 @@ class _LabelsSection(torch.autograd.Function):
             #      same weights, same own pixel), else two launches, the second accumulating onto the first's gradient
             jx = ncall - 1
             small = []
-            fork = _side_stream(dev)
-            with fork:  # the deep-supervision scales, on their own stream beside the full-resolution pair
-                for j in range(1, jx):
-                    e_c, lab, d, wtab, counts, cb = prep(j)
-                    de = torch.empty_like(e_c)
-                    one(j, e_c, None, lab, d, wtab, counts, cb, None, de, False)
-                    small.append(de)
+            fork = _side_stream(dev)  # (the fork point)
             e0, lab0, d0, wtab0, counts0, cb0 = prep(0)
             ema_c = op._embedding_arg(ema_embedding, "ema_embedding").to(e0.dtype)
             dx_ = op.make_desc(specs[jx], e0)
@@ -612,6 +643,12 @@ class _LabelsSection(torch.autograd.Function):
                 one(jx, e0, ema_c, lab0, dx_, wtab0, counts0, cb0, None, de0, True)
             else:
                 _lib.check(rc, "pea_affinity_fwd_bwd_labels_dual")
+            with fork:  # the deep-supervision scales, on their own stream beside the full-resolution pair (enqueued behind it: _side_stream)
+                for j in range(1, jx):
+                    e_c, lab, d, wtab, counts, cb = prep(j)
+                    de = torch.empty_like(e_c)
+                    one(j, e_c, None, lab, d, wtab, counts, cb, None, de, False)
+                    small.append(de)
             grads = [de0] + small
             fork.join()
             losses = rows[:, 0]

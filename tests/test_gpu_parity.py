@@ -678,6 +678,27 @@ def test_fill_border_relu_matches_reference_statements(pkg, dev):
         pkg.relu_(torch.zeros(1, 2, 4, 4))
 
 
+@pytest.mark.parametrize("shape,shift,relu", [((2, 12, 6, 20, 24), 1, True), ((2, 12, 6, 20, 24), 2, True), ((1, 3, 5, 9, 16), 1, True),
+                                              ((2, 12, 6, 20, 24), 1, False), ((1, 12, 7, 12, 20), 3, False), ((2, 3, 4, 10, 22), 1, True),
+                                              ((1, 2, 4, 6, 8), 1, False), ((1, 1, 4, 6, 8), 2, True)])
+def test_fill_border_relu_kernel_forms(pkg, dev, shape, shift, relu):
+    """round 6: the three forms of pea_fill_border_relu -- four voxels per lane (X % 4 == 0), the border slices alone (relu = 0: what a
+    map clamped by the forward still needs), one voxel per lane (any X) -- against scripts_ac3ac4/main.py:233-237 in torch, for the
+    channel counts < 3 the statements still make sense for"""
+    torch.manual_seed(sum(shape) + shift)
+    pred = torch.randn(*shape, device=dev)
+    ref = pred.clone()
+    K = shape[1]
+    if K > 1:
+        ref[:, 1, :, :shift, :] = ref[:, 1, :, shift:shift * 2, :]
+    if K > 2:
+        ref[:, 2, :, :, :shift] = ref[:, 2, :, :, shift:shift * 2]
+    ref[:, 0, :shift, :, :] = ref[:, 0, shift:shift * 2, :, :]
+    if relu:
+        ref = torch.nn.functional.relu(ref)
+    assert torch.equal(pkg.fill_border_relu_(pred, shift=shift, relu=relu), ref)
+
+
 def _section_inputs(synth, offsets, nb_half, B, D, H, W, seed):
     e, t, w, m = synth.synth_inputs_2d(B, D, H, W, offsets, seed)
     ema = synth.synth_embedding((B, D, H, W), seed + 1)
@@ -1572,6 +1593,33 @@ def test_ac3ac4_loss_section_matches_reference_golden(pkg, dev, name, path):
     assert relmax(emb.grad.cpu().numpy(), g["grad_emb"]) < GRAD_RTOL
     for j in range(1, 5):
         assert relmax(emds[j - 1].grad.cpu().numpy(), g["grad_emd%d" % j]) < GRAD_RTOL, j
+
+
+@pytest.mark.parametrize("name", ["gsection_ac3ac4_norm1", "gsection_ac3ac4_norm5"])
+def test_ac3ac4_loss_section_finished_pred(pkg, dev, name):
+    """round 6: ac3ac4_loss_section(finish_pred=True) -- the forward clamps the map, a border-only launch fills the three slices, the
+    cross loss' gradient is ADDED by its kernel (no second buffer) -- against the reference's run (scripts_ac3ac4/main.py:219-237)
+    and, bit for bit, against the unfinished section + finish_pred_3d_"""
+    g = load_golden(name)
+    crit = pkg.WeightedMSE()
+    downs = [cu(g["down%d" % j], dev) for j in range(1, 5)]
+
+    def run(finish):
+        emb = cu(g["emb"], dev).requires_grad_(True)
+        emds = [cu(g["emd%d" % j], dev).requires_grad_(True) for j in range(1, 5)]
+        loss, pred = pkg.ac3ac4_loss_section(emb, emds, cu(g["ema"], dev), cu(g["target"], dev), cu(g["weight"], dev), downs, crit,
+                                             embedding_mode=int(g["mode"]), affs0_weight=1, finish_pred=finish)
+        loss.backward()
+        if not finish:
+            pred = pkg.finish_pred_3d_(pred.clone())
+        return loss.detach(), pred, emb.grad, [e.grad for e in emds]
+
+    l1, p1, g1, s1 = run(True)
+    l0, p0, g0, s0 = run(False)
+    assert torch.equal(l1, l0) and torch.equal(p1, p0) and torch.equal(g1, g0) and all(torch.equal(a, b) for a, b in zip(s1, s0))
+    assert abs(l1.item() - float(g["total"])) <= 1e-5 * abs(float(g["total"]))
+    assert np.abs(p1.cpu().numpy() - g["pred"]).max() < AFFS_ATOL
+    assert relmax(g1.cpu().numpy(), g["grad_emb"]) < GRAD_RTOL
 
 
 def test_validation_section_matches_reference_golden(pkg, dev):
