@@ -609,8 +609,8 @@ def in_step_batches_ms(fwd, bwd, iters, nb=N_BATCHES):
 # switches that select kernels (csrc/pea_k_direct.hip env_make) + the library override: with one of them set, another kernel than the
 # profiled one may be running.  (Round-4 advice: the bare PEA_ prefix also caught PEA_BENCH_EXTRA, PEA_STEPS, ... and silently nulled
 # the roofline's traffic field.)
-KERNEL_SWITCHES = ("PEA_FORCE_DIRECT", "PEA_FWD_XDMA", "PEA_BWD_XDMA", "PEA_LABELS_DUAL", "PEA_FWD_WG3", "PEA_INFER_XDMA", "PEA_BWD_PF", "PEA_BOX",
-                   "PEA_H16_HW", "PEA_ZMARCH", "PEA_ZSEG", "PEA_ZM_NB", "PEA_ZM_SUP", "PEA_BOXM", "PEA_ZBLK_Y", "PEA_ZBLK_X", "PEA_BWD_REV",
+KERNEL_SWITCHES = ("PEA_FORCE_DIRECT", "PEA_FWD_XDMA", "PEA_BWD_XDMA", "PEA_FWD_WG3", "PEA_BWD_PF", "PEA_BOX",
+                   "PEA_H16_HW", "PEA_ZMARCH", "PEA_ZSEG", "PEA_ZM_SUP", "PEA_BOXM", "PEA_ZBLK_Y", "PEA_ZBLK_X", "PEA_BWD_REV",
                    "PEA_FWD_DUAL", "PEA_HIP_LIB")
 
 

@@ -126,12 +126,12 @@ int pea_desc_validate(const PeaDesc *desc);
 size_t pea_workspace_bytes(const PeaDesc *desc);
 int pea_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
 
-/* Re-read the PEA_* environment switches (they are read once, at the first call): PEA_FORCE_DIRECT, PEA_FWD_XDMA, PEA_BWD_XDMA,
- * PEA_LABELS_DUAL, PEA_FWD_WG3, PEA_INFER_XDMA, PEA_BWD_PF, PEA_BOX, PEA_BOXM, PEA_H16_HW, PEA_ZMARCH, PEA_ZSEG, PEA_ZM_NB, PEA_ZM_SUP,
- * PEA_ZBLK_Y / _X, PEA_BWD_REV, PEA_FWD_DUAL -- A/B and debugging switches (csrc/pea_host.h says what each does); tests that change
- * one call this.  Memoised launch plans are dropped with it.  The switch set is replaced as a whole (no half-written set is ever
- * seen), but one entry point may read it more than once: a launch that runs CONCURRENTLY with a reload may mix the two sets.
- * Call it between launches (tests and A/B runs do). */
+/* Re-read the PEA_* environment switches (they are read once, at the first call) -- fifteen A/B and debugging switches, each a default-ON
+ * selector with its fallback kernels or a walk parameter (csrc/pea_host.h says what each does): PEA_FORCE_DIRECT, PEA_FWD_XDMA,
+ * PEA_BWD_XDMA, PEA_FWD_WG3, PEA_BWD_PF, PEA_BOX, PEA_BOXM, PEA_H16_HW, PEA_ZMARCH, PEA_ZSEG, PEA_ZM_SUP, PEA_ZBLK_Y / _X, PEA_BWD_REV,
+ * PEA_FWD_DUAL; tests that change one call this.  Memoised launch plans are dropped with it.  The switch set is replaced as a whole (no
+ * half-written set is ever seen), but one entry point may read it more than once: a launch that runs CONCURRENTLY with a reload may
+ * mix the two sets.  Call it between launches (tests and A/B runs do). */
 void pea_reload_env(void);
 
 /* Inference: affs[B,K,Z,Y,X] only.  e_other may be NULL. */
@@ -276,7 +276,9 @@ int pea_gen_targets(const PeaDesc *desc, const int32_t *labels, unsigned flags, 
  *   target_i(q) = [label(q) == label(q + o_i)] (flags as pea_gen_targets), mask_i(q) = [q + o_i inside] with
  *   PEA_TGT_MASK_INSIDE else 1, weight_i(q) = target ? wtab[b][i][0] : wtab[b][i][1]
  * evaluated inside the kernel: results equal (to rounding) to pea_gen_targets + pea_affinity_fwd + pea_affinity_bwd.
- * Returns PEA_E_UNSUPPORTED when no fused kernel covers the descriptor (then use those three). */
+ * Returns PEA_E_UNSUPPORTED when no fused kernel covers the descriptor (then use those three).
+ * Label ids: any int32 but INT32_MIN (-2^31), which the LDS-staged kernels use as their outside-the-image marker (a label image that
+ * holds it gets it compared as "outside"; the Python layer's range check rejects it). */
 int pea_label_weights(const PeaDesc *desc, const int32_t *labels, unsigned flags, float *wtab, void *workspace,
                       size_t workspace_bytes, void *stream);
 int pea_affinity_fwd_bwd_labels(const PeaDesc *desc, const void *e, const void *e_other, const int32_t *labels,

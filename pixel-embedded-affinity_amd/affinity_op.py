@@ -111,14 +111,15 @@ def cross_supported(d, mode):
     microseconds; the march kernels' answer depends on the device's CU count, and nn.DataParallel replicas call this from one thread
     per device: round-4 advice)"""
     key = (id(d), mode, torch.cuda.current_device())
-    r = _CROSS_OK.get(key)
-    if r is None:
+    hit = _CROSS_OK.get(key)
+    if hit is None or hit[1] is not d:  # (the entry keeps its descriptor alive: an id cannot be reused while it is a key)
         r = bool(_lib.lib().pea_cross_supported(ctypes.byref(d), mode))
         with _CROSS_LOCK:
             if len(_CROSS_OK) > 2048:
                 _CROSS_OK.clear()
-            _CROSS_OK[key] = r
-    return r
+            _CROSS_OK[key] = (r, d)
+        return r
+    return hit[0]
 
 
 _lib._RELOAD_HOOKS.append(_CROSS_OK.clear)  # pea_cross_supported depends on the PEA_* switches
@@ -469,7 +470,7 @@ def activation_flags(activation):
         raise ValueError("activation must be one of %s (or FLAG_* bits), got %r" % (sorted(k for k in ACTIVATIONS if k), activation))
 
 
-_RANGE_MSG = "label ids must fit int32%s: relabel the segmentation first"
+_RANGE_MSG = "label ids must fit int32 (and not be -2^31, the kernels' outside marker)%s: relabel the segmentation first"
 _RANGE_CHECKS = collections.deque()  # (event, pinned flag) of range checks of GPU label tensors that have not been read back yet
 _RANGE_LOCK = threading.Lock()       # the reference drives replicas from nn.DataParallel threads: the queue is shared
 
@@ -501,12 +502,12 @@ def _labels_int32(labels):
         l64 = labels.view(torch.int64) if labels.dtype == torch.uint64 else labels  # ids >= 2^63 come out negative: flagged too
         if not labels.is_cuda:
             lo, hi = int(l64.min()), int(l64.max())
-            if lo < -2 ** 31 or hi >= 2 ** 31:
+            if lo <= -2 ** 31 or hi >= 2 ** 31:  # (-2^31 itself is the kernels' outside-the-image marker: include/pea.h)
                 raise ValueError(_RANGE_MSG % (" (got %d .. %d)" % (lo, hi)))
         elif not torch.cuda.is_current_stream_capturing():
             check_label_ranges(block=False)
             top = l64 >> 31  # 0 or -1 for an id inside int32
-            bad = ((top != 0) & (top != -1)).any()
+            bad = (((top != 0) & (top != -1)) | (l64 == -2 ** 31)).any()  # (-2^31: the kernels' outside-the-image marker)
             # the flag starts out False (never garbage) and the event is recorded on the stream the copy was queued on: the current
             # stream of the LABELS' device, which need not be the current device
             host = torch.zeros((), dtype=torch.bool).pin_memory()

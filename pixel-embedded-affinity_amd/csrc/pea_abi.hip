@@ -265,7 +265,7 @@ int pea_cross_supported(const PeaDesc* desc, int backward) {
   if (backward == 4) return xdma_cross_supported(P, desc->dtype, 4);  // ... with a detached second operand?
   if (backward == 3) {  // does pea_affinity_bwd_ex2 READ the raw affinity map for this descriptor (self loss)?
     if (zmarch_bwd_supported(P, desc->dtype)) return 1;
-    return (env().bwd_pf && !(P.flags & kActMask) && (P.D > 16 || env().bwd_pf == 2) && xdma_cross_supported(P, desc->dtype, 1)) ? 1 : 0;
+    return (env().bwd_pf && !(P.flags & kActMask) && P.D > 16 && xdma_cross_supported(P, desc->dtype, 1)) ? 1 : 0;
   }
   if (backward == 1 && zmarch_bwd_supported(P, desc->dtype)) return 1;
   if (xdma_cross_supported(P, desc->dtype, backward)) return 1;

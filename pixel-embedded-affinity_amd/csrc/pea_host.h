@@ -3,7 +3,9 @@
 // The library is built from several .hip files compiled in parallel (one per kernel family; a single file took 1 m 47 s):
 //   pea_abi.hip        the extern "C" entry points of include/pea.h: validation, descriptor -> KParams, dispatch
 //   pea_k_xdma.hip     LDS-DMA cross kernels (pea_xdma.h): the training forward / backward of axis-aligned stencils, f32 storage
-//   pea_k_xdma_h.hip   the same for f16 storage (pea_xdma_h16.h) and the projection-first backward (pea_xdma_pf.h)
+//   pea_k_xdma_h.hip   the same for f16 storage (pea_xdma_h16.h)
+//   pea_k_xdma_hq.hip  the f16 backward on producer / consumer waves (pea_xdma_hq.h)
+//   pea_k_xdma_pf.hip  the projection-first backward for f32 storage, D = 32 / 64 (pea_xdma_pf.h)
 //   pea_k_zmarch.hip   z-march kernels (pea_zmarch.h): 3D volumes with axis-aligned stencils that step along z (norm5 / norm1)
 //   pea_k_box.hip      unit-box stencils (pea_box.h): the 26-neighbourhood of a 3D volume through an LDS-DMA ring of 3-plane boxes
 //   pea_k_tiled.hip    LDS-tiled box kernels (pea_tiled.h, pea_chunked.h): what the cross / box / march kernels do not take -- diagonal
@@ -27,9 +29,7 @@ struct Env {
   int force_direct;   // PEA_FORCE_DIRECT=1: global-memory kernels only
   int fwd_xdma;       // PEA_FWD_XDMA=0: no LDS-DMA forward
   int bwd_xdma;       // PEA_BWD_XDMA=0: no LDS-DMA backward
-  int labels_dual;    // PEA_LABELS_DUAL=0: pea_affinity_fwd_bwd_labels_dual reports PEA_E_UNSUPPORTED
-  int infer_xdma;     // PEA_INFER_XDMA=0: inference (affs only) on k_fwd_tiled / the chunked kernels instead of the LDS-DMA forward
-  int bwd_pf;         // PEA_BWD_PF=0: never the projection-first backward (pea_xdma_pf.h); 2: also at D = 16 (where it loses)
+  int bwd_pf;         // PEA_BWD_PF=0: never the projection-first backward (pea_xdma_pf.h: D = 32 / 64)
   int fwd_wg3;        // PEA_FWD_WG3=0: the 2-workgroups-per-CU forward
   int h16_hw;         // PEA_H16_HW: the f16 kernels' working buffer.  0: f32 (packed-f32 gather); 1: f16 [pixel][2 halves] behind an LDS-DMA
                       // ring; 2 (default): as 1, and the backward of small crosses at D = 32 / 64 on producer / consumer waves (pea_xdma_hq.h)
@@ -37,7 +37,6 @@ struct Env {
   int zmarch;         // PEA_ZMARCH=0: 3D volumes with z offsets on the tile-per-plane cross kernels (pea_xdma.h) instead of the z-march
                       //   kernels (pea_zmarch.h); 2: the march also on volumes with fewer tile columns than CUs
   int boxm;           // PEA_BOXM=0: the unit-box backward per (z, tile) (pea_box.h) instead of marching (pea_boxm.h)
-  int zm_nb;          // PEA_ZM_NB=3: the z-march backward with a ring of three buffers instead of four (5 % slower once the waits count loads only)
   int zm_sup;         // PEA_ZM_SUP=sx (1, 2, 4, 8): the z-march kernels' eight XCD blocks of a round lie side by side, (8 / sx) x sx, as one
                       //   super-block (march_tile), blocks of 4 x 8 tile columns unless PEA_ZBLK_* says otherwise; 0: every XCD walks its own
                       //   contiguous range of 16 x 2 blocks (rounds 4-5); default (-1): sx = 1 where the tile grid is a whole number of super-blocks
@@ -46,9 +45,8 @@ struct Env {
   int bwd_rev;        // PEA_BWD_REV=0: the 2D cross backward walks every XCD's tile range first tile first.  Default 1: LAST tile first -- what
                       //   the forward touched last (the bottom rows of every image: e read, g and 1 / norm written) is what the backward
                       //   asks for first, and the next forward starts where the backward ended (-1.7 % / -0.8 %, profiles/r5_switch1.txt)
-  int fwd_dual;       // PEA_FWD_DUAL=0: pea_affinity_fwd_dual_ex reports PEA_E_UNSUPPORTED (the caller runs the two forwards); 4 (default): the
-                      //   one-launch pair on a ring of two four-plane buffers handed over in HALVES (e pair, ema pair), two workgroups per CU;
-                      //   2: the same ring handed over buffer by buffer (+2.6 %); 3: a ring of three, one workgroup per CU (+21 %)
+  int fwd_dual;       // PEA_FWD_DUAL=0: pea_affinity_fwd_dual_ex reports PEA_E_UNSUPPORTED (the caller runs the two forwards); default: the
+                      //   one-launch pair on a ring of two four-plane buffers handed over in HALVES (e pair, ema pair), two workgroups per CU
 };
 const Env& env();
 void env_reload();          // pea_reload_env(): tests that change a switch call it
@@ -162,11 +160,11 @@ bool xdma_h_bwd_other(const KParams& P, const void* e, const void* e_other, cons
 bool xdma_hq_bwd_self(const KParams& P, const void* x, const float* inv, const float* g, const float* affs, const float* dl, void* dx,
                       hipStream_t s);
 bool xdma_pf_bwd_self(const KParams& P, const float* x, const float* inv, const float* g, const float* affs, const float* dl, float* dx,
-                      hipStream_t s);  // the projection-first backward, f32 storage (pea_k_xdma_h.hip)
+                      hipStream_t s);  // the projection-first backward, f32 storage (pea_k_xdma_pf.hip)
 bool xdma_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* affs,
                     const float* dl, float* de, bool accumulate, hipStream_t s);  // affs: the raw cosine map or null (read at D > 16)
 bool xdma_pf_bwd_other(const KParams& P, const float* e, const float* e_other, const float* inv2, const float* g, const float* affs,
-                       const float* dl, float* de, hipStream_t s);  // D = 32 / 64, projection first (pea_k_xdma_h.hip)
+                       const float* dl, float* de, hipStream_t s);  // D = 32 / 64, projection first (pea_k_xdma_pf.hip)
 // the full-resolution pair (self loss + detached-EMA cross loss on the same target / weight / mask) as ONE forward launch
 // (pea_xdma_dual.h): A = the self loss' arguments (affs, gout, st, inv_out: the own plane), A2 = the cross loss' (eo = ema, gout,
 // st, inv_out: the second operand's plane); P2 differs from P in lambda only.  true = launched.

@@ -35,21 +35,18 @@ const Env* env_make() {
   e->force_direct = env_int("PEA_FORCE_DIRECT", 0);
   e->fwd_xdma = env_int("PEA_FWD_XDMA", 1);
   e->bwd_xdma = env_int("PEA_BWD_XDMA", 1);
-  e->labels_dual = env_int("PEA_LABELS_DUAL", 1);
   e->fwd_wg3 = env_int("PEA_FWD_WG3", 1);
-  e->infer_xdma = env_int("PEA_INFER_XDMA", 1);
   e->bwd_pf = env_int("PEA_BWD_PF", 1);
   e->box = env_int("PEA_BOX", 1);
   e->h16_hw = env_int("PEA_H16_HW", 2);
   e->zmarch = env_int("PEA_ZMARCH", 1);
   e->zseg = env_int("PEA_ZSEG", 0);
-  e->zm_nb = env_int("PEA_ZM_NB", 4);
   e->boxm = env_int("PEA_BOXM", 1);
   e->zm_sup = env_int("PEA_ZM_SUP", -1);
   e->zblk_y = env_int("PEA_ZBLK_Y", 0);
   e->zblk_x = env_int("PEA_ZBLK_X", 0);
   e->bwd_rev = env_int("PEA_BWD_REV", 1);
-  e->fwd_dual = env_int("PEA_FWD_DUAL", 4);
+  e->fwd_dual = env_int("PEA_FWD_DUAL", 1);
   return e;
 }
 }  // namespace

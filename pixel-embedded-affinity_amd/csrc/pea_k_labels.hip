@@ -98,7 +98,7 @@ bool labels_step(const KParams& P, int dtype, const void* e, const void* e_other
 bool labels_step_dual(const KParams& P, const KParams& P2, int dtype, const void* e, const void* ema, const int32_t* labels,
                       const float* wtab, unsigned lflags, float* affs, LossState* st, LossState* st2, const float* dl,
                       const float* dl2, void* de, hipStream_t s) {
-  if ((P.D != 16 && P.D != 32) || env().force_direct || !env().labels_dual) return false;
+  if ((P.D != 16 && P.D != 32) || env().force_direct) return false;
 #define PEA_LD(T_, D_) try_fused_labels_dual<T_, D_>(P, P2, (const T_*)e, (const T_*)ema, labels, wtab, lflags, affs, st, st2, dl, dl2, (T_*)de, s)
   if (P.D == 16) return dtype == PEA_F16 ? PEA_LD(__half, 16) : PEA_LD(float, 16);
   return dtype == PEA_F16 ? PEA_LD(__half, 32) : PEA_LD(float, 32);

@@ -89,11 +89,9 @@ bool bwd_self(const KParams& P, const float* x, const float* inv, const float* g
 bool xdma_fwd_self(const KParams& P, const FwdArgs& A, hipStream_t s) {
   if (!env().fwd_xdma || env().force_direct || A.eo != A.e) return false;
   if (A.dtype == PEA_F16) {  // f16 storage: pea_xdma_h16.h
-    if (!A.train && !env().infer_xdma) return false;
     return xdma_h_fwd_self(P, A, s);  // pea_k_xdma_h.hip
   }
   if (!A.train) {
-    if (!env().infer_xdma) return false;
     if (P.D == 16) return fwd_self<16, false>(P, A, s);
     if (P.D == 32) return fwd_self<32, false>(P, A, s);
     if (P.D == 64) return fwd_self<64, false>(P, A, s);
@@ -132,13 +130,9 @@ bool xdma_fwd_dual(const KParams& P, const KParams& P2, const FwdArgs& A, const 
     const size_t lds = (size_t)(NB_ == 3 ? 3 : 2) * 4 * kXdmaPSUF * 256;                               \
     PEA_LAUNCH(kern, grid, blk, lds, s, P, X.C, e, A.t, A.w, A.m, A.affs, A.gout, A.st, A.inv_out, DA) \
   }
-  if (env().fwd_dual == 3) {
-    if (crop) PEA_XFD(true, 3) else PEA_XFD(false, 3)
-  } else if (env().fwd_dual == 2) {
-    if (crop) PEA_XFD(true, 2) else PEA_XFD(false, 2)
-  } else {
-    if (crop) PEA_XFD(true, 4) else PEA_XFD(false, 4)
-  }
+  // (NB = 4: the ring of two four-plane buffers handed over in halves; the whole-buffer hand-off -- NB = 2, +2.6 % -- and the ring of
+  //  three at one workgroup per CU -- NB = 3, +21 % -- were switches until round 6 and are no longer compiled: EXPERIMENTS.md)
+  if (crop) PEA_XFD(true, 4) else PEA_XFD(false, 4)
 #undef PEA_XFD
   return true;
 }
@@ -250,10 +244,10 @@ bool xdma_bwd_self(const KParams& P, const float* x, const float* inv, const flo
                    hipStream_t s) {
   if (!inv || !env().bwd_xdma || env().force_direct) return false;
   // (D = 16 keeps k_bwd_xdma: with G in 16 registers and the own pixel kept there is no second read to save, and the stores
-  //  inside the chunk loop cost more than they give: 137 against 94-107 us at the bench shape; PEA_BWD_PF=2 forces it)
-  if (affs && env().bwd_pf && !(P.flags & kActMask) && (P.D > 16 || env().bwd_pf == 2)) {
+  //  inside the chunk loop cost more than they give: 137 against 94-107 us at the bench shape)
+  if (affs && env().bwd_pf && !(P.flags & kActMask) && P.D > 16) {
     bool done = false;
-    done = xdma_pf_bwd_self(P, x, inv, g, affs, dl, dx, s);  // pea_k_xdma_h.hip
+    done = xdma_pf_bwd_self(P, x, inv, g, affs, dl, dx, s);  // pea_k_xdma_pf.hip
     if (done) return true;
   }
   if (P.D == 16) return bwd_self<16>(P, x, inv, g, dl, dx, s);

@@ -21,15 +21,15 @@ bool plan(const KParams& P, int mode, ZPlan* out) {
   // (the segmentation depends on the CURRENT device's CU count: part of the key -- a thread that serves devices of different sizes must
   //  not be handed the other device's plan; round-4 advice)
   const Env& E = env();
-  return cache.get(P, mode * 4096 + E.zm_nb * 1024 + E.zmarch * 64 + E.zseg + (device_cus() << 13) + (E.zm_sup << 24), out, [&](ZPlan* p) {
-    p->nb = E.zm_nb == 3 ? 3 : 4;
+  return cache.get(P, mode * 4096 + E.zmarch * 64 + E.zseg + (device_cus() << 13) + (E.zm_sup << 24), out, [&](ZPlan* p) {
+    p->nb = 4;  // (a ring of three -- k_bwd_zm<.., 3>, a switch until round 6 -- is 5 % slower once the waits count loads only)
     if (!env().zmarch || !plan_zmarch(P, &p->M)) return false;
     if (!plan_xdma(P, kTH, kTW, mode ? kPSUF : kPSUB, &p->C, &p->lds, mode)) return false;
     XParams& C = p->C;
     if (mode == 0 && (C.npx > 8 || C.npy > 8)) return false;
     // forward: a ring of eight buffers (16 planes) + the parked dot products [kXP + 2][tile] + the loss partials
     if (mode == 1) p->lds = (size_t)16 * kPSUF * 256 + (size_t)(kXP + 2) * kTH * kTW * 4 + 256;
-    // backward: the ring of four (PEA_ZM_NB=3: three) two-plane buffers + the waves' blocks of prefetched g / a values
+    // backward: the ring of four two-plane buffers + the waves' blocks of prefetched g / a values
     else p->lds = (size_t)2 * p->nb * kPSUB * 256 + (size_t)(kTH * kTW / 64) * kZmG * 256;
     const long long cols = (long long)P.B * C.tiles_per_plane;
     // one workgroup per CU: whole columns when there are enough of them for two rounds, else segments of >= 8 planes
@@ -81,7 +81,6 @@ bool plan(const KParams& P, int mode, ZPlan* out) {
 // forward / inference of the self loss on a 3D volume (f32, D = 16, CROP_ZERO, every z offset in {-1 .. -4}); true = launched
 bool zmarch_fwd(const KParams& P, const FwdArgs& A, hipStream_t s) {
   if (env().force_direct || !env().fwd_xdma || A.eo != A.e || A.dtype != PEA_F32) return false;
-  if (!A.train && !env().infer_xdma) return false;
   const float* e = (const float*)A.e;
   if (misaligned(e, 16) || misaligned(A.t, 16) || misaligned(A.w, 16) || misaligned(A.affs, 16) || misaligned(A.gout, 16) ||
       misaligned(A.m, 4) || misaligned(A.inv_out, 4))
@@ -118,13 +117,8 @@ bool zmarch_bwd(const KParams& P, const float* x, const float* inv, const float*
   ZPlan Z;
   if (!plan(P, 0, &Z)) return false;
   const dim3 grid((unsigned)(Z.C.tiles_per_xcd * kXcd)), blk(kTH * kTW);
-  if (Z.nb == 3) {  // (the ring depth the plan sized its LDS for, not a second look at the switch: round-4 advice)
-    constexpr auto kern = k_bwd_zm<kTH, kTW, kPSUB, 3>;
-    PEA_LAUNCH(kern, grid, blk, Z.lds, s, P, Z.C, Z.M, x, inv, g, affs, dl, dx)
-  } else {
-    constexpr auto kern = k_bwd_zm<kTH, kTW, kPSUB, 4>;
-    PEA_LAUNCH(kern, grid, blk, Z.lds, s, P, Z.C, Z.M, x, inv, g, affs, dl, dx)
-  }
+  constexpr auto kern = k_bwd_zm<kTH, kTW, kPSUB, 4>;  // (the ring depth the plan sized its LDS for)
+  PEA_LAUNCH(kern, grid, blk, Z.lds, s, P, Z.C, Z.M, x, inv, g, affs, dl, dx)
   return true;
 }
 

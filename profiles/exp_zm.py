@@ -76,8 +76,6 @@ if os.environ.get("STENCIL") == "n26":
     pkg._lib.set_switch("PEA_ZBLK_Y", None); pkg._lib.set_switch("PEA_ZBLK_X", None)
     sys.exit(0)
 if os.environ.get("AB", "1") == "1":  # the same box, the same buffers: the alternatives
-    pkg._lib.set_switch("PEA_ZM_NB", "3"); run("bwd", "(PEA_ZM_NB=3: ring of three buffers)")
-    pkg._lib.set_switch("PEA_ZM_NB", None); run("bwd", "(ring of four again)")
     for gy, gx in [tuple(int(v) for v in b.split('x')) for b in os.environ.get('BLOCKS', '4x8,16x2,2x16,32x1,1x32,4x4,8x8,16x4').split(',')]:  # the block of tile columns an XCD marches
         pkg._lib.set_switch("PEA_ZBLK_Y", gy); pkg._lib.set_switch("PEA_ZBLK_X", gx)
         run("fwd", "(block %d x %d tile columns)" % (gy, gx)); run("bwd", "(block %d x %d)" % (gy, gx))

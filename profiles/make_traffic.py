@@ -8,7 +8,7 @@ import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.path.join(ROOT, "profiles", "traffic.json")
+PATH = os.environ.get("PEA_TRAFFIC_OUT") or os.path.join(ROOT, "profiles", "traffic.json")  # (round 6: the passes write a scratch file; it replaces the record only when all of them succeeded)
 
 
 def sha16():
@@ -33,6 +33,8 @@ def mean_counter(d, name):
 
 key = sys.argv[1]
 (fetch, fdur), (write, _) = mean_counter(sys.argv[2], "FETCH_SIZE"), mean_counter(sys.argv[3], "WRITE_SIZE")
+if not fetch or not write:
+    sys.exit("make_traffic.py %s: no FETCH_SIZE / WRITE_SIZE rows under %s / %s (a pass failed)" % (key, sys.argv[2], sys.argv[3]))
 doc = json.load(open(PATH)) if os.path.exists(PATH) else {}
 sha = sha16()
 if doc.get("src_sha16") != sha:  # entries of other sources are void

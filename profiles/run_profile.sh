@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-section $@"
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-section --no-configs $@"  # (--no-configs: the other configurations launch kernels of the same names)
 timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python3 $ROOT/bench.py $ARGS > $OUT/stats.log 2>&1
 timeout -k 5 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o r -- python3 $ROOT/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
 timeout -k 5 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o r -- python3 $ROOT/bench.py $ARGS > $OUT/pmc_write.log 2>&1

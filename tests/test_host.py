@@ -130,6 +130,9 @@ def test_label_ids_are_range_checked_before_the_int32_cast(pkg):
     assert ok.dtype == torch.int32 and ok.tolist() == [[0, 5, 2 ** 31 - 1]]
     with pytest.raises(ValueError, match="fit int32"):
         pkg.affinity_op._labels_int32(torch.tensor([[0, 2 ** 31]], dtype=torch.int64))
+    with pytest.raises(ValueError, match="outside marker"):  # -2^31: what the LDS-staged label kernels mark "outside the image" with
+        pkg.affinity_op._labels_int32(torch.tensor([[0, -2 ** 31]], dtype=torch.int64))
+    assert pkg.affinity_op._labels_int32(torch.tensor([[-2 ** 31 + 1]], dtype=torch.int64)).tolist() == [[-2 ** 31 + 1]]
 
 
 def test_labels_in_path_refuses_offsets_as_long_as_the_image(pkg):
