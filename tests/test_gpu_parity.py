@@ -366,9 +366,12 @@ def test_wide_label_ids_are_range_checked_without_a_host_sync(pkg, dev):
     raises there, a good tensor passes through unchanged; uint64 ids >= 2^63 are caught as well"""
     op = pkg.affinity_op
     pkg.check_label_ranges()
-    good = torch.tensor([[0, 5, 2 ** 31 - 1, -2 ** 31]], dtype=torch.int64, device=dev)
-    assert op._labels_int32(good).tolist() == [[0, 5, 2 ** 31 - 1, -2 ** 31]]
+    good = torch.tensor([[0, 5, 2 ** 31 - 1, -2 ** 31 + 1]], dtype=torch.int64, device=dev)
+    assert op._labels_int32(good).tolist() == [[0, 5, 2 ** 31 - 1, -2 ** 31 + 1]]
     pkg.check_label_ranges()
+    op._labels_int32(torch.tensor([[3, -2 ** 31]], dtype=torch.int64, device=dev))  # -2^31: the LDS-staged kernels' outside-the-image marker
+    with pytest.raises(ValueError, match="outside marker"):
+        pkg.check_label_ranges()
     op._labels_int32(torch.tensor([[0, 2 ** 31]], dtype=torch.int64, device=dev))  # does not raise here ...
     with pytest.raises(ValueError, match="fit int32"):
         pkg.check_label_ranges()                                                  # ... but here
