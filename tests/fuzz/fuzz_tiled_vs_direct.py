@@ -65,7 +65,10 @@ for it in range(ncase):
     d_go = float((a[4] - b[4]).abs().max() / b[4].abs().max().clamp_min(1e-30)) if mode == 2 else 0.0
     for k, v in (("affs", d_affs), ("loss", d_loss), ("grad", d_grad), ("grad_o", d_go)):
         worst[k] = max(worst[k], v)
-    ok = d_affs < 1e-5 and d_loss < 1e-5 and d_grad < tol_g and d_go < tol_g and bool(torch.isfinite(a[3]).all())
+    # f16 gradients in the DENORMAL range (a full-volume normaliser makes them ~1e-6): the two kernels' f32 results round to neighbouring
+    # halves, and one denormal ulp (2^-24) is then 0.6 % of the largest value (round-6 soak, seed 601 case 156: 5.6e-3) -- allow 1.5 ulps
+    ulp_ok = f16 and float((a[3] - b[3]).abs().max()) <= 1.5 * 2.0 ** -24 and (mode != 2 or float((a[4] - b[4]).abs().max()) <= 1.5 * 2.0 ** -24)
+    ok = d_affs < 1e-5 and d_loss < 1e-5 and ((d_grad < tol_g and d_go < tol_g) or ulp_ok) and bool(torch.isfinite(a[3]).all())
     if not ok:
         bad += 1
         orc = ge.load_oracle(); orc.build()  # the referee (test infrastructure, only on a disagreement)

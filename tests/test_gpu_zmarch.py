@@ -293,3 +293,41 @@ def test_ac3ac4_section_backward_runs_the_march(pkg, dev, orc, synth, monkeypatc
     g_self0, _ = standalone_grads()
     assert not torch.equal(g_self0, g_self)  # (the check above can tell the two kernels apart)
     assert relmax(g_self0.cpu().numpy(), g_self.cpu().numpy()) < 2e-5
+
+
+def test_ac3ac4_section_finished_pred_where_the_march_reads_the_raw_map(pkg, dev, orc, synth):
+    """round 6: ac3ac4_loss_section(finish_pred=True) on a volume large enough for the default dispatch to march (512 tile columns): the
+    z-march backward reads the forward's RAW map, so the forward must NOT clamp it -- the section then finishes the map with one fill +
+    relu pass instead; every output bit for bit the unfinished section's + finish_pred_3d_, and the march is what ran (the gradient
+    equals the stand-alone losses' with the march on)"""
+    crit = pkg.WeightedMSE()
+    B, D = 1, 16
+    shapes = [(8, 256, 512), (8, 128, 256), (8, 64, 128), (8, 32, 64), (8, 16, 32)]
+    sh5, sh1 = orc.norm_offsets(NORM5), orc.norm_offsets([1, 1, 1])
+    g = torch.Generator(device=dev).manual_seed(77)
+    embs = [torch.randn((B, D) + s, generator=g, device=dev) for s in shapes]
+    ema = torch.randn((B, D) + shapes[0], generator=g, device=dev)
+    t0 = (torch.rand((B, 12) + shapes[0], generator=g, device=dev) < 0.6).float()
+    w0 = torch.rand((B, 12) + shapes[0], generator=g, device=dev) + 0.5
+    downs = [torch.cat([(torch.rand((B, 3) + s, generator=g, device=dev) < 0.6).float(), torch.rand((B, 3) + s, generator=g, device=dev) + 0.5], dim=1)
+             for s in shapes[1:]]  # down1 .. down4
+    spec = pkg.AffinitySpec(3, sh5, None, pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
+    assert _march_on(pkg, spec, embs[0])
+
+    def run(finish):
+        x = [e.clone().requires_grad_(True) for e in embs]
+        loss, pred = pkg.ac3ac4_loss_section(x[0], x[1:][::-1], ema, t0, w0, downs, crit, embedding_mode=5, finish_pred=finish)
+        loss.backward()
+        if not finish:
+            pred = pkg.finish_pred_3d_(pred.clone())
+        return loss.detach(), pred, [v.grad for v in x]
+
+    l1, p1, g1 = run(True)
+    l0, p0, g0 = run(False)
+    assert torch.equal(l1, l0) and torch.equal(p1, p0) and all(torch.equal(a, b) for a, b in zip(g1, g0))
+    assert float(p1.min()) >= 0.0 and torch.equal(p1[:, 0, 0], p1[:, 0, 1]) and torch.equal(p1[:, 1, :, 0], p1[:, 1, :, 1])
+    a = embs[0].clone().requires_grad_(True)
+    pkg.embedding_loss_norm5(a, t0, w0, crit)[0].backward()
+    b = embs[0].clone().requires_grad_(True)
+    pkg.ema_embedding_loss_norm5(b, ema, t0, w0, crit)[0].backward()
+    assert torch.equal(g1[0], a.grad + b.grad)
