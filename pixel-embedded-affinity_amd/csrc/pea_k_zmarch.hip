@@ -42,12 +42,13 @@ bool plan(const KParams& P, int mode, ZPlan* out) {
     p->M.zseg = (P.Z + nseg - 1) / nseg;
     p->M.nseg = (P.Z + p->M.zseg - 1) / p->M.zseg;
     C.zrun = p->M.nseg;
-    // The walk.  Round 6 (profiles/r6_sup.txt, same process): the eight XCDs' blocks of a round as ONE super-block -- blocks of 4 x 8
-    // tile columns (64 rows x 256 pixels), the XCDs' eight blocks stacked in y (512 rows x 256 pixels per round; march_tile) -- 1.511 +
-    // 1.776 ms against 1.546 + 1.805 for round 4's walk (every XCD on its own contiguous range of 16 x 2 blocks: best of nineteen
-    // shapes then, profiles/r4_zm_blocks.txt; 8 x 4 is 3 % slower either way).  Super-blocks are padded to the tile grid, so they are
-    // taken only where the grid is a whole number of them (else XCDs would idle: 16 x 2 stacked eight high on 64 tile rows takes 2x).
-    const int sx = E.zm_sup < 0 ? 1 : E.zm_sup;
+    // The walk.  Round 6 (profiles/r6_sup.txt, r6_sup_wide*.txt: 60 combinations, same process): the eight XCDs' blocks of a round as ONE
+    // super-block (march_tile) -- blocks of 8 x 2 tile columns (128 rows x 64 pixels), the XCDs 4 high x 2 wide: 512 rows x 128 pixels per
+    // super-block, two super-blocks per XCD in flight -- 1.422 + 1.743 ms against 1.546 + 1.805 for round 4's walk (every XCD on its own
+    // contiguous range of 16 x 2 blocks).  Every arrangement whose super-block is 512 rows tall and 32 .. 128 pixels wide lands within
+    // 1 % of it (4 x 2 / 4 x 1 / 4 x 4 stacked eight high, 16 x 1 two high); 256 pixels wide +1.7 %; 16 x 2 side by side +5 %.
+    // Super-blocks are padded to the tile grid, so they are taken only where the grid is a whole number of them (else XCDs would idle).
+    const int sx = E.zm_sup < 0 ? 2 : E.zm_sup;
     const bool sup_ok = sx == 1 || sx == 2 || sx == 4 || sx == 8;
     C.zgy = E.zblk_y > 0 ? E.zblk_y : 16;
     C.zgx = E.zblk_x > 0 ? E.zblk_x : 2;
@@ -56,7 +57,7 @@ bool plan(const KParams& P, int mode, ZPlan* out) {
     C.ntiles = (int)nt;
     C.tiles_per_xcd = (C.ntiles + kXcd - 1) / kXcd;
     if (sup_ok) {
-      const int gy = E.zblk_y > 0 ? E.zblk_y : 4, gx = E.zblk_x > 0 ? E.zblk_x : 8, sy = kXcd / sx;
+      const int gy = E.zblk_y > 0 ? E.zblk_y : 8, gx = E.zblk_x > 0 ? E.zblk_x : 2, sy = kXcd / sx;
       const bool whole = C.tiles_y % (gy * sy) == 0 && C.tiles_x % (gx * sx) == 0;
       if (whole || E.zm_sup > 0) {  // (an explicit PEA_ZM_SUP: also on ragged grids -- the tests' padded super-blocks)
         C.zgy = gy; C.zgx = gx; C.sup_x = sx; C.sup_y = sy;
