@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kBoxTH* kBoxTW, 4) void k_fwd_box(const KParams P, 
   float* sN = (float*)(lds + kBoxSN);
   float* s_part = (float*)(lds + kBoxSP);
   int tile, b, z, y0, x0;
-  if (!xdma_tile<TH, TW, BParams>(C, P, tile, b, z, y0, x0)) return;
+  if (!march_tile<TH, TW, BParams>(C, P, tile, b, z, y0, x0)) return;
   const size_t S = (size_t)P.S;
   const rsrc_t xB = mkbuf(e + (size_t)b * D_T * S);
   const unsigned ecs = (unsigned)P.S * 4u;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kBoxTH* kBoxTW, 6) void k_bwd_box(const KParams P, 
   extern __shared__ f4 lds4[];
   char* lds = (char*)lds4;
   int tile, b, z, y0, x0;
-  if (!xdma_tile<TH, TW, BParams>(C, P, tile, b, z, y0, x0)) return;
+  if (!march_tile<TH, TW, BParams>(C, P, tile, b, z, y0, x0)) return;
   const size_t S = (size_t)P.S;
   const rsrc_t xB = mkbuf(xt + (size_t)b * D_T * S), dB = mkbuf(dx + (size_t)b * D_T * S);
   const rsrc_t iB = mkbuf(invp + (size_t)b * S);

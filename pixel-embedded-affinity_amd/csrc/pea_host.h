@@ -39,7 +39,8 @@ struct Env {
   int boxm;           // PEA_BOXM=0: the unit-box backward per (z, tile) (pea_box.h) instead of marching (pea_boxm.h)
   int zm_sup;         // PEA_ZM_SUP=sx (1, 2, 4, 8): the z-march kernels' eight XCD blocks of a round lie side by side, (8 / sx) x sx, as one
                       //   super-block (march_tile), blocks of 8 x 2 tile columns unless PEA_ZBLK_* says otherwise; 0: every XCD walks its own
-                      //   contiguous range of 16 x 2 blocks (rounds 4-5); default (-1): sx = 2 where the tile grid is a whole number of super-blocks
+                      //   contiguous range of blocks (rounds 4-5; also for the unit-box kernels); default (-1): the measured best per kernel
+                      //   where the tile grid is a whole number of super-blocks (march 4 x 2 XCDs of 8 x 2 blocks, k_fwd_box 4 x 2 of 2 x 8)
   int zseg;           // PEA_ZSEG=n: planes per segment of a tile column (0: whole columns where there are enough of them)
   int zblk_y, zblk_x; // PEA_ZBLK_Y / PEA_ZBLK_X: tiles per block of the z-fastest walk of 3D volumes (0: the default 4 x 2; Y < 0: plane-major)
   int bwd_rev;        // PEA_BWD_REV=0: the 2D cross backward walks every XCD's tile range first tile first.  Default 1: LAST tile first -- what

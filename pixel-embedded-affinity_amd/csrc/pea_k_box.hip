@@ -11,6 +11,18 @@ namespace {
 
 struct BPlan { BParams C; };
 
+// the XCDs' blocks of a round as one super-block (pea_xdma.h march_tile), (8 / sx) x sx: taken where the tile grid is a whole number
+// of super-blocks (they are padded to the grid: XCDs would idle otherwise)
+void set_super_blocks(const KParams& P, BParams* C, int sx) {
+  if (C->zrun < 1 || !(sx == 1 || sx == 2 || sx == 4 || sx == 8)) return;
+  const int sy = kXcd / sx;
+  if (C->tiles_y % (C->zgy * sy) || C->tiles_x % (C->zgx * sx)) return;
+  const long long per_xcd = (long long)P.B * (C->tiles_y / (C->zgy * sy)) * (C->tiles_x / (C->zgx * sx)) * C->zgy * C->zgx * C->zrun;
+  if (per_xcd * kXcd > 0x7fffff00LL) return;
+  C->sup_x = sx; C->sup_y = sy;
+  C->tiles_per_xcd = (int)per_xcd;
+}
+
 bool plan(const KParams& P, BParams* out) {
   static thread_local PlanCache<BPlan, 8> cache;
   BPlan t;
@@ -19,6 +31,17 @@ bool plan(const KParams& P, BParams* out) {
         if (env().zblk_y > 0) p->C.zgy = env().zblk_y;
         if (env().zblk_x > 0) p->C.zgx = env().zblk_x;
         if (env().zblk_y < 0) p->C.zrun = 0;
+        // Round 6 (profiles/r6_sup_n26*.txt, 24 x 1024^2, three rounds in one process): blocks of 2 x 8 tiles with the XCDs' blocks of a
+        // round as one super-block, 4 high x 2 wide (march_tile) -- k_fwd_box 2.600 against 2.692 ms for every XCD on its own range of
+        // 4 x 2 blocks; taken where the tile grid is a whole number of super-blocks (small volumes keep the 4 x 2 blocks)
+        if (env().zm_sup != 0 && env().zblk_y == 0 && env().zblk_x == 0 && p->C.zrun > 1) {
+          BParams T = p->C;
+          T.zgy = 2; T.zgx = 8;
+          set_super_blocks(P, &T, 2);
+          if (T.sup_x) p->C = T;
+        } else if (env().zm_sup > 0) {
+          set_super_blocks(P, &p->C, env().zm_sup);
+        }
         return true;
       }))
     return false;
@@ -74,16 +97,17 @@ static bool box_bwd_march(const KParams& P, const BParams& C0, const float* x, c
   M.zseg = (P.Z + nseg - 1) / nseg;
   M.nseg = (P.Z + M.zseg - 1) / M.zseg;
   BParams C = C0;
-  // xdma_tile's "z" is the segment; an XCD's 32 workgroups march through one block of 4 x 8 tile columns (measured on the
+  // xdma_tile's "z" is the segment; an XCD's 32 workgroups march through blocks of 2 x 8 tile columns (round 4 measured on the
   // 24 x 1024^2 sub-volume: 4 x 8 and 4 x 4 1.82 ms, 8 x 4 and 16 x 4 1.88, 16 x 2 -- the norm5 march's best -- 1.91, 32 x 1 2.25;
   // the region here has a halo of 1 - 4 pixels, not 27: what matters is that the blocks of the eight XCDs are spread out)
   C.zrun = M.nseg;
-  C.zgy = env().zblk_y > 0 ? env().zblk_y : 4;
+  C.zgy = env().zblk_y > 0 ? env().zblk_y : 2;
   C.zgx = env().zblk_x > 0 ? env().zblk_x : 8;
   const long long nt = cols * M.nseg;
   if (nt > 0x7fffff00LL) return false;
   C.ntiles = (int)nt;
   C.tiles_per_xcd = (C.ntiles + kXcd - 1) / kXcd;
+  C.sup_x = C.sup_y = 0;  // (round 6: 2 x 8 blocks 1.935 ms, 4 x 8 1.96, super-blocks no better: profiles/r6_sup_n26b.txt)
   const dim3 grid((unsigned)(C.tiles_per_xcd * kXcd)), blk(kBoxTH * kBoxTW);
   constexpr auto kern = k_bwd_boxm;
   if (allow_lds<kern>(kBmLds)) return false;

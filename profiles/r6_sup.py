@@ -13,6 +13,10 @@ op, L = pkg.affinity_op, pkg._lib.lib()
 P = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 offs = aff.axis_offsets_3d(aff.NORM5_SHIFTS)
+SUPVARS = ["PEA_ZM_SUP"]
+if os.environ.get("STENCIL") == "n26":  # the 26-neighbourhood: k_fwd_box (tile per plane) and k_bwd_boxm (march), their walks by PEA_BOX_SUP / PEA_BOXM_SUP
+    offs = [[dz, dy, dx] for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dz, dy, dx) != (0, 0, 0)]
+    SUPVARS = ["PEA_BOX_SUP", "PEA_BOXM_SUP"]
 Z, Y, X = (int(v) for v in os.environ.get("DIMS", "24,1024,1024").split(","))
 B, K = int(os.environ.get("B", "1")), len(offs)
 iters = int(os.environ.get("ITERS", "8"))
@@ -46,7 +50,7 @@ for rnd in range(int(os.environ.get("ROUNDS", "2"))):
     for blk in os.environ.get("BLOCKS", "16x2,8x4,4x8").split(","):
         gy, gx = (int(v) for v in blk.split("x"))
         for sup in os.environ.get("SUPS", "0,8,4,2,1").split(","):
-            pkg._lib.set_switch("PEA_ZBLK_Y", gy); pkg._lib.set_switch("PEA_ZBLK_X", gx); pkg._lib.set_switch("PEA_ZM_SUP", sup)
+            pkg._lib.set_switch("PEA_ZBLK_Y", gy); pkg._lib.set_switch("PEA_ZBLK_X", gx); [pkg._lib.set_switch(v, sup) for v in SUPVARS]
             in_step(2)
             f, b = in_step(iters)
             chk = (float(lossv[0]), float(dE.double().abs().sum()))

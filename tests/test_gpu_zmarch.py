@@ -331,3 +331,39 @@ def test_ac3ac4_section_finished_pred_where_the_march_reads_the_raw_map(pkg, dev
     b = embs[0].clone().requires_grad_(True)
     pkg.ema_embedding_loss_norm5(b, ema, t0, w0, crit)[0].backward()
     assert torch.equal(g1[0], a.grad + b.grad)
+
+
+def test_unit_box_walks_change_no_bit(pkg, dev, orc, synth, monkeypatch):
+    """round 6: k_fwd_box / k_bwd_box walk blocks of 2 x 8 tiles with the XCDs' blocks as one super-block (4 high x 2 wide) where the tile
+    grid is a whole number of them (here 8 x 16 tiles = exactly one), k_bwd_boxm blocks of 2 x 8 tile columns; PEA_ZM_SUP=0 = rounds 4-5's
+    walks.  Loss, map and gradient bit for bit between the walks (march and per-tile backward), and against the oracle"""
+    B, D, Z, Y, X = 1, 16, 3, 128, 512
+    offs = [[dz, dy, dx] for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dz, dy, dx) != (0, 0, 0)]
+    e, t, w = synth.synth_inputs_3d(B, D, Z, Y, X, offs, 404)
+    spec = pkg.AffinitySpec(3, offs, None, pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED)
+    T, W = cu(t, dev), cu(w, dev)
+
+    def run():
+        x = cu(e, dev).requires_grad_(True)
+        loss, affs, _ = pkg.affinity_op.FusedAffinityMSE.apply(x, None, T, W, None, spec)
+        loss.backward()
+        return loss.detach().clone(), affs.clone(), x.grad.clone()
+
+    res = {}
+    for sup, march in (("-1", "2"), ("0", "2"), ("-1", "0"), ("0", "0")):
+        monkeypatch.setenv("PEA_ZM_SUP", sup)
+        monkeypatch.setenv("PEA_BOXM", "1" if march == "2" else "0")
+        monkeypatch.setenv("PEA_ZMARCH", "2")
+        res[(sup, march)] = run()
+    for k in (("0", "2"), ("-1", "0"), ("0", "0")):
+        a, b = res[("-1", "2")], res[k]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), k
+    assert torch.equal(res[("-1", "2")][2], res[("0", "2")][2]) and torch.equal(res[("-1", "0")][2], res[("0", "0")][2])
+    d = orc.make_desc(B, D, [Z, Y, X], offs, None, pkg._lib.BORDER_CROP_ZERO, pkg._lib.NORM_CROPPED, ndim=3)
+    o_affs, o_loss = orc.c_fwd(d, e, None, t, w, None)
+    o_grad, _ = orc.c_bwd(d, e, None, t, w, None)
+    got = res[("-1", "2")]
+    assert np.abs(got[1].cpu().numpy() - o_affs).max() < AFFS_ATOL
+    assert abs(got[0].item() - o_loss[0]) <= LOSS_RTOL * o_loss[0]
+    assert relmax(got[2].cpu().numpy(), o_grad) < GRAD_RTOL
+    assert relmax(res[("-1", "0")][2].cpu().numpy(), o_grad) < GRAD_RTOL
