@@ -958,7 +958,12 @@ def main():
         # the roofline uses the in-step durations (kt["fwd"] includes the loss reduction launch, as the step does)
         in_step_times_ms(fwd, bwd, 10)
         kt["fwd"], kt["bwd"], kspread = in_step_batches_ms(fwd, bwd, max(20, min(args.steps, 200)))
-        section = None if args.no_section else section_us()
+        section = None
+        if not args.no_section:
+            try:
+                section = section_us()
+            except Exception as ex:  # noqa: BLE001 -- an extra field: the headline line must not be lost to it
+                section = {"error": repr(ex)[:300]}
         section3d = None
         if not args.no_section:
             try:
